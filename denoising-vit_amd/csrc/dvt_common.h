@@ -1,0 +1,36 @@
+// Shared host/device helpers for libdvt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dvt_hip.h"
+
+#define DVT_CHECK_LAUNCH()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+static inline int dvt_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Wave = 64 lanes on CDNA4; all reductions below are written for exactly that.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Fire-and-forget fp32 global atomic add (global_atomic_add_f32, no return value).
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- internal cross-TU entry points (not part of the C ABI) ----
+int dvt_grid_fwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ridx,
+                     const float* params, float* enc, int n, hipStream_t stream);
+int dvt_grid_bwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ridx,
+                     const float* d_enc, float* d_params, uint32_t* touched, int n,
+                     hipStream_t stream);
+int dvt_loss_launch(const float* F, const float* G, const int32_t* g_idx, int lattice,
+                    const float* Hres, const float* raw_rows, float* d_pred, float* d_hres,
+                    float* d_G, float* row_sums, int n, int c, float grad_scale, hipStream_t s);

@@ -1,0 +1,202 @@
+// The fused per-image fit loop: every launch of one Adam step is enqueued from native code,
+// with no host<->device traffic inside the loop (the index stream is resident, there is no
+// range-assert sync, losses are reduced on the device only on logging steps).
+//
+// Reference: main_img_denoising.py:67-89 (denoise_an_image inner loop), with the models of
+// neural_feature_field.py:40-49 and offline_denoiser.py:62-140.  Quirks reproduced
+// (SURVEY.md Q1-Q5): gradients reach Adam scaled by 1024; dense Adam incl. weight decay on
+// untouched grid entries; per-tensor step counts (G stops, h starts at the switch);
+// phase 2 iff step > int(freeze_after * num_iters).
+//
+// Arena layout (float offsets, each tensor padded to a multiple of 256 floats so that one
+// Adam wave-iteration never straddles tensors and the touched bitmap words line up):
+//   [ grid | W1 | b1 | W2 | b2 | G | Wh1 | bh1 | Wh2 | bh2 | Wh3 | bh3 ]
+// phase 1 steps the contiguous prefix [grid .. G], phase 2 steps [grid .. b2] and [Wh1 .. bh3].
+#include <math.h>
+
+#include "dvt_common.h"
+
+namespace {
+
+inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
+
+struct Work {
+  float *enc, *h1, *F, *raw, *dF, *dh1, *denc, *rows, *r1, *r2, *Hres, *dH, *dr2, *dr1;
+};
+
+int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
+  const int64_t B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
+  const int64_t E = (int64_t)c->grid.n_levels * c->grid.n_features;
+  int64_t o = 0;
+  auto take = [&](int64_t n) {
+    float* p = base ? base + o : nullptr;
+    o += up256(n);
+    return p;
+  };
+  Work t;
+  t.enc = take(B * E);
+  t.h1 = take(B * H);
+  t.F = take(B * C);
+  t.raw = take(B * C);
+  t.dF = take(B * C);
+  t.dh1 = take(B * H);
+  t.denc = take(B * E);
+  t.rows = take(B * 8);
+  t.r1 = take(B * R);
+  t.r2 = take(B * R);
+  t.Hres = take(B * C);
+  t.dH = take(B * C);
+  t.dr2 = take(B * R);
+  t.dr1 = take(B * R);
+  if (w) *w = t;
+  return o;
+}
+
+int check_cfg(const DvtFitConfig* c) {
+  if (!c) return DVT_E_BADARG;
+  if (c->feat_dim <= 0 || (c->feat_dim & 3) || c->feat_dim > 1024) return DVT_E_BADARG;
+  if (c->hidden <= 0 || (c->hidden & 3) || c->res_hidden <= 0 || (c->res_hidden & 3))
+    return DVT_E_BADARG;
+  if (c->lattice <= 0 || c->n_rows <= 0 || c->batch <= 0 || c->num_iters <= 0) return DVT_E_BADARG;
+  if (c->grid.n_features != 8 || c->grid.n_levels < 1 || c->grid.n_levels > DVT_MAX_LEVELS)
+    return DVT_E_BADARG;
+  if (c->off_grid != 0) return DVT_E_BADARG;  // bitmap word <-> arena chunk correspondence
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dvt_fit_layout(DvtFitConfig* c) {
+  if (!c) return DVT_E_BADARG;
+  c->off_grid = 0;
+  int rc = check_cfg(c);
+  if (rc) return rc;
+  const int64_t C = c->feat_dim, H = c->hidden, R = c->res_hidden;
+  const int64_t E = (int64_t)c->grid.n_levels * c->grid.n_features;
+  int64_t o = 0;
+  c->off_grid = o; o += up256((int64_t)c->grid.n_entries_total * c->grid.n_features);
+  c->off_w1 = o;   o += up256(H * E);
+  c->off_b1 = o;   o += up256(H);
+  c->off_w2 = o;   o += up256(C * H);
+  c->off_b2 = o;   o += up256(C);
+  c->off_G = o;    o += up256((int64_t)c->lattice * C);
+  c->off_wh1 = o;  o += up256(R * C);
+  c->off_bh1 = o;  o += up256(R);
+  c->off_wh2 = o;  o += up256(R * R);
+  c->off_bh2 = o;  o += up256(R);
+  c->off_wh3 = o;  o += up256(C * R);
+  c->off_bh3 = o;  o += up256(C);
+  c->arena_floats = o;
+  return 0;
+}
+
+extern "C" int64_t dvt_fit_workspace_floats(const DvtFitConfig* c) {
+  if (check_cfg(c)) return -1;
+  return carve(c, nullptr, nullptr);
+}
+
+extern "C" int dvt_field_infer(const DvtFitConfig* c, const float* params, const float* xy,
+                               float* out, float* workspace, int n, void* stream) {
+  int rc = check_cfg(c);
+  if (rc) return rc;
+  if (!params || !xy || !out || !workspace || n < 0) return DVT_E_BADARG;
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int E = c->grid.n_levels * c->grid.n_features;
+  float* enc = workspace;
+  float* h1 = workspace + up256((int64_t)n * E);
+  rc = dvt_grid_fwd_idx(&c->grid, xy, nullptr, params + c->off_grid, enc, n, s);
+  if (rc) return rc;
+  rc = dvt_linear_fwd(enc, params + c->off_w1, params + c->off_b1, h1, n, c->hidden, E, 1, s);
+  if (rc) return rc;
+  return dvt_linear_fwd(h1, params + c->off_w2, params + c->off_b2, out, n, c->feat_dim,
+                        c->hidden, 0, s);
+}
+
+extern "C" int dvt_fit_run(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin,
+                           int step_end, void* stream) {
+  int rc = check_cfg(c);
+  if (rc) return rc;
+  if (!b || !b->feat || !b->xy || !b->idx || !b->params || !b->adam_m || !b->adam_v ||
+      !b->grads || !b->touched || !b->workspace || !b->h_lr)
+    return DVT_E_BADARG;
+  if (step_begin < 0 || step_end > c->num_iters || step_begin > step_end) return DVT_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  Work w;
+  carve(c, b->workspace, &w);
+  const int B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
+  const int E = c->grid.n_levels * c->grid.n_features;
+  float* P = b->params;
+  float* Gd = b->grads;
+
+#define DVT_TRY(x)         \
+  do {                     \
+    int rc__ = (x);        \
+    if (rc__) return rc__; \
+  } while (0)
+
+  for (int step = step_begin; step < step_end; ++step) {
+    const int32_t* ridx = b->idx + (size_t)step * B;
+    const bool phase2 = step > c->switch_step;
+    const bool use_res = phase2 && c->enable_residual;
+    const bool log = b->losses != nullptr &&
+                     ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
+
+    // ---- forward ----
+    DVT_TRY(dvt_gather_rows(b->feat, ridx, w.raw, B, C, 0, s));
+    DVT_TRY(dvt_grid_fwd_idx(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, B, s));
+    DVT_TRY(dvt_linear_fwd(w.enc, P + c->off_w1, P + c->off_b1, w.h1, B, H, E, 1, s));
+    DVT_TRY(dvt_linear_fwd(w.h1, P + c->off_w2, P + c->off_b2, w.F, B, C, H, 0, s));
+    if (use_res) {
+      DVT_TRY(dvt_linear_fwd(w.raw, P + c->off_wh1, P + c->off_bh1, w.r1, B, R, C, 1, s));
+      DVT_TRY(dvt_linear_fwd(w.r1, P + c->off_wh2, P + c->off_bh2, w.r2, B, R, R, 1, s));
+      DVT_TRY(dvt_linear_fwd(w.r2, P + c->off_wh3, P + c->off_bh3, w.Hres, B, C, R, 0, s));
+    }
+    // ---- loss + d(pred), G gradient scattered in the same pass while G still trains ----
+    DVT_TRY(dvt_loss_launch(w.F, P + c->off_G, ridx, c->lattice, use_res ? w.Hres : nullptr, w.raw,
+                            w.dF, use_res ? w.dH : nullptr, phase2 ? nullptr : Gd + c->off_G,
+                            w.rows, B, C, (float)c->grad_scale, s));
+    if (log) DVT_TRY(dvt_loss_reduce(w.rows, b->losses + (size_t)step * 8, B, C, use_res, s));
+    // ---- backward: field MLP -> encoding -> hash grid ----
+    DVT_TRY(dvt_linear_bwd(w.dF, w.h1, P + c->off_w2, Gd + c->off_w2, Gd + c->off_b2, w.dh1, w.h1,
+                           B, C, H, s));
+    DVT_TRY(dvt_linear_bwd(w.dh1, w.enc, P + c->off_w1, Gd + c->off_w1, Gd + c->off_b1, w.denc,
+                           nullptr, B, H, E, s));
+    DVT_TRY(dvt_grid_bwd_idx(&c->grid, b->xy, ridx, w.denc, Gd + c->off_grid, b->touched, B, s));
+    if (use_res) {
+      DVT_TRY(dvt_linear_bwd(w.dH, w.r2, P + c->off_wh3, Gd + c->off_wh3, Gd + c->off_bh3, w.dr2,
+                             w.r2, B, C, R, s));
+      DVT_TRY(dvt_linear_bwd(w.dr2, w.r1, P + c->off_wh2, Gd + c->off_wh2, Gd + c->off_bh2, w.dr1,
+                             w.r1, B, R, R, s));
+      DVT_TRY(dvt_linear_bwd(w.dr1, w.raw, P + c->off_wh1, Gd + c->off_wh1, Gd + c->off_bh1,
+                             nullptr, nullptr, B, R, C, s));
+    }
+    // ---- Adam (dense) + zero_grad ----
+    DvtAdamArgs a{};
+    a.beta1 = c->beta1;
+    a.beta2 = c->beta2;
+    a.eps = c->eps;
+    a.weight_decay = c->weight_decay;
+    a.sparse_end = c->off_w1;
+    const double lr = b->h_lr[step];
+    auto seg = [&](int64_t beg, int64_t end, int t) {
+      DvtAdamSeg sg{};
+      sg.begin = beg;
+      sg.end = end;
+      sg.lr = lr;
+      sg.bias_correction1 = 1.0 - pow(c->beta1, (double)t);
+      sg.bias_correction2_sqrt = sqrt(1.0 - pow(c->beta2, (double)t));
+      sg.active = 1;
+      a.segs[a.n_segs++] = sg;
+    };
+    if (!phase2) {
+      seg(c->off_grid, c->off_wh1, step + 1);  // grid + field MLP + G
+    } else {
+      seg(c->off_grid, c->off_G, step + 1);  // grid + field MLP (G frozen: grad None)
+      if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
+    }
+    DVT_TRY(dvt_adam_step(&a, P, b->adam_m, b->adam_v, Gd, b->touched, s));
+  }
+#undef DVT_TRY
+  return 0;
+}

@@ -1,0 +1,218 @@
+// Exact-fp32 linear layers on the f32-input matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD, bitwise an fmaf chain).
+//
+// Replaces the cuBLAS SGEMMs behind `nn.Sequential(Linear, ReLU, Linear)` of the field MLP
+// (dvt/models/neural_feature_field.py:40-44, :49) and of the residual predictor
+// (dvt/models/offline_denoiser.py:40-46, :107), forward and backward.
+//
+// One kernel template covers the three contractions of a linear layer; the operands differ
+// only in which index is contiguous in memory:
+//   forward  y = x . w^T      A = x  [m][k] k-contiguous   B = w  [n][k] k-contiguous
+//   dgrad    dx = dy . w      A = dy [m][n] k-contiguous   B = w  [n][k] row-contiguous
+//   wgrad    dw = dy^T . x    A = dy [b][n] row-contiguous B = x  [b][k] row-contiguous
+// Tile 64x64x32 per 256-thread workgroup (4 waves, each one 32x32 accumulator = 16 VGPRs);
+// tiles are staged through LDS so that global reads are 16-B coalesced and the MFMA
+// fragment reads (lane l: A[l&31][l>>5], B[l>>5][l&31]) are conflict-free:
+//   k-contiguous operand  -> LDS [row][k] with leading dimension 33
+//   row-contiguous operand-> LDS [k][row] with leading dimension 64
+// The small batch (2048 rows) yields few tiles, so wgrad splits the batch reduction over
+// blockIdx.z and accumulates with fp32 atomics into a gradient buffer that the fused Adam
+// kernel clears (dvt_adam.hip).
+#include "dvt_common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDK = BK + 1;  // [row][k] layout
+constexpr int LDR = 64;      // [k][row] layout
+constexpr int TILE_FLOATS = 64 * LDK;  // 2112 >= 32*64
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  const float* bias;  // [N] added per output column
+  const float* mask;  // [M, ldmask]: output multiplied by (mask > 0)
+  int ldmask;
+  float* colsum;  // [M]: += sum_k A(m,k), written by the n-tile-0 blocks (A row-contiguous only)
+  int relu;
+  int kchunk;  // K range per blockIdx.z (multiple of BK)
+  int atomic;  // accumulate into C with atomics
+};
+
+// ---- global -> register tile loads (2 float4 per thread per operand) ----
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, int r0, int R,
+                                          int k0, int kend, int tid, float4 regs[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KCONTIG) {
+      const int r = f >> 3, kq = f & 7;
+      const int gr = r0 + r, gk = k0 + 4 * kq;
+      if (gr < R && gk < kend) v = *reinterpret_cast<const float4*>(X + (size_t)gr * ld + gk);
+    } else {
+      const int k = f >> 4, rq = f & 15;
+      const int gk = k0 + k, gr = r0 + 4 * rq;
+      if (gk < kend && gr < R) v = *reinterpret_cast<const float4*>(X + (size_t)gk * ld + gr);
+    }
+    regs[i] = v;
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 regs[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    if (KCONTIG) {
+      const int r = f >> 3, kq = f & 7;
+      float* d = S + r * LDK + 4 * kq;  // bank = (r + 4kq + j) % 32: conflict-free
+      d[0] = regs[i].x;
+      d[1] = regs[i].y;
+      d[2] = regs[i].z;
+      d[3] = regs[i].w;
+    } else {
+      const int k = f >> 4, rq = f & 15;
+      *reinterpret_cast<float4*>(S + k * LDR + 4 * rq) = regs[i];
+    }
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ float frag(const float* __restrict__ S, int row, int k) {
+  return KCONTIG ? S[row * LDK + k] : S[k * LDR + row];
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[TILE_FLOATS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  if (kbeg >= kend) return;
+
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float csum = 0.f;
+  const bool do_colsum = (!A_KC) && p.colsum != nullptr && blockIdx.x == 0;
+
+  float4 ra[2], rb[2];
+  load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
+  load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    store_tile<A_KC>(As, tid, ra);
+    store_tile<B_KC>(Bs, tid, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {  // prefetch the next tile while the MFMAs run
+      load_tile<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra);
+      load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb);
+    }
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float a = frag<A_KC>(As, ar, 2 * kk + kh);
+      const float b = frag<B_KC>(Bs, bc, 2 * kk + kh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (do_colsum && tid < 64) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) csum += As[k * LDR + tid];
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int gn = n0 + wn * 32 + (lane & 31);
+  const float bias = (p.bias != nullptr && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int gm = m0 + wm * 32 + row;
+    if (gm < p.M && gn < p.N) {
+      float v = acc[r] + bias;
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.mask != nullptr) v = p.mask[(size_t)gm * p.ldmask + gn] > 0.f ? v : 0.f;
+      float* c = p.C + (size_t)gm * p.ldc + gn;
+      if (p.atomic)
+        atomic_add_f32(c, v);
+      else
+        *c = v;
+    }
+  }
+  if (do_colsum && tid < 64 && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
+}
+
+template <bool A_KC, bool B_KC>
+int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
+  dim3 grid(dvt_cdiv(a.N, BN), dvt_cdiv(a.M, BM), ksplits);
+  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dvt_linear_fwd(const float* x, const float* w, const float* b, float* y, int m,
+                              int n, int k, int relu, void* stream) {
+  if (!x || !w || !y || m < 0 || n <= 0 || k <= 0 || (k & 3) || (n & 3)) return DVT_E_BADARG;
+  if (m == 0) return 0;
+  GemmArgs a{};
+  a.A = x; a.B = w; a.C = y;
+  a.M = m; a.N = n; a.K = k;
+  a.lda = k; a.ldb = k; a.ldc = n;
+  a.bias = b; a.relu = relu;
+  a.kchunk = (k + BK - 1) / BK * BK;
+  return launch<true, true>(a, 1, (hipStream_t)stream);
+}
+
+extern "C" int dvt_linear_bwd(const float* dy, const float* x, const float* w, float* dw,
+                              float* db, float* dx, const float* relu_mask, int m, int n, int k,
+                              void* stream) {
+  if (!dy || m < 0 || n <= 0 || k <= 0 || (k & 3) || (n & 3)) return DVT_E_BADARG;
+  if (m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dw != nullptr) {
+    if (!x) return DVT_E_BADARG;
+    // dw[n,k] += sum_b dy[b,n] * x[b,k]; batch reduction split so that >= ~512 workgroups exist.
+    GemmArgs a{};
+    a.A = dy; a.B = x; a.C = dw;
+    a.M = n; a.N = k; a.K = m;
+    a.lda = n; a.ldb = k; a.ldc = k;
+    a.colsum = db;
+    a.atomic = 1;
+    const int tiles = dvt_cdiv(n, BM) * dvt_cdiv(k, BN);
+    const int ktiles = dvt_cdiv(m, BK);
+    int splits = dvt_cdiv(768, tiles);
+    if (splits > ktiles / 2) splits = ktiles / 2;
+    if (splits < 1) splits = 1;
+    a.kchunk = dvt_cdiv(ktiles, splits) * BK;
+    splits = dvt_cdiv(m, a.kchunk);
+    int rc = launch<false, false>(a, splits, s);
+    if (rc) return rc;
+  } else if (db != nullptr) {
+    return DVT_E_BADARG;  // db is produced by the wgrad launch
+  }
+  if (dx != nullptr) {
+    if (!w) return DVT_E_BADARG;
+    GemmArgs a{};
+    a.A = dy; a.B = w; a.C = dx;
+    a.M = m; a.N = k; a.K = n;
+    a.lda = n; a.ldb = k; a.ldc = k;
+    a.mask = relu_mask; a.ldmask = k;
+    a.kchunk = (n + BK - 1) / BK * BK;
+    int rc = launch<true, false>(a, 1, s);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,343 @@
+// Row gathers, the lattice artifact map G, and the fused loss forward+backward.
+//
+// Reference: dvt/models/offline_denoiser.py
+//   :96-102  shared_patterns = grid_sample(G[1,C,H,W], lattice coords, bilinear, align_corners)
+//            -- the coords handed in by main_img_denoising.py:58-62 are exactly the lattice
+//            points linspace(-1,1,H) x linspace(-1,1,W), so the sample is a row gather of
+//            G stored [H*W, C] with row = flat_row_index % (H*W);
+//   :113-118 pred = F + G (+ h.detach());
+//   :122-125 loss = mse(pred, raw) + 1 - mean(cosine_similarity(pred, raw, dim=-1));
+//   :131-138 + 0.1 * mse(h, (raw - F - G).detach()) + 0.02 * mean|h|.
+// and main_img_denoising.py:73-76 (row gathers by the sampled indices), :88 (loss * 1024).
+//
+// One wave (64 lanes) owns one row of C <= 1024 channels, kept in registers as float4 so
+// that every tensor is read exactly once and the gradient rows are written exactly once.
+#include "dvt_common.h"
+
+namespace {
+
+constexpr int MAXQ = 4;  // float4 slots per lane: C <= 64*4*4 = 1024
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restrict__ src,
+                                                          const int32_t* __restrict__ idx,
+                                                          float4* __restrict__ dst, int n, int cq,
+                                                          int modulo) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int r = idx[row];
+  if (modulo > 0) r %= modulo;
+  const float4* s = src + (size_t)r * cq;
+  float4* d = dst + (size_t)row * cq;
+  for (int q = lane; q < cq; q += 64) d[q] = s[q];
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src,
+                                                               const int32_t* __restrict__ idx,
+                                                               float* __restrict__ dst, int n,
+                                                               int c, int modulo) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int r = idx[row];
+  if (modulo > 0) r %= modulo;
+  const float* s = src + (size_t)row * c;
+  float* d = dst + (size_t)r * c;
+  for (int j = lane; j < c; j += 64) atomic_add_f32(d + j, s[j]);
+}
+
+
+// F.grid_sample(G, coords, mode="bilinear", padding_mode="zeros", align_corners=True) for a map
+// stored row-major [H*W, C]; coords are (x, y) in [-1, 1] (offline_denoiser.py:96-102).
+__device__ __forceinline__ void bilinear_setup(float2 xy, int H, int W, int rows[4], float w[4]) {
+  const float ix = ((xy.x + 1.f) / 2.f) * (float)(W - 1);
+  const float iy = ((xy.y + 1.f) / 2.f) * (float)(H - 1);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = ix - fx, ty = iy - fy;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int x = x0 + (c & 1), y = y0 + (c >> 1);
+    const bool in = x >= 0 && x < W && y >= 0 && y < H;
+    rows[c] = in ? y * W + x : -1;
+    w[c] = ((c & 1) ? tx : 1.f - tx) * ((c & 2) ? ty : 1.f - ty);
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_rows_fwd_kernel(const float4* __restrict__ G,
+                                                                const float2* __restrict__ coords,
+                                                                float4* __restrict__ out, int n,
+                                                                int cq, int H, int W) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int rows[4];
+  float w[4];
+  bilinear_setup(coords[row], H, W, rows, w);
+  for (int q = lane; q < cq; q += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (rows[c] >= 0 && w[c] != 0.f) {
+        const float4 g = G[(size_t)rows[c] * cq + q];
+        acc.x = fmaf(w[c], g.x, acc.x);
+        acc.y = fmaf(w[c], g.y, acc.y);
+        acc.z = fmaf(w[c], g.z, acc.z);
+        acc.w = fmaf(w[c], g.w, acc.w);
+      }
+    }
+    out[(size_t)row * cq + q] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_rows_bwd_kernel(const float* __restrict__ d_out,
+                                                                const float2* __restrict__ coords,
+                                                                float* __restrict__ d_G, int n,
+                                                                int c, int H, int W) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int rows[4];
+  float w[4];
+  bilinear_setup(coords[row], H, W, rows, w);
+  for (int j = lane; j < c; j += 64) {
+    const float g = d_out[(size_t)row * c + j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (rows[k] >= 0 && w[k] != 0.f) atomic_add_f32(d_G + (size_t)rows[k] * c + j, w[k] * g);
+  }
+}
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// HAS_RES: the residual predictor output Hres participates (phase 2).
+template <bool HAS_RES>
+__global__ __launch_bounds__(256) void loss_kernel(
+    const float4* __restrict__ F, const float4* __restrict__ G, const int32_t* __restrict__ g_idx,
+    int lattice, const float4* __restrict__ Hres, const float4* __restrict__ raw,
+    float4* __restrict__ d_pred, float4* __restrict__ d_hres, float* __restrict__ d_G,
+    float* __restrict__ row_sums, int n, int cq, float grad_scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int grow = g_idx != nullptr ? g_idx[row] : row;
+  if (lattice > 0) grow %= lattice;
+  const size_t base = (size_t)row * cq, gbase = (size_t)grow * cq;
+
+  float4 vp[MAXQ], vr[MAXQ], vh[MAXQ], vfg[MAXQ];
+  float sse = 0.f, dot = 0.f, np = 0.f, nr = 0.f, rsse = 0.f, rabs = 0.f;
+#pragma unroll
+  for (int s = 0; s < MAXQ; ++s) {
+    const int q = lane + 64 * s;
+    if (q < cq) {
+      const float4 f = F[base + q], g = G[gbase + q], r = raw[base + q];
+      float4 fg = f4_add(f, g);
+      float4 p = fg;
+      if (HAS_RES) {
+        const float4 h = Hres[base + q];
+        vh[s] = h;
+        p = f4_add(fg, h);
+        // gt_residual = raw - F - G ; residual terms use (h - gt)
+        const float ex = h.x - (r.x - fg.x), ey = h.y - (r.y - fg.y), ez = h.z - (r.z - fg.z),
+                    ew = h.w - (r.w - fg.w);
+        rsse += ex * ex + ey * ey + ez * ez + ew * ew;
+        rabs += fabsf(h.x) + fabsf(h.y) + fabsf(h.z) + fabsf(h.w);
+      }
+      vp[s] = p;
+      vr[s] = r;
+      vfg[s] = fg;
+      const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z, dw = p.w - r.w;
+      sse += dx * dx + dy * dy + dz * dz + dw * dw;
+      dot += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
+      np += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+      nr += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+    }
+  }
+  sse = wave_sum(sse);
+  dot = wave_sum(dot);
+  np = wave_sum(np);
+  nr = wave_sum(nr);
+  if (HAS_RES) {
+    rsse = wave_sum(rsse);
+    rabs = wave_sum(rabs);
+  }
+  // torch (ATen cosine_similarity): sum(x/max(|x|,eps) * y/max(|y|,eps)), eps = 1e-8
+  const float n1 = sqrtf(np), n2 = sqrtf(nr);
+  const bool clamped = n1 < 1e-8f;
+  const float denom = fmaxf(n1, 1e-8f) * fmaxf(n2, 1e-8f);
+  const float cosv = dot / denom;
+  if (lane == 0 && row_sums != nullptr) {
+    float* o = row_sums + (size_t)row * 8;
+    o[0] = sse;
+    o[1] = cosv;
+    o[2] = rsse;
+    o[3] = rabs;
+  }
+  if (d_pred == nullptr) return;
+  const float inv_nc = 1.0f / ((float)n * (float)(cq * 4));
+  const float inv_n = 1.0f / (float)n;
+  // d/dp [mse] = 2 (p - r) / (n c);  d/dp [1 - mean cos] = -(1/n) (r/denom - cos * p / |p|^2)
+  // (when the clamp is active the denominator is constant: gradient = -(1/n) r / denom)
+  const float a_r = -inv_n / denom;
+  const float a_p = clamped ? 0.f : inv_n * cosv / np;
+  const float c_mse = 2.0f * inv_nc;
+#pragma unroll
+  for (int s = 0; s < MAXQ; ++s) {
+    const int q = lane + 64 * s;
+    if (q < cq) {
+      const float4 p = vp[s], r = vr[s];
+      float4 d;
+      d.x = grad_scale * (c_mse * (p.x - r.x) + a_r * r.x + a_p * p.x);
+      d.y = grad_scale * (c_mse * (p.y - r.y) + a_r * r.y + a_p * p.y);
+      d.z = grad_scale * (c_mse * (p.z - r.z) + a_r * r.z + a_p * p.z);
+      d.w = grad_scale * (c_mse * (p.w - r.w) + a_r * r.w + a_p * p.w);
+      d_pred[base + q] = d;
+      if (d_G != nullptr) {
+        float* g = d_G + (gbase + q) * 4;
+        atomic_add_f32(g + 0, d.x);
+        atomic_add_f32(g + 1, d.y);
+        atomic_add_f32(g + 2, d.z);
+        atomic_add_f32(g + 3, d.w);
+      }
+      if (HAS_RES && d_hres != nullptr) {
+        const float4 h = vh[s], fg = vfg[s];
+        const float c_res = 0.1f * 2.0f * inv_nc, c_abs = 0.02f * inv_nc;
+        float4 e;
+        e.x = grad_scale * (c_res * (h.x - (r.x - fg.x)) + c_abs * sgn(h.x));
+        e.y = grad_scale * (c_res * (h.y - (r.y - fg.y)) + c_abs * sgn(h.y));
+        e.z = grad_scale * (c_res * (h.z - (r.z - fg.z)) + c_abs * sgn(h.z));
+        e.w = grad_scale * (c_res * (h.w - (r.w - fg.w)) + c_abs * sgn(h.w));
+        d_hres[base + q] = e;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ row_sums,
+                                                          float* __restrict__ out, int n, int c,
+                                                          int with_res) {
+  __shared__ float sm[4][4];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float* r = row_sums + (size_t)i * 8;
+    a0 += r[0];
+    a1 += r[1];
+    a2 += r[2];
+    a3 += r[3];
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  a3 = wave_sum(a3);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[w][0] = a0;
+    sm[w][1] = a1;
+    sm[w][2] = a2;
+    sm[w][3] = a3;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      s0 += sm[i][0];
+      s1 += sm[i][1];
+      s2 += sm[i][2];
+      s3 += sm[i][3];
+    }
+    const float nc = (float)n * (float)c;
+    const float l2 = s0 / nc;
+    const float cosl = 1.0f - s1 / (float)n;
+    const float res = with_res ? 0.1f * s2 / nc : 0.f;
+    const float spars = with_res ? 0.02f * s3 / nc : 0.f;
+    out[0] = l2 + cosl + res + spars;
+    out[1] = l2;
+    out[2] = cosl;
+    out[3] = res;
+    out[4] = spars;
+  }
+}
+
+}  // namespace
+
+// Internal (used by dvt_fit.hip): loss with the G-gradient scatter fused in.
+int dvt_loss_launch(const float* F, const float* G, const int32_t* g_idx, int lattice,
+                    const float* Hres, const float* raw_rows, float* d_pred, float* d_hres,
+                    float* d_G, float* row_sums, int n, int c, float grad_scale, hipStream_t s) {
+  if (!F || !G || !raw_rows || n < 0 || c <= 0 || (c & 3) || c > 64 * 4 * MAXQ) return DVT_E_BADARG;
+  if (n == 0) return 0;
+  const int cq = c / 4;
+  dim3 grid(dvt_cdiv(n, 4)), block(256);
+  if (Hres != nullptr)
+    hipLaunchKernelGGL(loss_kernel<true>, grid, block, 0, s, (const float4*)F, (const float4*)G,
+                       g_idx, lattice, (const float4*)Hres, (const float4*)raw_rows,
+                       (float4*)d_pred, (float4*)d_hres, d_G, row_sums, n, cq, grad_scale);
+  else
+    hipLaunchKernelGGL(loss_kernel<false>, grid, block, 0, s, (const float4*)F, (const float4*)G,
+                       g_idx, lattice, (const float4*)nullptr, (const float4*)raw_rows,
+                       (float4*)d_pred, (float4*)nullptr, d_G, row_sums, n, cq, grad_scale);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_loss_fwd_bwd(const float* F, const float* G, const int32_t* g_idx, int lattice,
+                                const float* Hres, const float* raw_rows, float* d_pred,
+                                float* d_hres, float* row_sums, int n, int c, float grad_scale,
+                                void* stream) {
+  return dvt_loss_launch(F, G, g_idx, lattice, Hres, raw_rows, d_pred, d_hres, nullptr, row_sums,
+                         n, c, grad_scale, (hipStream_t)stream);
+}
+
+extern "C" int dvt_loss_reduce(const float* row_sums, float* out5, int n, int c, int with_residual,
+                               void* stream) {
+  if (!row_sums || !out5 || n <= 0 || c <= 0) return DVT_E_BADARG;
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_sums,
+                     out5, n, c, with_residual);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_gather_rows(const float* src, const int32_t* idx, float* dst, int n, int c,
+                               int modulo, void* stream) {
+  if (!src || !idx || !dst || n < 0 || c <= 0 || (c & 3)) return DVT_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(dvt_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)src, idx, (float4*)dst, n, c / 4, modulo);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_scatter_add_rows(const float* src, const int32_t* idx, float* dst, int n,
+                                    int c, int modulo, void* stream) {
+  if (!src || !idx || !dst || n < 0 || c <= 0) return DVT_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(dvt_cdiv(n, 4)), dim3(256), 0,
+                     (hipStream_t)stream, src, idx, dst, n, c, modulo);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_bilinear_rows_fwd(const float* G_rows, const float* coords, float* out, int n,
+                                     int c, int H, int W, void* stream) {
+  if (!G_rows || !coords || !out || n < 0 || c <= 0 || (c & 3) || H < 1 || W < 1)
+    return DVT_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bilinear_rows_fwd_kernel, dim3(dvt_cdiv(n, 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)G_rows, (const float2*)coords,
+                     (float4*)out, n, c / 4, H, W);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_bilinear_rows_bwd(const float* d_out, const float* coords, float* d_G_rows,
+                                     int n, int c, int H, int W, void* stream) {
+  if (!d_out || !coords || !d_G_rows || n < 0 || c <= 0 || H < 1 || W < 1) return DVT_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bilinear_rows_bwd_kernel, dim3(dvt_cdiv(n, 4)), dim3(256), 0,
+                     (hipStream_t)stream, d_out, (const float2*)coords, d_G_rows, n, c, H, W);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,242 @@
+"""FitEngine: the fused per-image fit of DVT stage 1 on one MI355X.
+
+Host-side mirror of `denoise_an_image` (reference main_img_denoising.py:28-149): builds the
+parameter arena (hash grid F, field MLP, shared artifacts G, residual predictor h), the Adam
+state and the index stream, then hands the whole inner loop (:67-89) to native code
+(`dvt_fit_run`, csrc/dvt_fit.hip) -- PyTorch only owns the memory.  Parameters can be
+imported from / exported to the reference-style modules (`SingleImageDenoiser`,
+`NeuralFeatureField`) so both APIs describe the same model.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils.misc import lr_schedule
+
+
+@dataclass
+class FitSettings:
+    """Flags of main_img_denoising.py:152-208 that shape the fit (same names, same defaults)."""
+    feat_dim: int = 768
+    noise_map_height: int = 37
+    noise_map_width: int = 37
+    n_levels: int = 16
+    n_features_per_level: int = 8
+    base_resolution: int = 16
+    max_resolution: int = 1024
+    log2_hashmap_size: int = 20
+    num_iters: int = 25000
+    warmup_iters: int = 2500
+    freeze_shared_artifacts_after: float = 0.5
+    lr: float = 0.01
+    min_lr: float = 0.001
+    weight_decay: float = 1e-5
+    pixel_bsz: int = 2048
+    enable_residual_predictor: bool = True
+    grad_scale: float = 1024.0  # GradScaler(2**10) whose unscale_ is never called (:55, :88)
+    beta1: float = 0.9
+    beta2: float = 0.99
+    eps: float = 1e-15
+    grid_seed: int = 1337
+
+    @property
+    def lattice(self) -> int:
+        return self.noise_map_height * self.noise_map_width
+
+
+_TENSORS = [
+    # (arena attr, shape fn)
+    ("grid", lambda s, c: (int(c.grid.n_entries_total) * s.n_features_per_level,)),
+    ("w1", lambda s, c: (c.hidden, s.n_levels * s.n_features_per_level)),
+    ("b1", lambda s, c: (c.hidden,)),
+    ("w2", lambda s, c: (s.feat_dim, c.hidden)),
+    ("b2", lambda s, c: (s.feat_dim,)),
+    ("G", lambda s, c: (s.lattice, s.feat_dim)),
+    ("wh1", lambda s, c: (c.res_hidden, s.feat_dim)),
+    ("bh1", lambda s, c: (c.res_hidden,)),
+    ("wh2", lambda s, c: (c.res_hidden, c.res_hidden)),
+    ("bh2", lambda s, c: (c.res_hidden,)),
+    ("wh3", lambda s, c: (s.feat_dim, c.res_hidden)),
+    ("bh3", lambda s, c: (s.feat_dim,)),
+]
+
+
+class FitEngine:
+    def __init__(self, settings: FitSettings, n_rows: int, device: torch.device | str = "cuda"):
+        self.s = settings
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DvtError("FitEngine needs a HIP device; there is no CPU fallback")
+        L = _lib.lib()
+        cfg = _lib.FitConfig()
+        cfg.feat_dim = settings.feat_dim
+        cfg.hidden = settings.feat_dim // 2
+        cfg.res_hidden = settings.feat_dim // 4
+        cfg.lattice = settings.lattice
+        cfg.n_rows = n_rows
+        cfg.batch = settings.pixel_bsz
+        cfg.num_iters = settings.num_iters
+        cfg.switch_step = int(settings.freeze_shared_artifacts_after * settings.num_iters)
+        cfg.enable_residual = int(settings.enable_residual_predictor)
+        cfg.grad_scale = settings.grad_scale
+        cfg.beta1, cfg.beta2 = settings.beta1, settings.beta2
+        cfg.eps, cfg.weight_decay = settings.eps, settings.weight_decay
+        cfg.grid = _lib.grid_table(settings.n_levels, settings.n_features_per_level,
+                                   settings.base_resolution, settings.max_resolution,
+                                   settings.log2_hashmap_size)
+        _lib.check(L.dvt_fit_layout(C.byref(cfg)), "dvt_fit_layout")
+        self.cfg = cfg
+        n = int(cfg.arena_floats)
+        dev = self.device
+        self.params = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.adam_m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.adam_v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.touched = torch.zeros(int(cfg.off_w1) // 256, device=dev, dtype=torch.int32)
+        self.workspace = torch.empty(int(L.dvt_fit_workspace_floats(C.byref(cfg))), device=dev,
+                                     dtype=torch.float32)
+        self.losses = torch.zeros((settings.num_iters, 8), device=dev, dtype=torch.float32)
+        self.h_lr = np.ascontiguousarray(
+            [lr_schedule(i, settings.lr, settings.min_lr, settings.warmup_iters, settings.num_iters)
+             for i in range(settings.num_iters)], dtype=np.float64)
+        self._infer_ws = None
+
+    # ------------------------------------------------------------------ parameter views
+    def view(self, name: str) -> torch.Tensor:
+        """A view of one tensor inside the arena (reference-shaped, except G = [H*W, C])."""
+        off = int(getattr(self.cfg, "off_" + name))
+        shape = dict(_TENSORS)[name](self.s, self.cfg)
+        return self.params[off: off + math.prod(shape)].view(shape)
+
+    def reset(self, generator: torch.Generator | None = None) -> None:
+        """Fresh models for a new image, initialised like the reference constructors:
+        grid U(-1e-4, 1e-4) with the SAME seed for every image (tcnn seed=1337), nn.Linear
+        default init (kaiming_uniform(a=sqrt 5) -> U(+-1/sqrt(fan_in)) for weight and bias),
+        G ~ N(0, 0.02^2) (offline_denoiser.py:33-36).  Adam state and gradients are cleared."""
+        dev = self.device
+        self.params.zero_()
+        g = torch.Generator(device=dev).manual_seed(self.s.grid_seed)
+        self.view("grid").uniform_(-1e-4, 1e-4, generator=g)
+        for wname, bname in (("w1", "b1"), ("w2", "b2"), ("wh1", "bh1"), ("wh2", "bh2"),
+                             ("wh3", "bh3")):
+            w = self.view(wname)
+            bound = 1.0 / math.sqrt(w.shape[1])
+            w.uniform_(-bound, bound, generator=generator)
+            self.view(bname).uniform_(-bound, bound, generator=generator)
+        self.view("G").normal_(0.0, 0.02, generator=generator)
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.grads.zero_()
+        self.touched.zero_()
+
+    def load_modules(self, denoiser, neural_field) -> None:
+        """Copy the parameters of reference-style modules into the arena (and clear state)."""
+        with torch.no_grad():
+            self.params.zero_()
+            self.view("grid").copy_(neural_field.neural_field.params.detach().to(self.device))
+            self.view("w1").copy_(neural_field.mlp[0].weight.detach())
+            self.view("b1").copy_(neural_field.mlp[0].bias.detach())
+            self.view("w2").copy_(neural_field.mlp[2].weight.detach())
+            self.view("b2").copy_(neural_field.mlp[2].bias.detach())
+            G = denoiser.shared_artifacts.detach()  # [1, C, H, W] -> [H*W, C]
+            self.view("G").copy_(G.permute(0, 2, 3, 1).reshape(self.s.lattice, self.s.feat_dim))
+            if self.s.enable_residual_predictor:
+                rp = denoiser.residual_predictor
+                for i, (wn, bn) in zip((0, 2, 4), (("wh1", "bh1"), ("wh2", "bh2"), ("wh3", "bh3"))):
+                    self.view(wn).copy_(rp[i].weight.detach())
+                    self.view(bn).copy_(rp[i].bias.detach())
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.grads.zero_()
+        self.touched.zero_()
+
+    def export_modules(self, denoiser, neural_field) -> None:
+        with torch.no_grad():
+            neural_field.neural_field.params.copy_(self.view("grid"))
+            neural_field.mlp[0].weight.copy_(self.view("w1"))
+            neural_field.mlp[0].bias.copy_(self.view("b1"))
+            neural_field.mlp[2].weight.copy_(self.view("w2"))
+            neural_field.mlp[2].bias.copy_(self.view("b2"))
+            H, W, Cc = self.s.noise_map_height, self.s.noise_map_width, self.s.feat_dim
+            denoiser.shared_artifacts.copy_(self.view("G").view(1, H, W, Cc).permute(0, 3, 1, 2))
+            if self.s.enable_residual_predictor:
+                rp = denoiser.residual_predictor
+                for i, (wn, bn) in zip((0, 2, 4), (("wh1", "bh1"), ("wh2", "bh2"), ("wh3", "bh3"))):
+                    rp[i].weight.copy_(self.view(wn))
+                    rp[i].bias.copy_(self.view(bn))
+
+    # ------------------------------------------------------------------ the loop
+    @staticmethod
+    def sample_indices(n_rows: int, num_iters: int, batch: int) -> np.ndarray:
+        """The reference's index stream (main_img_denoising.py:73): `np.random.randint(0, N, B)`
+        per step from the process-global MT19937 (seeded once by fix_random_seeds, quirk Q6).
+        One [num_iters, B] draw consumes the stream exactly like num_iters successive draws."""
+        return np.random.randint(0, n_rows, (num_iters, batch)).astype(np.int32)
+
+    def fit(self, feat: torch.Tensor, xy: torch.Tensor, idx: torch.Tensor | np.ndarray | None = None,
+            log_every: int = 1000, step_begin: int = 0, step_end: int | None = None) -> None:
+        """Enqueue Adam steps [step_begin, step_end) on the current stream (asynchronous).
+
+        feat [n_rows, C] fp32 = all_raw_features.reshape(-1, C); xy [n_rows, 2] fp32 =
+        all_pixel_coords.reshape(-1, 2); idx [num_iters, pixel_bsz] int32 row indices
+        (default: the reference's numpy stream)."""
+        s, cfg = self.s, self.cfg
+        _lib.require_cuda(feat, xy)
+        if feat.dtype != torch.float32 or xy.dtype != torch.float32:
+            raise _lib.DvtError("feat/xy must be fp32")
+        if feat.shape != (cfg.n_rows, s.feat_dim) or xy.shape != (cfg.n_rows, 2):
+            raise _lib.DvtError(f"feat {tuple(feat.shape)} / xy {tuple(xy.shape)} do not match "
+                                f"n_rows={cfg.n_rows}, C={s.feat_dim}")
+        if not feat.is_contiguous() or not xy.is_contiguous():
+            raise _lib.DvtError("feat/xy must be contiguous")
+        if idx is None:
+            idx = self.sample_indices(cfg.n_rows, s.num_iters, s.pixel_bsz)
+        if isinstance(idx, np.ndarray):
+            idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
+        if idx.dtype != torch.int32 or tuple(idx.shape) != (s.num_iters, s.pixel_bsz):
+            raise _lib.DvtError("idx must be int32 [num_iters, pixel_bsz]")
+        self._idx = idx.contiguous()  # keep alive while kernels are in flight
+        self._feat, self._xy = feat, xy
+        b = _lib.FitBuffers()
+        b.feat, b.xy, b.idx = feat.data_ptr(), xy.data_ptr(), self._idx.data_ptr()
+        b.params, b.adam_m, b.adam_v = (self.params.data_ptr(), self.adam_m.data_ptr(),
+                                        self.adam_v.data_ptr())
+        b.grads, b.touched = self.grads.data_ptr(), self.touched.data_ptr()
+        b.workspace, b.losses = self.workspace.data_ptr(), self.losses.data_ptr()
+        b.h_lr = self.h_lr.ctypes.data
+        b.log_every = int(log_every)
+        end = s.num_iters if step_end is None else step_end
+        _lib.check(_lib.lib().dvt_fit_run(C.byref(cfg), C.byref(b), step_begin, end, _lib.stream()),
+                   "dvt_fit_run")
+
+    def infer(self, xy: torch.Tensor) -> torch.Tensor:
+        """F(xy): the denoised features saved by the reference (quirk Q7) -- the field evaluated
+        on a coordinate lattice, main_img_denoising.py:121-130 / offline_denoiser.py:151."""
+        _lib.require_cuda(xy)
+        shape = xy.shape[:-1]
+        xy2 = xy.reshape(-1, 2).contiguous().float()
+        n = xy2.shape[0]
+        E = self.s.n_levels * self.s.n_features_per_level
+        need = ((n * E + 255) // 256 * 256) + n * self.cfg.hidden + 256
+        if self._infer_ws is None or self._infer_ws.numel() < need:
+            self._infer_ws = torch.empty(need, device=self.device, dtype=torch.float32)
+        out = torch.empty((n, self.s.feat_dim), device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dvt_field_infer(C.byref(self.cfg), self.params.data_ptr(),
+                                              xy2.data_ptr(), out.data_ptr(),
+                                              self._infer_ws.data_ptr(), n, _lib.stream()),
+                   "dvt_field_infer")
+        return out.reshape(*shape, self.s.feat_dim)
+
+    def loss_log(self) -> dict[int, dict[str, float]]:
+        """Loss scalars of the logged steps (one D2H copy, after the loop)."""
+        host = self.losses.cpu().numpy()
+        keys = ("loss", "patch_l2_loss", "cosine_similarity_loss", "residual_loss",
+                "residual_sparsity_loss")
+        return {i: dict(zip(keys, map(float, host[i, :5]))) for i in range(host.shape[0])
+                if host[i, 0] != 0.0}

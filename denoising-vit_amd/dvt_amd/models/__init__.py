@@ -1,0 +1,3 @@
+"""`dvt.models` surface of the reference (dvt/models/__init__.py): same names."""
+from .neural_feature_field import HashGridEncoding, HipLinear, NeuralFeatureField  # noqa: F401
+from .offline_denoiser import SingleImageDenoiser  # noqa: F401

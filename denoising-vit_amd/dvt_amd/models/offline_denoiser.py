@@ -1,0 +1,189 @@
+"""SingleImageDenoiser on MI355X -- drop-in for dvt/models/offline_denoiser.py:11-171.
+
+Same constructor, attributes (`shared_artifacts` [1,C,H,W], `residual_predictor` Sequential
+with Linear at 0/2/4, `use_residual_predictor`, `start_residual_predictor()`,
+`stop_shared_artifacts_grad()`), forward signature and result-dict keys.  The composition
+`F(coords) + G (+ h.detach())`, the four loss terms and their gradients run in ONE HIP
+kernel (csrc/dvt_loss.hip); the bilinear lookup of G and the residual MLP run on the
+hand-written gather / f32-MFMA kernels.  The fused whole-loop fast path lives in
+`dvt_amd.fit.FitEngine`; this module is the reference-style API
+(`loss.backward(); optimizer.step()` keeps working).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import _lib
+from .neural_feature_field import HipLinear, NeuralFeatureField
+
+
+class _BilinearRowsFn(torch.autograd.Function):
+    """grid_sample(G[1,C,H,W], coords[n,2], bilinear, align_corners=True) -> [n, C]."""
+
+    @staticmethod
+    def forward(ctx, G: Tensor, coords: Tensor):
+        _lib.require_cuda(G, coords)
+        _, C_, H, W = G.shape
+        rows = G.detach().permute(0, 2, 3, 1).reshape(H * W, C_).contiguous().float()
+        coords = coords.contiguous().float()
+        n = coords.shape[0]
+        out = torch.empty((n, C_), device=G.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dvt_bilinear_rows_fwd(_lib.ptr(rows), _lib.ptr(coords), _lib.ptr(out),
+                                                    n, C_, H, W, _lib.stream()),
+                   "dvt_bilinear_rows_fwd")
+        ctx.save_for_backward(coords)
+        ctx.shape = (C_, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        (coords,) = ctx.saved_tensors
+        C_, H, W = ctx.shape
+        d_rows = torch.zeros((H * W, C_), device=d_out.device, dtype=torch.float32)
+        d_out = d_out.contiguous().float()
+        _lib.check(_lib.lib().dvt_bilinear_rows_bwd(_lib.ptr(d_out), _lib.ptr(coords),
+                                                    _lib.ptr(d_rows), coords.shape[0], C_, H, W,
+                                                    _lib.stream()), "dvt_bilinear_rows_bwd")
+        return d_rows.reshape(1, H, W, C_).permute(0, 3, 1, 2), None
+
+
+class _LossFn(torch.autograd.Function):
+    """All loss terms of offline_denoiser.py:113-140 + their gradients in one kernel launch.
+
+    Returns a [5] tensor {loss, patch_l2, cos_loss, residual_loss, residual_sparsity_loss};
+    gradients flow through element 0 (the total), exactly the quantity the driver
+    backpropagates (main_img_denoising.py:86-88).
+    """
+
+    @staticmethod
+    def forward(ctx, feats: Tensor, shared: Tensor, residual: Tensor | None, raw: Tensor):
+        _lib.require_cuda(feats, shared, residual, raw)
+        n, c = raw.shape
+        feats = feats.contiguous().float()
+        shared = shared.contiguous().float()
+        raw = raw.contiguous().float()
+        res = None if residual is None else residual.contiguous().float()
+        d_pred = torch.empty_like(feats)
+        d_res = torch.empty_like(feats) if res is not None else None
+        rows = torch.empty((n, 8), device=raw.device, dtype=torch.float32)
+        out = torch.zeros(8, device=raw.device, dtype=torch.float32)
+        L = _lib.lib()
+        _lib.check(L.dvt_loss_fwd_bwd(_lib.ptr(feats), _lib.ptr(shared), None, 0, _lib.ptr(res),
+                                      _lib.ptr(raw), _lib.ptr(d_pred), _lib.ptr(d_res),
+                                      _lib.ptr(rows), n, c, 1.0, _lib.stream()), "dvt_loss_fwd_bwd")
+        _lib.check(L.dvt_loss_reduce(_lib.ptr(rows), _lib.ptr(out), n, c, int(res is not None),
+                                     _lib.stream()), "dvt_loss_reduce")
+        ctx.save_for_backward(d_pred, d_res)
+        return out[:5]
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        d_pred, d_res = ctx.saved_tensors
+        s = g[0]
+        gp = d_pred * s
+        # `pred = F + G + h.detach()`: F and G share d_pred; h only gets the residual terms
+        return gp, gp, (None if d_res is None else d_res * s), None
+
+
+class SingleImageDenoiser(nn.Module):
+    def __init__(
+        self,
+        noise_map_height: int = 37,
+        noise_map_width: int = 37,
+        feat_dim: int = 768,
+        layer_index: int = 11,
+        enable_residual_predictor: bool = True,
+        disable_pe: bool = False,
+    ):
+        super().__init__()
+        self.noise_map_h = noise_map_height
+        self.noise_map_w = noise_map_width
+        self.feat_dim = feat_dim
+        self.layer_idx = layer_index
+        # g: the input-independent artifact term shared by all views (reference :27-36)
+        if disable_pe:
+            self.shared_artifacts = nn.Parameter(
+                torch.zeros(1, feat_dim, noise_map_height, noise_map_width), requires_grad=False)
+        else:
+            self.shared_artifacts = nn.Parameter(
+                torch.randn(1, feat_dim, noise_map_height, noise_map_width) * 0.02,
+                requires_grad=True)
+        self.enable_residual_predictor = enable_residual_predictor
+        if self.enable_residual_predictor:
+            # h: residual term co-dependent on the image and the location (reference :38-46)
+            self.residual_predictor = nn.Sequential(
+                HipLinear(feat_dim, feat_dim // 4),
+                nn.ReLU(),
+                HipLinear(feat_dim // 4, feat_dim // 4),
+                nn.ReLU(),
+                HipLinear(feat_dim // 4, feat_dim),
+            )
+        self.residual_predictor_start = False
+
+    def start_residual_predictor(self):
+        """Enables the training of the residual predictor."""
+        self.residual_predictor_start = True
+
+    @property
+    def use_residual_predictor(self):
+        return self.enable_residual_predictor and self.residual_predictor_start
+
+    def stop_shared_artifacts_grad(self):
+        """Stops gradient updates for the shared artifacts."""
+        self.shared_artifacts.requires_grad = False
+
+    def forward(
+        self,
+        raw_vit_outputs: Tensor,
+        global_pixel_coords: Tensor,
+        neural_field: NeuralFeatureField = None,
+        shared_artifact_coords: Tensor = None,
+        return_visualization: bool = False,
+    ) -> Dict[str, Tensor]:
+        if len(raw_vit_outputs.shape) != 2:
+            original_shape = raw_vit_outputs.shape
+            raw_vit_outputs = raw_vit_outputs.reshape(-1, self.feat_dim)
+            global_pixel_coords = global_pixel_coords.reshape(-1, 2)
+            shared_patterns = self.shared_artifacts.permute(0, 2, 3, 1).reshape(-1, self.feat_dim)
+        else:
+            assert shared_artifact_coords is not None, "shared_artifact_coords must be provided."
+            original_shape = None
+            shared_patterns = _BilinearRowsFn.apply(self.shared_artifacts, shared_artifact_coords)
+        denoised_feats = neural_field(global_pixel_coords)
+        pred_residual = (self.residual_predictor(raw_vit_outputs)
+                         if self.use_residual_predictor else None)
+
+        losses = _LossFn.apply(denoised_feats, shared_patterns, pred_residual, raw_vit_outputs)
+        results = {
+            "patch_l2_loss": losses[1].detach(),
+            "loss": losses[0],
+            "cosine_similarity_loss": losses[2].detach(),
+        }
+        if self.use_residual_predictor:
+            results["residual_loss"] = losses[3].detach()
+            results["residual_sparsity_loss"] = losses[4].detach()
+
+        if return_visualization:
+            assert original_shape is not None, "original_shape must be provided."
+            shp = tuple(original_shape[:-1]) + (-1,)
+            if self.use_residual_predictor:
+                pred = denoised_feats + shared_patterns + pred_residual.detach()
+            else:
+                pred = shared_patterns + denoised_feats
+            results["raw_vit_outputs"] = raw_vit_outputs.detach().reshape(shp)
+            results["pred_features"] = pred.detach().reshape(shp)
+            results["denoised_feats"] = denoised_feats.detach().reshape(shp)
+            results["shared_patterns"] = shared_patterns.detach().reshape(shp)
+            if self.use_residual_predictor:
+                results["pred_residual"] = pred_residual.detach().reshape(shp)
+                results["shared_patterns_and_residual"] = (
+                    shared_patterns + pred_residual).detach().reshape(shp)
+                denoised_features = raw_vit_outputs - shared_patterns - pred_residual
+            else:
+                denoised_features = raw_vit_outputs - shared_patterns
+            results["denoised_features"] = denoised_features.detach().reshape(shp)
+        return results

@@ -1,0 +1,236 @@
+/*
+ * dvt_hip.h -- C ABI of libdvt_hip.so: the MI355X (gfx950) implementation of the
+ * DVT stage-1 per-image denoising hot path.
+ *
+ * Every entry point replaces one native/GPU boundary of the reference
+ * (Jiawei-Yang/Denoising-ViT, paths relative to the reference root):
+ *
+ *   dvt_grid_*      tinycudann `tcnn.Encoding(HashGrid)` fwd/bwd, the only native FFI on the
+ *                   reference's path -- dvt/models/neural_feature_field.py:25-39 (ctor), :48 (call)
+ *   dvt_linear_*    the `nn.Sequential(Linear, ReLU, Linear)` field MLP and the residual
+ *                   predictor -- neural_feature_field.py:40-44,:49; offline_denoiser.py:40-46,:107
+ *   dvt_gather_rows / dvt_bilinear_rows_*   `F.grid_sample(shared_artifacts, coords)` -- offline_denoiser.py:96-102
+ *   dvt_loss_*      reconstruction composition + 4 loss terms -- offline_denoiser.py:113-140
+ *   dvt_adam_step   `torch.optim.Adam(lr, eps=1e-15, wd, betas=(0.9,0.99))` + zero_grad
+ *                   -- main_img_denoising.py:48-54, :87-89
+ *   dvt_fit_run     the whole inner loop of denoise_an_image -- main_img_denoising.py:67-89
+ *   dvt_field_infer final full-image inference F(lattice) -- main_img_denoising.py:121-130
+ *   dvt_vit_*       frozen ViT forward_intermediates (timm) -- dvt/models/vit_wrapper.py:122-143,
+ *                   main_img_denoising.py:317-323
+ *
+ * Conventions
+ *   - all functions return int: 0 = ok, >0 = hipError_t, <0 = DVT_E_* argument error;
+ *     they never throw and never allocate device memory;
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch) unless the name
+ *     starts with `h_` / the doc says host;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - the caller selects the device (hipSetDevice); functions are re-entrant on
+ *     distinct streams; row-major fp32 unless stated.
+ */
+#ifndef DVT_HIP_H
+#define DVT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVT_MAX_LEVELS 32
+
+#define DVT_E_BADARG (-1) /* shape/alignment precondition violated */
+#define DVT_E_NOTIMPL (-2)
+
+/* ABI version; bumped on any struct change. */
+int dvt_abi_version(void);
+/* HOST: sizeof() of {DvtGridTable, DvtAdamSeg, DvtAdamArgs, DvtFitConfig, DvtFitBuffers} so that
+ * a foreign-language binding (ctypes) can verify its struct mirrors. */
+int dvt_struct_sizes(int64_t* h_out5);
+
+/* ------------------------------------------------------------------------------------
+ * Hash grid (tcnn HashGrid, 2-D, linear interpolation, CoherentPrime hash)
+ * ---------------------------------------------------------------------------------- */
+
+/* Per-level table, computed ONCE on the host in fp32 (tcnn grid.h: grid_scale /
+ * grid_resolution / offset table) and passed by value to every kernel.            */
+typedef struct DvtGridTable {
+  int32_t n_levels;
+  int32_t n_features; /* features per level; this build supports 8 (tcnn config :30) */
+  uint32_t n_entries_total; /* sum of entries over levels; params = n_entries_total * n_features */
+  uint32_t pad_;
+  float scale[DVT_MAX_LEVELS];        /* exp2f(l*log2f(pls))*base - 1 */
+  uint32_t resolution[DVT_MAX_LEVELS]; /* ceilf(scale)+1 */
+  uint32_t entries[DVT_MAX_LEVELS];    /* min(round_up(res^2,8), 2^log2_T) */
+  uint32_t offset[DVT_MAX_LEVELS];     /* cumulative entries */
+  uint32_t hashed[DVT_MAX_LEVELS];     /* 1 if res^2 > entries (only then the hash is used) */
+} DvtGridTable;
+
+/* HOST function: fill `out` for (n_levels, base_resolution, max_resolution, log2_hashmap_size).
+ * per_level_scale = exp((ln max - ln base)/(L-1)) evaluated in float64 then narrowed to
+ * fp32 exactly as neural_feature_field.py:34-36 -> tcnn json float.                  */
+int dvt_grid_table(int n_levels, int n_features, int base_resolution, int max_resolution,
+                   int log2_hashmap_size, DvtGridTable* h_out);
+
+/* enc[n, L*F] (column = level*F + f) from xy[n,2] in [0,1].  Replaces tcnn fwd. */
+int dvt_grid_fwd(const DvtGridTable* h_tbl, const float* xy, const float* params, float* enc,
+                 int n, void* stream);
+
+/* d_params[idx*F+f] += w * d_enc[level*F+f] (fp32 atomics) into a buffer the caller keeps
+ * zeroed between steps; when `touched` != NULL also sets bit (entry) of the bitmap
+ * touched[entry>>5] so that dvt_adam_step can skip reading/clearing untouched gradients.
+ * Replaces tcnn bwd (dL/dparams only; coords never require grad on this path).        */
+int dvt_grid_bwd(const DvtGridTable* h_tbl, const float* xy, const float* d_enc, float* d_params,
+                 uint32_t* touched, int n, void* stream);
+
+/* Debug/parity: the 4 corner entry indices (absolute, incl. level offset) and weights for
+ * every (sample, level): idx[n, L, 4] uint32, w[n, L, 4] fp32. Integer path is bit-exact
+ * against the oracle.                                                                   */
+int dvt_grid_corners(const DvtGridTable* h_tbl, const float* xy, uint32_t* idx, float* w, int n,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * fp32 linear layers on f32-input MFMA (exact fp32: v_mfma_f32_32x32x2_f32)
+ * ---------------------------------------------------------------------------------- */
+
+/* y[m,n] = act(x[m,k] . w[n,k]^T + b[n]);  relu != 0 applies ReLU. b may be NULL.
+ * Preconditions: k % 4 == 0, n % 4 == 0 (else DVT_E_BADARG).                       */
+int dvt_linear_fwd(const float* x, const float* w, const float* b, float* y, int m, int n, int k,
+                   int relu, void* stream);
+
+/* Backward of the above for upstream grad dy[m,n]:
+ *   dw[n,k] += dy^T . x   (atomic accumulation into a zeroed buffer; split over m)
+ *   db[n]   += colsum(dy) (db may be NULL)
+ *   dx[m,k]  = dy . w, multiplied by (relu_mask[m,k] > 0) when relu_mask != NULL
+ *              (relu_mask = the ReLU output that produced x); dx may be NULL.       */
+int dvt_linear_bwd(const float* dy, const float* x, const float* w, float* dw, float* db,
+                   float* dx, const float* relu_mask, int m, int n, int k, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row gathers / lattice artifact map G
+ * ---------------------------------------------------------------------------------- */
+
+/* dst[i, :] = src[idx[i] % modulo, :] (modulo <= 0: no modulo). c % 4 == 0.          */
+int dvt_gather_rows(const float* src, const int32_t* idx, float* dst, int n, int c, int modulo,
+                    void* stream);
+
+/* dst[idx[i] % modulo, :] += src[i, :] (fp32 atomics).                              */
+int dvt_scatter_add_rows(const float* src, const int32_t* idx, float* dst, int n, int c,
+                         int modulo, void* stream);
+
+/* General form of offline_denoiser.py:96-102 for arbitrary coords (module API):
+ * out[i,:] = grid_sample(G, coords[i], bilinear, zeros padding, align_corners=True) with the
+ * map stored row-major G_rows[H*W, c]; coords[n,2] = (x, y) in [-1,1]. c % 4 == 0.   */
+int dvt_bilinear_rows_fwd(const float* G_rows, const float* coords, float* out, int n, int c,
+                          int H, int W, void* stream);
+/* d_G_rows[H*W, c] += scatter of d_out[n, c] with the same 4 weights (fp32 atomics). */
+int dvt_bilinear_rows_bwd(const float* d_out, const float* coords, float* d_G_rows, int n, int c,
+                          int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Loss (offline_denoiser.py:113-140) forward + backward in one pass
+ * ---------------------------------------------------------------------------------- */
+
+/* Per row i (n rows, c channels):
+ *   raw = raw_rows[i]            (already gathered, [n,c])
+ *   g   = G[g_idx[i] % lattice]  (G stored [lattice, c]; g_idx may be NULL -> row i)
+ *   pred = F[i] + g (+ Hres[i] when Hres != NULL, treated as detached)
+ *   loss = mse(pred, raw) + 1 - mean_i cos(pred_i, raw_i)
+ *          (+ 0.1*mse(Hres, raw - F - g) + 0.02*mean|Hres| when Hres != NULL)
+ * Writes d_pred[n,c] = grad_scale * dloss/dpred, d_hres[n,c] (when Hres != NULL) and the
+ * per-row partial sums row_sums[n,8] = {sse, cos, res_sse, res_abs, 0...}.
+ * d_pred / d_hres may be NULL (inference: only row_sums).                           */
+int dvt_loss_fwd_bwd(const float* F, const float* G, const int32_t* g_idx, int lattice,
+                     const float* Hres, const float* raw_rows, float* d_pred, float* d_hres,
+                     float* row_sums, int n, int c, float grad_scale, void* stream);
+
+/* out[0..4] = {loss, patch_l2_loss, cosine_similarity_loss, residual_loss,
+ * residual_sparsity_loss} from row_sums (one small reduction launch).               */
+int dvt_loss_reduce(const float* row_sums, float* out5, int n, int c, int with_residual,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused dense Adam + zero_grad over a flat parameter arena
+ * ---------------------------------------------------------------------------------- */
+
+#define DVT_ADAM_MAX_SEGS 8
+typedef struct DvtAdamSeg {
+  int64_t begin; /* float offset in the arena, multiple of 256 */
+  int64_t end;   /* float offset (exclusive), multiple of 256 (pad with zeros) */
+  double lr;     /* learning rate of this step (python float in the reference) */
+  double bias_correction1;      /* 1 - beta1^t, t = this tensor group's own step count */
+  double bias_correction2_sqrt; /* sqrt(1 - beta2^t) */
+  int32_t active;               /* 0: skipped entirely (grad None in torch) */
+  int32_t pad_;
+} DvtAdamSeg;
+
+typedef struct DvtAdamArgs {
+  double beta1, beta2, eps, weight_decay; /* python floats in the reference; narrowed like torch does */
+  int32_t n_segs;
+  int32_t pad_;
+  /* floats [0, sparse_end) carry a SPARSE gradient gated by `touched` (1 bit per 8 floats,
+   * one 32-bit word per 256 floats); beyond it gradients are dense.  sparse_end % 256 == 0. */
+  int64_t sparse_end;
+  DvtAdamSeg segs[DVT_ADAM_MAX_SEGS];
+} DvtAdamArgs;
+
+/* torch.optim.Adam semantics (L2 decay folded into the gradient, lerp first moment,
+ * eps added after the bias-corrected sqrt), g is consumed and cleared (zero_grad).
+ * 24 B/param of HBM traffic for untouched sparse-segment params.                    */
+int dvt_adam_step(const DvtAdamArgs* h_args, float* p, float* m, float* v, float* g,
+                  uint32_t* touched, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused fit loop (the product fast path)
+ * ---------------------------------------------------------------------------------- */
+
+typedef struct DvtFitConfig {
+  int32_t feat_dim;     /* C */
+  int32_t hidden;       /* field MLP hidden = C/2 */
+  int32_t res_hidden;   /* residual predictor hidden = C/4 */
+  int32_t lattice;      /* H*W of the shared-artifact map G */
+  int32_t n_rows;       /* rows in the feature store = (views+1)*lattice */
+  int32_t batch;        /* pixel_bsz */
+  int32_t num_iters;
+  int32_t switch_step;  /* int(freeze_shared_artifacts_after*num_iters); phase 2 iff step > switch_step */
+  int32_t enable_residual; /* enable_residual_predictor */
+  int32_t pad0_;
+  double grad_scale;    /* 1024: GradScaler quirk, main_img_denoising.py:55,:88 */
+  double beta1, beta2, eps, weight_decay;
+  DvtGridTable grid;
+  /* arena layout (float offsets, each a multiple of 256) */
+  int64_t off_grid, off_w1, off_b1, off_w2, off_b2, off_G, off_wh1, off_bh1, off_wh2, off_bh2,
+      off_wh3, off_bh3, arena_floats;
+} DvtFitConfig;
+
+typedef struct DvtFitBuffers {
+  const float* feat;   /* [n_rows, C] feature store (NHWC patch tokens of all views) */
+  const float* xy;     /* [n_rows, 2] global pixel coords in [0,1] */
+  const int32_t* idx;  /* [num_iters, batch] row index stream (host-generated, np.random.randint) */
+  float* params;       /* arena */
+  float* adam_m;
+  float* adam_v;
+  float* grads;        /* arena-shaped, must be zero on entry of step 0 */
+  uint32_t* touched;   /* bitmap, (off_w1/256) words, zero on entry */
+  float* workspace;    /* dvt_fit_workspace_floats() floats */
+  float* losses;       /* [num_iters, 8] written only for steps where (step % log_every == 0) or last */
+  const double* h_lr;  /* HOST: lr per step (misc.adjust_learning_rate) */
+  int32_t log_every;   /* 0: never */
+  int32_t pad_;
+} DvtFitBuffers;
+
+/* HOST: fill the arena offsets of cfg from its dims (layout documented in DESIGN.md). */
+int dvt_fit_layout(DvtFitConfig* h_cfg);
+int64_t dvt_fit_workspace_floats(const DvtFitConfig* h_cfg);
+
+/* Enqueue steps [step_begin, step_end) of the inner loop on `stream` (asynchronous). */
+int dvt_fit_run(const DvtFitConfig* h_cfg, const DvtFitBuffers* h_bufs, int step_begin,
+                int step_end, void* stream);
+
+/* out[n, C] = field(xy[n,2]) using arena params; workspace >= n*(L*F + hidden) floats. */
+int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float* xy, float* out,
+                    float* workspace, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVT_HIP_H */
