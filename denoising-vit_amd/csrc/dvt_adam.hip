@@ -105,6 +105,10 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
     const DvtAdamSeg& sg = h->segs[s];
     if (!sg.active || sg.end == sg.begin) continue;
     const long long n_chunks = (sg.end - sg.begin) / 256;
+    // algorithmic bytes: p, m, v read + written once (24 B/param); dense-gradient part +8 B/param
+    const double dense_floats = (double)(sg.end - (sg.begin > h->sparse_end ? sg.begin : (sg.end < h->sparse_end ? sg.end : h->sparse_end)));
+    DvtProbeScope probe(DVT_PROBE_ADAM, (hipStream_t)stream,
+                        24.0 * (double)(sg.end - sg.begin) + 8.0 * dense_floats);
     long long blocks = (n_chunks + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a,

@@ -34,3 +34,20 @@ int dvt_grid_bwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ri
 int dvt_loss_launch(const float* F, const float* G, const int32_t* g_idx, int lattice,
                     const float* Hres, const float* raw_rows, float* d_pred, float* d_hres,
                     float* d_G, float* row_sums, int n, int c, float grad_scale, hipStream_t s);
+
+// ---- profiling probes (dvt_prof.hip) ----
+extern unsigned g_dvt_prof_mask;
+void dvt_prof_begin(int probe, hipStream_t s);
+void dvt_prof_end(int probe, hipStream_t s, double work);
+struct DvtProbeScope {
+  int probe;
+  hipStream_t s;
+  double work;
+  bool on;
+  DvtProbeScope(int p, hipStream_t st, double w) : probe(p), s(st), work(w), on((g_dvt_prof_mask >> p) & 1u) {
+    if (on) dvt_prof_begin(probe, s);
+  }
+  ~DvtProbeScope() {
+    if (on) dvt_prof_end(probe, s, work);
+  }
+};

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
   dim3 grid(dvt_cdiv(a.N, BN), dvt_cdiv(a.M, BM), ksplits);
+  DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
   hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
   DVT_CHECK_LAUNCH();
   return 0;

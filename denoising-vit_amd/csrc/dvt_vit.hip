@@ -1,0 +1,646 @@
+// Frozen DINOv2 ViT forward for gfx950: bf16 operands on v_mfma_f32_16x16x32_bf16, fp32
+// accumulation / residual stream / LayerNorm / softmax.  C ABI in include/dvt_vit.h.
+//
+// Reference: dvt/models/vit_wrapper.py:122-143 (get_intermediate_layers ->
+// timm.VisionTransformer.forward_intermediates [timm 1.0.7, third party, not in the tree]),
+// called from main_img_denoising.py:317-323 and :332-336.  Block structure restated in
+// x += ls1 * proj(MHA(LN1(x))); x += ls2 * fc2(GELU(fc1(LN2(x)))).
+//
+// Data layout in HBM (one forward of `batch` images):
+//   tokens of an image are padded from 1370 to s_pad = 1408 (multiple of 128) rows so that
+//   no 128-row GEMM tile and no 64-key attention tile straddles two images; pad keys are
+//   masked in the softmax, pad rows never reach the output.
+//   x      fp32 [batch*s_pad, dim]        residual stream
+//   xn     bf16 [batch*s_pad, dim]        LayerNorm output / attention output (GEMM A operand)
+//   qk     bf16 [batch*s_pad, 2*dim]      q | k, head-major inside (timm qkv layout)
+//   vt     bf16 [batch, heads, 64, s_pad] V TRANSPOSED per head: written by the qkv GEMM
+//                                         epilogue so that P.V can read key-contiguous operands
+//   hid    bf16 [batch*s_pad, mlp_dim]    GELU(fc1)
+//   col    bf16 [batch*s_pad, k_patch]    im2col of the input image
+//
+// Kernels and what bounds them:
+//   gemm_bf16   128x128x64 tiles, 4 waves x (64x64) = 16 MFMA accumulators per wave, operands
+//               staged with global_load_lds (16 B/lane, XOR-swizzled via the SOURCE address),
+//               2 LDS stages; MFMA-bound (2.5 PF/s bf16 dense).  Epilogues fused: +bias (q/k),
+//               V transposed store, +bias+GELU, LayerScale+residual (fp32 in place), patch
+//               embedding + pos_embed + cls.
+//   attention   flash-style, S^T = K.Q^T so that the softmax statistics of a query live in
+//               one lane column and P is already in B-operand layout for O^T = V^T.P^T.
+//   layernorm   one wave per row, HBM-bound.
+#include <math.h>
+
+#include "../../include/dvt_vit.h"
+#include "dvt_common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+namespace {
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+
+// ======================================================================================
+// GEMM  C[M,N] = A[M,K] . W[N,K]^T   (both operands K-contiguous bf16)
+// ======================================================================================
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
+
+enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4 };
+
+struct GemmBArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  int M, N, K;
+  const float* bias;  // [N]
+  bf16_t* out;        // EPI_BIAS / EPI_GELU: [M, N]; EPI_QKV: qk [M, 2*dim]
+  bf16_t* vt;         // EPI_QKV: [batch, heads, 64, s_pad]
+  float* x;           // EPI_RESID / EPI_EMBED: residual stream [M, N]
+  const float* gamma; // EPI_RESID: LayerScale [N]
+  const float* pos;   // EPI_EMBED: pos_embed [n_tokens, N]
+  const float* cls;   // EPI_EMBED: cls token [N]
+  int dim, heads, s_pad, n_tokens;
+};
+
+// async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Stage one 128x64 bf16 tile (rows r0.., k0..) into `lds` (16 KB, rows of 128 B).  The LDS
+// image is lane-linear; the 16-B chunk index inside a row is XOR-ed with (row & 7) by
+// permuting the SOURCE address, and the fragment reads apply the same XOR.
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ X, int ld, int r0, int k0,
+                                           char* lds, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 256 + wave * 64 + lane;  // LDS slot (16 B units)
+    const int row = s >> 3, cp = s & 7;
+    const int c = cp ^ (row & 7);
+    glds16(X + (size_t)(r0 + row) * ld + k0 + c * 8, lds + (it * 256 + wave * 64) * 16);
+  }
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs, so give every XCD a
+  // contiguous run of tiles (N fastest) -> the A row panel of a run stays in that XCD's L2.
+  const int ntn = p.N / GBN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int m0 = (bid / ntn) * GBM, n0 = (bid % ntn) * GBN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GBK;
+  stage_tile(p.A, p.K, m0, 0, smem, wave, lane);
+  stage_tile(p.W, p.K, n0, 0, smem + GBM * GBK * 2, wave, lane);
+  __syncthreads();  // waits vmcnt(0) for the LDS-DMA before releasing the workgroup
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    if (kt + 1 < nk) {
+      stage_tile(p.A, p.K, m0, (kt + 1) * GBK, nxt, wave, lane);
+      stage_tile(p.W, p.K, n0, (kt + 1) * GBK, nxt + GBM * GBK * 2, wave, lane);
+    }
+    const char* As = cur;
+    const char* Bs = cur + GBM * GBK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+      const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = read_frag(As, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = read_frag(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading `cur`
+  }
+
+  // ---- epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*(lane>>4) + r][n0 + wn*64 + j*16 + (lane&15)]
+  const int g = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + lc;
+    const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mrow = m0 + wm * 64 + i * 16 + 4 * g;  // first of this lane's 4 rows
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias;
+      if (EPI == EPI_RESID) {
+        const float gm = p.gamma[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* px = p.x + (size_t)(mrow + r) * p.N + n;
+          *px = *px + gm * v[r];
+        }
+      } else if (EPI == EPI_EMBED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = mrow + r, s = t % p.s_pad;
+          float o;
+          if (s == 0)
+            o = p.cls[n] + p.pos[n];
+          else if (s < p.n_tokens)
+            o = v[r] + p.pos[(size_t)s * p.N + n];
+          else
+            o = 0.f;
+          p.x[(size_t)t * p.N + n] = o;
+        }
+      } else if (EPI == EPI_QKV && n0 >= 2 * p.dim) {
+        // V: transposed store vt[b][h][d][s], the lane's 4 rows are 4 consecutive tokens
+        const int f = n - 2 * p.dim, h = f >> 6, d = f & 63;
+        const int b = mrow / p.s_pad, s = mrow - b * p.s_pad;
+        uint2 pk;
+        pk.x = pack2(v[0], v[1]);
+        pk.y = pack2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p.vt + ((size_t)(b * p.heads + h) * 64 + d) * p.s_pad + s) = pk;
+      } else {
+        if (EPI == EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+        }
+        const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
+        // pair adjacent columns across lanes (l, l^1): even lanes store rows r=0,1 of the
+        // column pair, odd lanes rows r=2,3 -> 4-B stores instead of 2-B stores
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+          const float mine0 = v[rp], mine1 = v[rp + 2];
+          const float send = odd ? mine0 : mine1;
+          const float recv = __shfl_xor(send, 1, 64);
+          const int r = odd ? rp + 2 : rp;
+          const uint32_t w = odd ? pack2(recv, mine1) : pack2(mine0, recv);
+          const int ncol = odd ? n - 1 : n;
+          *reinterpret_cast<uint32_t*>(p.out + (size_t)(mrow + r) * ldo + ncol) = w;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm(const GemmBArgs& a, hipStream_t s) {
+  if (a.M % GBM || a.N % GBN || a.K % GBK || a.M <= 0) return DVT_E_BADARG;
+  const int tiles = (a.M / GBM) * (a.N / GBN);
+  DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(tiles), dim3(256), 0, s, a);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ======================================================================================
+// im2col for the patch embedding (Conv2d 3 -> dim, kernel = patch, stride)
+// ======================================================================================
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img,
+                                                     bf16_t* __restrict__ col, DvtVitConfig c) {
+  const int t = blockIdx.x;  // token row in [0, batch*s_pad)
+  const int b = t / c.s_pad, s = t - b * c.s_pad;
+  bf16_t* dst = col + (size_t)t * c.k_patch;
+  const int pp = c.patch * c.patch;
+  if (s == 0 || s >= c.n_tokens) {
+    for (int k = threadIdx.x; k < c.k_patch; k += 256) dst[k] = 0;
+    return;
+  }
+  const int py = (s - 1) / c.grid_w, px = (s - 1) - py * c.grid_w;
+  const float* src = img + (size_t)b * 3 * c.img_h * c.img_w;
+  for (int k = threadIdx.x; k < c.k_patch; k += 256) {
+    float v = 0.f;
+    if (k < 3 * pp) {
+      const int ch = k / pp, rem = k - ch * pp, ky = rem / c.patch, kx = rem - ky * c.patch;
+      v = src[((size_t)ch * c.img_h + py * c.stride + ky) * c.img_w + px * c.stride + kx];
+    }
+    dst[k] = f2bf(v);
+  }
+}
+
+// ======================================================================================
+// LayerNorm: fp32 row -> bf16 row (or fp32 output for the final norm), one wave per row
+// ======================================================================================
+template <bool FINAL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b,
+                                                        bf16_t* __restrict__ y_bf16,
+                                                        float* __restrict__ y_f32, int rows,
+                                                        int dim, float eps, int s_pad,
+                                                        int n_tokens) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  size_t in_row = row;
+  if (FINAL) {  // output row = b*(n_tokens-1) + (s-1), input row = b*s_pad + s, s = 1..n_tokens-1
+    const int per = n_tokens - 1;
+    const int bb = row / per, s = row - bb * per + 1;
+    in_row = (size_t)bb * s_pad + s;
+  }
+  const float4* xr = reinterpret_cast<const float4*>(x + in_row * dim);
+  const int nq = dim >> 2;
+  float4 v[4];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      v[i] = xr[q];
+      sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)dim;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      const float a = v[i].x - mean, bq = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
+      var += a * a + bq * bq + cq * cq + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(var) / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      const float4 ww = reinterpret_cast<const float4*>(w)[q];
+      const float4 bb = reinterpret_cast<const float4*>(b)[q];
+      const float o0 = (v[i].x - mean) * rstd * ww.x + bb.x, o1 = (v[i].y - mean) * rstd * ww.y + bb.y;
+      const float o2 = (v[i].z - mean) * rstd * ww.z + bb.z, o3 = (v[i].w - mean) * rstd * ww.w + bb.w;
+      if (FINAL) {
+        reinterpret_cast<float4*>(y_f32 + (size_t)row * dim)[q] = make_float4(o0, o1, o2, o3);
+      } else {
+        uint2 pk;
+        pk.x = pack2(o0, o1);
+        pk.y = pack2(o2, o3);
+        reinterpret_cast<uint2*>(y_bf16 + (size_t)row * dim)[q] = pk;
+      }
+    }
+  }
+}
+
+// ======================================================================================
+// Attention (head_dim 64): one workgroup = 64 queries of one (image, head); 4 waves x 16 queries
+// ======================================================================================
+constexpr int KV_TILE = 64;
+constexpr int VT_LD = 144;  // bytes per V^T row in LDS (128 + 16): conflict-free ds_read_b64
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qk,
+                                                        const bf16_t* __restrict__ vt,
+                                                        bf16_t* __restrict__ out, int heads,
+                                                        int s_pad, int n_valid) {
+  __shared__ __attribute__((aligned(16))) char Ks[KV_TILE * 128];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * VT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lc = lane & 15;
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int dim = heads * 64, ldq = 2 * dim;
+  const size_t row0 = (size_t)b * s_pad;
+
+  // Q fragments (B operand of S^T = K.Q^T): lane column = query lc, k = d = 32*ks + 8*g + j.
+  // Pre-scaled by head_dim^-0.5 = 0.125 (exact in bf16).
+  bf16x8 qf[2];
+  {
+    const bf16_t* qrow = qk + (row0 + qb * 64 + wave * 16 + lc) * ldq + h * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      union { bf16x8 v; uint32_t u[4]; } raw;
+      raw.v = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = __uint_as_float(raw.u[j] << 16) * 0.125f;
+        const float hi = __uint_as_float(raw.u[j] & 0xffff0000u) * 0.125f;
+        raw.u[j] = pack2(lo, hi);
+      }
+      qf[ks] = raw.v;
+    }
+  }
+  const bf16_t* kbase = qk + row0 * ldq + dim + h * 64;
+  const bf16_t* vbase = vt + ((size_t)(b * heads + h) * 64) * s_pad;
+
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;  // running max / partial sum (this lane's keys only)
+  const float LOG2E = 1.4426950408889634f;
+
+  const int ntiles = (n_valid + KV_TILE - 1) / KV_TILE;
+  // register-staged K / V^T tiles: 2 x 16 B per thread per operand (chunk s = tid + 256*i)
+  const int sr0 = tid >> 3, sc = tid & 7, sr1 = sr0 + 32;
+  const bf16_t* kp0 = kbase + (size_t)sr0 * ldq + sc * 8;
+  const bf16_t* kp1 = kbase + (size_t)sr1 * ldq + sc * 8;
+  const bf16_t* vp0 = vbase + (size_t)sr0 * s_pad + sc * 8;
+  const bf16_t* vp1 = vbase + (size_t)sr1 * s_pad + sc * 8;
+  char* kd0 = Ks + sr0 * 128 + ((sc ^ (sr0 & 7)) << 4);
+  char* kd1 = Ks + sr1 * 128 + ((sc ^ (sr1 & 7)) << 4);
+  char* vd0 = Vs + sr0 * VT_LD + sc * 16;
+  char* vd1 = Vs + sr1 * VT_LD + sc * 16;
+  uint4 kr0, kr1, vr0, vr1;
+#define ATT_LOAD(kt)                                                                   \
+  do {                                                                                 \
+    kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq);         \
+    kr1 = *reinterpret_cast<const uint4*>(kp1 + (size_t)(kt) * KV_TILE * ldq);         \
+    vr0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * KV_TILE);                       \
+    vr1 = *reinterpret_cast<const uint4*>(vp1 + (kt) * KV_TILE);                       \
+  } while (0)
+#define ATT_STORE()                           \
+  do {                                        \
+    *reinterpret_cast<uint4*>(kd0) = kr0;     \
+    *reinterpret_cast<uint4*>(kd1) = kr1;     \
+    *reinterpret_cast<uint4*>(vd0) = vr0;     \
+    *reinterpret_cast<uint4*>(vd1) = vr1;     \
+  } while (0)
+  ATT_LOAD(0);
+  ATT_STORE();
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (kt + 1 < ntiles) ATT_LOAD(kt + 1);
+    // ---- S^T[key][q] = K . Q^T : acc s[mt][r] <-> key = 16*mt + 4*g + r, q = lc
+    f32x4 s[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      s[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int krow = mt * 16 + lc;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow * 128 + (((ks * 4 + g) ^ (krow & 7)) << 4));
+        s[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[mt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax over keys (a query's 64 keys live in the 4 lanes {lc + 16*g})
+    const int kbase_idx = kt * KV_TILE;
+    float tmax = -1e30f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kbase_idx + mt * 16 + 4 * g + r;
+        if (key >= n_valid) s[mt][r] = -1e30f;
+        tmax = fmaxf(tmax, s[mt][r]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = exp2f((m_run - m_new) * LOG2E);
+    const float mb = m_new * LOG2E;
+    float psum = 0.f;
+    float pv[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[mt][r] = exp2f(s[mt][r] * LOG2E - mb);
+        psum += pv[mt][r];
+      }
+    // B operand of O^T = V^T.P^T: k slot j = 4*(mt&1) + r of k-step ks = mt>>1
+    union { bf16x8 v; uint32_t u[4]; } pf0, pf1;
+    pf0.u[0] = pack2(pv[0][0], pv[0][1]); pf0.u[1] = pack2(pv[0][2], pv[0][3]);
+    pf0.u[2] = pack2(pv[1][0], pv[1][1]); pf0.u[3] = pack2(pv[1][2], pv[1][3]);
+    pf1.u[0] = pack2(pv[2][0], pv[2][1]); pf1.u[1] = pack2(pv[2][2], pv[2][3]);
+    pf1.u[2] = pack2(pv[3][0], pv[3][1]); pf1.u[3] = pack2(pv[3][2], pv[3][3]);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[i][0] *= alpha;
+      o[i][1] *= alpha;
+      o[i][2] *= alpha;
+      o[i][3] *= alpha;
+    }
+    // ---- O^T[d][q] += V^T . P^T : A rows = d (16*mt + lc), k slots <-> keys 32*ks + 16*(j>>2) + 4*g + (j&3)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const char* vrow = Vs + (mt * 16 + lc) * VT_LD + g * 8;
+      union { bf16x8 v; uint2 h[2]; } vf0, vf1;
+      vf0.h[0] = *reinterpret_cast<const uint2*>(vrow);
+      vf0.h[1] = *reinterpret_cast<const uint2*>(vrow + 32);
+      vf1.h[0] = *reinterpret_cast<const uint2*>(vrow + 64);
+      vf1.h[1] = *reinterpret_cast<const uint2*>(vrow + 96);
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0.v, pf0.v, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1.v, pf1.v, o[mt], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      ATT_STORE();
+      __syncthreads();
+    }
+  }
+#undef ATT_LOAD
+#undef ATT_STORE
+  // total row sum across the 4 key groups of the query
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+  // o[mt][r] = O[q = lc][d = 16*mt + 4*g + r]
+  bf16_t* orow = out + (row0 + qb * 64 + wave * 16 + lc) * dim + h * 64;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    uint2 pk;
+    pk.x = pack2(o[mt][0] * inv, o[mt][1] * inv);
+    pk.y = pack2(o[mt][2] * inv, o[mt][3] * inv);
+    *reinterpret_cast<uint2*>(orow + mt * 16 + 4 * g) = pk;
+  }
+}
+
+inline int64_t up256b(int64_t x) { return (x + 255) / 256 * 256; }
+
+struct VitWork {
+  float* x;
+  bf16_t *xn, *qk, *vt, *hid, *col;
+};
+
+int64_t vit_carve(const DvtVitConfig* c, int batch, char* base, VitWork* w) {
+  const int64_t T = (int64_t)batch * c->s_pad;
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) {
+    char* p = base ? base + o : nullptr;
+    o += up256b(bytes);
+    return p;
+  };
+  VitWork t;
+  t.x = (float*)take(T * c->dim * 4);
+  t.xn = (bf16_t*)take(T * c->dim * 2);
+  t.qk = (bf16_t*)take(T * 2 * c->dim * 2);
+  t.vt = (bf16_t*)take(T * c->dim * 2);
+  t.hid = (bf16_t*)take(T * c->mlp_dim * 2);
+  t.col = (bf16_t*)take(T * c->k_patch * 2);
+  if (w) *w = t;
+  return o;
+}
+
+int check_vit_cfg(const DvtVitConfig* c) {
+  if (!c || c->dim <= 0 || c->dim % 128 || c->dim > 1024 || c->heads * 64 != c->dim) return DVT_E_BADARG;
+  if (c->depth < 1 || c->depth > DVT_VIT_MAX_DEPTH || c->mlp_dim % 128) return DVT_E_BADARG;
+  if (c->s_pad % 128 || c->s_pad < c->n_tokens || c->k_patch % 64) return DVT_E_BADARG;
+  if (c->n_tokens != 1 + c->grid_h * c->grid_w) return DVT_E_BADARG;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dvt_vit_struct_sizes(int64_t* out) {
+  if (!out) return DVT_E_BADARG;
+  out[0] = sizeof(DvtVitConfig);
+  out[1] = sizeof(DvtVitBlockWeights);
+  out[2] = sizeof(DvtVitWeights);
+  return 0;
+}
+
+extern "C" int dvt_vit_config(int dim, int depth, int patch, int stride, int img_h, int img_w,
+                              DvtVitConfig* c) {
+  if (!c || dim <= 0 || dim % 64 || patch <= 0 || stride <= 0 || img_h < patch || img_w < patch)
+    return DVT_E_BADARG;
+  c->dim = dim;
+  c->depth = depth;
+  c->heads = dim / 64;
+  c->mlp_dim = 4 * dim;
+  c->patch = patch;
+  c->stride = stride;
+  c->img_h = img_h;
+  c->img_w = img_w;
+  c->grid_h = (img_h - patch) / stride + 1;  // vit_wrapper.py:84-88 dynamic_feat_size
+  c->grid_w = (img_w - patch) / stride + 1;
+  c->n_tokens = 1 + c->grid_h * c->grid_w;
+  c->s_pad = (c->n_tokens + 127) / 128 * 128;
+  c->k_patch = (3 * patch * patch + 63) / 64 * 64;
+  c->pad_ = 0;
+  c->ln_eps = 1e-6f;
+  c->pad2_ = 0.f;
+  return check_vit_cfg(c);
+}
+
+extern "C" int64_t dvt_vit_workspace_bytes(const DvtVitConfig* c, int batch) {
+  if (check_vit_cfg(c) || batch <= 0) return -1;
+  return vit_carve(c, batch, nullptr, nullptr);
+}
+
+extern "C" int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, void* y, int m,
+                                 int n, int k, void* stream) {
+  if (!x || !w || !y) return DVT_E_BADARG;
+  GemmBArgs a{};
+  a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
+  a.bias = b; a.out = (bf16_t*)y;
+  return launch_gemm<EPI_BIAS>(a, (hipStream_t)stream);
+}
+
+extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows,
+                                 int dim, float eps, void* stream) {
+  if (!x || !w || !b || !y || rows < 0 || dim <= 0 || dim % 4 || dim > 1024) return DVT_E_BADARG;
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3(dvt_cdiv(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, w, b, (bf16_t*)y, (float*)nullptr, rows, dim, eps, 0, 0);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads,
+                                 int s_pad, int n_valid, void* stream) {
+  if (!qk || !vt || !out || batch <= 0 || heads <= 0 || s_pad % 64 || n_valid <= 0 || n_valid > s_pad)
+    return DVT_E_BADARG;
+  DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
+                      4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
+  hipLaunchKernelGGL(attention_kernel, dim3(s_pad / 64, heads, batch), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads,
+                     s_pad, n_valid);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, const float* img,
+                               float* feat, int batch, int n_blocks, void* workspace,
+                               void* stream) {
+  int rc = check_vit_cfg(c);
+  if (rc) return rc;
+  if (!w || !img || !feat || !workspace || batch <= 0 || n_blocks < 0 || n_blocks > c->depth)
+    return DVT_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  VitWork k;
+  vit_carve(c, batch, (char*)workspace, &k);
+  const int T = batch * c->s_pad, D = c->dim;
+
+#define DVT_TRY(x)         \
+  do {                     \
+    int rc__ = (x);        \
+    if (rc__) return rc__; \
+  } while (0)
+
+  // patch embedding: im2col -> GEMM with the (+bias, +pos_embed, cls) epilogue
+  hipLaunchKernelGGL(im2col_kernel, dim3(T), dim3(256), 0, s, img, k.col, *c);
+  DVT_CHECK_LAUNCH();
+  {
+    GemmBArgs a{};
+    a.A = k.col; a.W = (const bf16_t*)w->patch_w; a.M = T; a.N = D; a.K = c->k_patch;
+    a.bias = w->patch_b; a.x = k.x; a.pos = w->pos_embed; a.cls = w->cls_token;
+    a.s_pad = c->s_pad; a.n_tokens = c->n_tokens; a.dim = D; a.heads = c->heads;
+    DVT_TRY(launch_gemm<EPI_EMBED>(a, s));
+  }
+  for (int l = 0; l < n_blocks; ++l) {
+    const DvtVitBlockWeights& bw = w->blocks[l];
+    DVT_TRY(dvt_vit_layernorm(k.x, bw.norm1_w, bw.norm1_b, k.xn, T, D, c->ln_eps, s));
+    {
+      GemmBArgs a{};
+      a.A = k.xn; a.W = (const bf16_t*)bw.qkv_w; a.M = T; a.N = 3 * D; a.K = D;
+      a.bias = bw.qkv_b; a.out = k.qk; a.vt = k.vt;
+      a.dim = D; a.heads = c->heads; a.s_pad = c->s_pad; a.n_tokens = c->n_tokens;
+      DVT_TRY(launch_gemm<EPI_QKV>(a, s));
+    }
+    DVT_TRY(dvt_vit_attention(k.qk, k.vt, k.xn, batch, c->heads, c->s_pad, c->n_tokens, s));
+    {
+      GemmBArgs a{};
+      a.A = k.xn; a.W = (const bf16_t*)bw.proj_w; a.M = T; a.N = D; a.K = D;
+      a.bias = bw.proj_b; a.x = k.x; a.gamma = bw.ls1;
+      DVT_TRY(launch_gemm<EPI_RESID>(a, s));
+    }
+    DVT_TRY(dvt_vit_layernorm(k.x, bw.norm2_w, bw.norm2_b, k.xn, T, D, c->ln_eps, s));
+    {
+      GemmBArgs a{};
+      a.A = k.xn; a.W = (const bf16_t*)bw.fc1_w; a.M = T; a.N = c->mlp_dim; a.K = D;
+      a.bias = bw.fc1_b; a.out = k.hid;
+      DVT_TRY(launch_gemm<EPI_GELU>(a, s));
+    }
+    {
+      GemmBArgs a{};
+      a.A = k.hid; a.W = (const bf16_t*)bw.fc2_w; a.M = T; a.N = D; a.K = c->mlp_dim;
+      a.bias = bw.fc2_b; a.x = k.x; a.gamma = bw.ls2;
+      DVT_TRY(launch_gemm<EPI_RESID>(a, s));
+    }
+  }
+#undef DVT_TRY
+  // final LayerNorm, drop cls/pad rows, NHWC fp32 straight into the feature store
+  const int out_rows = batch * (c->n_tokens - 1);
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3(dvt_cdiv(out_rows, 4)), dim3(256), 0, s, k.x,
+                     w->norm_w, w->norm_b, (bf16_t*)nullptr, feat, out_rows, D, c->ln_eps, c->s_pad,
+                     c->n_tokens);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}

@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "dvt_adam.hip",
     "dvt_fit.hip",
     "dvt_vit.hip",
+    "dvt_prof.hip",
 ]
 DVT_MAX_LEVELS = 32
 DVT_ADAM_MAX_SEGS = 8
@@ -146,7 +147,25 @@ _SIGNATURES = {
     "dvt_fit_workspace_floats": (C.c_int64, [C.POINTER(FitConfig)]),
     "dvt_fit_run": (_I, [C.POINTER(FitConfig), C.POINTER(FitBuffers), _I, _I, _P]),
     "dvt_field_infer": (_I, [C.POINTER(FitConfig), _P, _P, _P, _P, _I, _P]),
+    "dvt_prof_enable": (_I, [C.c_uint]),
+    "dvt_prof_collect": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
+
+PROBES = {"adam": 0, "vit_gemm": 1, "vit_attn": 2, "fit_gemm": 3, "grid": 4}
+
+
+def prof_enable(names=()) -> None:
+    mask = 0
+    for n in names:
+        mask |= 1 << PROBES[n]
+    check(lib().dvt_prof_enable(mask), "dvt_prof_enable")
+
+
+def prof_collect(name: str) -> dict:
+    ms, cnt, work = C.c_double(), C.c_int64(), C.c_double()
+    check(lib().dvt_prof_collect(PROBES[name], C.byref(ms), C.byref(cnt), C.byref(work)),
+          "dvt_prof_collect")
+    return {"total_ms": ms.value, "launches": cnt.value, "work": work.value}
 
 _lib = None
 
@@ -154,6 +173,10 @@ _lib = None
 def register_signatures(extra: dict) -> None:
     """Other binding modules (ViT) add their entry points here before the first load."""
     _SIGNATURES.update(extra)
+    if _lib is not None:  # already loaded: type the new entry points right away
+        for name, (res, args) in extra.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

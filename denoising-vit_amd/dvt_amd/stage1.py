@@ -1,0 +1,199 @@
+"""Stage-1 driver: per image, frozen-ViT features of 768 random views + the original, then
+the fused neural-field fit, then the two .npy outputs.
+
+Mirrors the reference's main_img_denoising.py (CLI flags :152-208 with the same names and
+defaults, work-list handling :226-234, per-image flow :301-352, output layout :131-146,
+resume by file existence :303-307) and the sharding of sample_scripts/stage1.sh (one
+process per GPU, disjoint contiguous slices, no collective in the loop).
+
+    python -m dvt_amd.stage1 --img_path demo/cat.jpg --num_iters 1000 --warmup_iters 100 \\
+        --data_root demo --save_root out/
+
+Multi-GPU: launch with torch.distributed.run (one rank per GPU); each rank takes
+`misc.shard_range(start_idx, num_imgs, rank, world)` of the work-list.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import views as V
+from .fit import FitEngine, FitSettings
+from .models import MODEL_LIST, PretrainedViTWrapper
+from .utils import misc
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser(description="DVT Stage-1: Single Image Denoising (MI355X)")
+    p.add_argument("--model", type=str, default="vit_base_patch14_dinov2.lvd142m", choices=MODEL_LIST)
+    p.add_argument("--input_size", type=int, default=518, nargs="+")
+    p.add_argument("--stride_size", type=int, default=14)
+    p.add_argument("--layer_depth_ratio", type=float, default=1.0)
+    p.add_argument("--img_path", type=str, default="demo/assets/demo/cat.jpg")
+    p.add_argument("--dtype", type=str, default="float32")
+    p.add_argument("--data_root", type=str, default=None)
+    p.add_argument("--save_root", type=str, default=None)
+    p.add_argument("--start_idx", type=int, default=0)
+    p.add_argument("--num_imgs", type=int, default=100)
+    p.add_argument("--num_views", type=int, default=768)
+    p.add_argument("--num_iters", type=int, default=25000)
+    p.add_argument("--warmup_iters", type=int, default=2500)
+    p.add_argument("--n_levels", type=int, default=16)
+    p.add_argument("--freeze_shared_artifacts_after", type=float, default=0.5)
+    p.add_argument("--lr", type=float, default=0.01)
+    p.add_argument("--min_lr", type=float, default=0.001)
+    p.add_argument("--weight_decay", type=float, default=1e-5)
+    p.add_argument("--extract_bsz", type=int, default=32)
+    p.add_argument("--pixel_bsz", type=int, default=2048)
+    p.add_argument("--output_dir", type=str, default="./work_dirs/demo")
+    p.add_argument("--num_vis_samples", type=int, default=5)
+    p.add_argument("--vis_freq", type=int, default=100)
+    p.add_argument("--seed", type=int, default=0)
+    # additions of this build
+    p.add_argument("--vit_checkpoint", type=str, default=None, help="timm-layout state dict (.pth)")
+    p.add_argument("--synthetic", action="store_true", help="N(0,1) views instead of image crops")
+    args = p.parse_args(argv)
+    if isinstance(args.input_size, int):
+        args.input_size = (args.input_size, args.input_size)
+    elif len(args.input_size) == 1:
+        args.input_size = (args.input_size[0], args.input_size[0])
+    args.input_size = tuple(args.input_size)
+    assert args.input_size[0] % args.stride_size == 0, "height must be divisible by stride_size"
+    assert args.input_size[1] % args.stride_size == 0, "width must be divisible by stride_size"
+    return args
+
+
+def work_list(args) -> list[str]:
+    """main_img_denoising.py:226-234."""
+    if os.path.isfile(args.img_path):
+        if args.img_path.endswith("txt"):
+            with open(args.img_path) as f:
+                names = f.read().splitlines()
+        else:
+            names = [args.img_path]
+    else:
+        names = glob.glob(os.path.join(args.img_path, "**/*"), recursive=True)
+    return names[args.start_idx: args.start_idx + args.num_imgs]
+
+
+class Stage1:
+    """Holds everything that is reused across images on one GPU: ViT weights, the view /
+    feature / coordinate buffers (main_img_denoising.py:261-276) and the fit engine."""
+
+    def __init__(self, args, device, vit: PretrainedViTWrapper | None = None):
+        self.args, self.device = args, torch.device(device)
+        self.vit = vit or PretrainedViTWrapper(args.model, stride=args.stride_size,
+                                               checkpoint_path=getattr(args, "vit_checkpoint", None),
+                                               img_size=args.input_size)
+        v = self.vit
+        self.layer_index = int(args.layer_depth_ratio * v.last_layer_index)
+        self.pos_h = (args.input_size[0] - v.patch_size) // args.stride_size + 1
+        self.pos_w = (args.input_size[1] - v.patch_size) // args.stride_size + 1
+        self.feat_dim = v.n_output_dims
+        n = args.num_views + 1
+        dev = self.device
+        self.views = torch.zeros((n, 3, *args.input_size), device=dev)
+        self.coords = torch.zeros((n, self.pos_h, self.pos_w, 2), device=dev)
+        self.features = torch.zeros((n, self.pos_h, self.pos_w, self.feat_dim), device=dev)
+        s = FitSettings(feat_dim=self.feat_dim, noise_map_height=self.pos_h,
+                        noise_map_width=self.pos_w, n_levels=args.n_levels,
+                        num_iters=args.num_iters, warmup_iters=args.warmup_iters,
+                        freeze_shared_artifacts_after=args.freeze_shared_artifacts_after,
+                        lr=args.lr, min_lr=args.min_lr, weight_decay=args.weight_decay,
+                        pixel_bsz=args.pixel_bsz)
+        self.engine = FitEngine(s, n * self.pos_h * self.pos_w, dev)
+        self.gen = torch.Generator(device=dev).manual_seed(args.seed)
+        self.timings = []
+
+    def extract(self) -> None:
+        """Feature extraction of all views into the feature store (:315-339), NHWC, no
+        NCHW round trip; batches of 128 views keep every GEMM at M = 128*1408 rows."""
+        with torch.no_grad():
+            self.vit.features_nhwc(self.views, self.layer_index, out=self.features)
+
+    def fit(self, log_every: int = 1000) -> torch.Tensor:
+        """denoise_an_image (:28-149): fresh models, the loop, then F on the original image's
+        lattice (quirk Q7).  Returns denoised_feats [1, H, W, C] (device)."""
+        e = self.engine
+        e.reset(self.gen)
+        C = self.feat_dim
+        e.fit(self.features.view(-1, C), self.coords.view(-1, 2), None, log_every=log_every)
+        return e.infer(self.coords[-1]).unsqueeze(0)
+
+    def process(self, set_views, save_paths=None):
+        """One image: set_views() fills self.views / self.coords; returns (raw, denoised) on
+        the host and records the reference's two timers (:341, :355)."""
+        set_views()
+        torch.cuda.synchronize(self.device)
+        t0 = time.time()
+        self.extract()
+        torch.cuda.synchronize(self.device)
+        t1 = time.time()
+        den = self.fit()
+        raw_h = self.features[-1].float().cpu().numpy()
+        den_h = den.float().cpu().numpy()
+        t2 = time.time()
+        self.timings.append({"t_extract": t1 - t0, "t_fit": t2 - t1})
+        if save_paths is not None:
+            misc.atomic_save_npy(save_paths[0], raw_h)  # [H, W, C]
+            misc.atomic_save_npy(save_paths[1], den_h)  # [1, H, W, C]
+        return raw_h, den_h
+
+
+def main(args, rank: int = 0, world: int = 1):
+    os.makedirs(args.output_dir, exist_ok=True)
+    misc.fix_random_seeds(args.seed)
+    if rank == 0:
+        print(f"Arguments:\n{json.dumps(vars(args), indent=4)}")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(device)
+    names = work_list(args)
+    lo, hi = misc.shard_range(0, len(names), rank, world)
+    names = names[lo:hi]
+    st = Stage1(args, device)
+    norm = st.vit.transformation.transforms[-1]
+    start = time.time()
+    done = 0
+    for idx, filename in enumerate(names):
+        filename = filename.strip().split(" ")[0]
+        paths = None
+        if args.data_root is not None:
+            filename = os.path.join(args.data_root, filename)
+            if misc.check_if_file_exists(args, filename):
+                print(f"Skipping {filename}")
+                continue
+            paths = misc.output_paths(args.save_root, args.model, args.data_root, filename)
+
+        def set_views():
+            if args.synthetic:
+                v, c = V.synthetic_views(args.num_views, args.input_size, st.pos_h, st.pos_w,
+                                         device, seed=args.seed + idx)
+                st.views.copy_(v)
+                st.coords.copy_(c)
+            else:
+                img = V.load_image(filename, args.input_size, norm.mean, norm.std, device)
+                boxes, coords = V.sample_view_boxes(args.num_views, args.input_size, st.pos_h, st.pos_w)
+                V.render_views(img, boxes, st.views)
+                st.coords.copy_(coords.to(device))
+
+        st.process(set_views, paths)
+        done += 1
+        t = st.timings[-1]
+        print(f"[rank {rank}] [{idx + 1}/{len(names)}] {filename}: Feature extraction time: "
+              f"{t['t_extract']:.2f}s, Denoising time: {t['t_fit']:.2f}s")
+        with open(os.path.join(args.output_dir, f"timings_rank{rank}.jsonl"), "a") as f:
+            f.write(json.dumps({"file": filename, **t}) + "\n")
+    print(f"[rank {rank}] {done} images in {time.time() - start:.1f}s")
+    return done
+
+
+if __name__ == "__main__":
+    a = get_args()
+    r, w = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    main(a, r, w)

@@ -1,0 +1,196 @@
+"""Host side of the HIP ViT extractor (csrc/dvt_vit.hip, C ABI in include/dvt_vit.h).
+
+Weights are accepted in the timm `VisionTransformer` state-dict layout the reference loads
+(`timm.create_model(model_identifier, pretrained=True, num_classes=0, dynamic_img_size=True)`,
+dvt/models/vit_wrapper.py:105-120): patch_embed.proj.{weight,bias}, cls_token, pos_embed,
+blocks.N.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,mlp.fc1,mlp.fc2,ls2.gamma}, norm.
+There is no network here, so checkpoints come from a local file or are randomly initialised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+DVT_VIT_MAX_DEPTH = 48
+
+
+class VitConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim", "depth", "heads", "mlp_dim", "patch", "stride", "img_h", "img_w", "grid_h",
+        "grid_w", "n_tokens", "s_pad", "k_patch", "pad_")] + [("ln_eps", C.c_float),
+                                                              ("pad2_", C.c_float)]
+
+
+class VitBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "norm2_w", "norm2_b",
+        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("patch_w", "patch_b", "cls_token", "pos_embed", "norm_w",
+                                          "norm_b")] + [("blocks", VitBlockWeights * DVT_VIT_MAX_DEPTH)]
+
+
+_P, _I = C.c_void_p, C.c_int
+_lib.register_signatures({
+    "dvt_vit_config": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(VitConfig)]),
+    "dvt_vit_workspace_bytes": (C.c_int64, [C.POINTER(VitConfig), _I]),
+    "dvt_vit_struct_sizes": (_I, [C.POINTER(C.c_int64)]),
+    "dvt_vit_forward": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
+    "dvt_vit_gemm_bias": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dvt_vit_layernorm": (_I, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
+    "dvt_vit_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+})
+
+
+@dataclass(frozen=True)
+class VitSpec:
+    dim: int
+    depth: int
+    patch: int = 14
+    img_size: int = 518
+    ls_init: float = 1e-5  # DINOv2 LayerScale init
+
+
+# the two backbones of BASELINE.json (of the 20 ids in the reference's MODEL_LIST)
+SPECS = {
+    "vit_base_patch14_dinov2.lvd142m": VitSpec(768, 12),
+    "vit_large_patch14_dinov2.lvd142m": VitSpec(1024, 24),
+}
+
+
+def vit_config(dim: int, depth: int, patch: int, stride: int, img_h: int, img_w: int) -> VitConfig:
+    cfg = VitConfig()
+    _lib.check(_lib.lib().dvt_vit_config(dim, depth, patch, stride, img_h, img_w, C.byref(cfg)),
+               "dvt_vit_config")
+    sizes = (C.c_int64 * 3)()
+    _lib.lib().dvt_vit_struct_sizes(sizes)
+    if list(sizes) != [C.sizeof(VitConfig), C.sizeof(VitBlockWeights), C.sizeof(VitWeights)]:
+        raise _lib.DvtError("ViT struct layout mismatch between ctypes and C")
+    return cfg
+
+
+def random_state_dict(dim: int, depth: int, patch: int, n_tokens: int, seed: int = 0,
+                      ls_gamma: float | None = 1e-5, well_conditioned: bool = False) -> dict:
+    """Random-init weights in the timm layout (trunc_normal(0.02)-like matrices).  With
+    `well_conditioned` biases / LayerScale / norm affine are random O(1) so that parity tests
+    exercise every term (LayerScale 1e-5 would hide block errors)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, std=0.02: torch.randn(*s, generator=g) * std  # noqa: E731
+    sd = {
+        "patch_embed.proj.weight": rn(dim, 3, patch, patch, std=0.05 if well_conditioned else 0.02),
+        "patch_embed.proj.bias": rn(dim, std=0.1) if well_conditioned else torch.zeros(dim),
+        "cls_token": rn(1, 1, dim, std=0.5 if well_conditioned else 1e-6),
+        "pos_embed": rn(1, n_tokens, dim, std=0.5 if well_conditioned else 0.02),
+        "norm.weight": 1 + rn(dim, std=0.2) if well_conditioned else torch.ones(dim),
+        "norm.bias": rn(dim, std=0.2) if well_conditioned else torch.zeros(dim),
+    }
+    ws = 1.0 / math.sqrt(dim) if well_conditioned else 0.02
+    for i in range(depth):
+        p = f"blocks.{i}."
+        for nm in ("norm1", "norm2"):
+            sd[p + nm + ".weight"] = 1 + rn(dim, std=0.2) if well_conditioned else torch.ones(dim)
+            sd[p + nm + ".bias"] = rn(dim, std=0.2) if well_conditioned else torch.zeros(dim)
+        sd[p + "attn.qkv.weight"] = rn(3 * dim, dim, std=ws * (2.0 if well_conditioned else 1.0))
+        sd[p + "attn.qkv.bias"] = rn(3 * dim, std=0.2) if well_conditioned else torch.zeros(3 * dim)
+        sd[p + "attn.proj.weight"] = rn(dim, dim, std=ws)
+        sd[p + "attn.proj.bias"] = rn(dim, std=0.2) if well_conditioned else torch.zeros(dim)
+        sd[p + "mlp.fc1.weight"] = rn(4 * dim, dim, std=ws)
+        sd[p + "mlp.fc1.bias"] = rn(4 * dim, std=0.2) if well_conditioned else torch.zeros(4 * dim)
+        sd[p + "mlp.fc2.weight"] = rn(dim, 4 * dim, std=ws * 0.5)
+        sd[p + "mlp.fc2.bias"] = rn(dim, std=0.2) if well_conditioned else torch.zeros(dim)
+        for nm in ("ls1", "ls2"):
+            sd[p + nm + ".gamma"] = (0.5 + torch.rand(dim, generator=g) if well_conditioned
+                                     else torch.full((dim,), float(ls_gamma)))
+    return sd
+
+
+class HipViT:
+    """Device-resident weights + the forward launcher."""
+
+    def __init__(self, state_dict: dict, patch: int, stride: int, img_size: tuple[int, int],
+                 device: torch.device | str = "cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DvtError("HipViT needs a HIP device; there is no CPU fallback")
+        sd = {k: v.detach() for k, v in state_dict.items()}
+        dim = sd["pos_embed"].shape[-1]
+        depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+        self.cfg = vit_config(dim, depth, patch, stride, img_size[0], img_size[1])
+        cfg = self.cfg
+        if sd["pos_embed"].shape[1] != cfg.n_tokens:
+            raise _lib.DvtError(
+                f"pos_embed has {sd['pos_embed'].shape[1]} tokens, the {cfg.grid_h}x{cfg.grid_w} "
+                "grid needs {cfg.n_tokens}: pos-embed resampling (other strides/sizes) is out of "
+                "scope of this build (SURVEY.md N4)")
+        dev = self.device
+        self._keep = []
+
+        def f32(t):
+            t = t.to(dev, torch.float32).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        def bf16(t):
+            t = t.to(dev, torch.float32).to(torch.bfloat16).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        w = VitWeights()
+        pw = sd["patch_embed.proj.weight"].reshape(dim, -1).float()
+        pw_pad = torch.zeros(dim, cfg.k_patch)
+        pw_pad[:, : pw.shape[1]] = pw
+        w.patch_w, w.patch_b = bf16(pw_pad), f32(sd["patch_embed.proj.bias"])
+        w.cls_token, w.pos_embed = f32(sd["cls_token"].reshape(-1)), f32(sd["pos_embed"].reshape(-1, dim))
+        w.norm_w, w.norm_b = f32(sd["norm.weight"]), f32(sd["norm.bias"])
+        for i in range(depth):
+            p, b = f"blocks.{i}.", w.blocks[i]
+            b.norm1_w, b.norm1_b = f32(sd[p + "norm1.weight"]), f32(sd[p + "norm1.bias"])
+            b.qkv_w, b.qkv_b = bf16(sd[p + "attn.qkv.weight"]), f32(sd[p + "attn.qkv.bias"])
+            b.proj_w, b.proj_b = bf16(sd[p + "attn.proj.weight"]), f32(sd[p + "attn.proj.bias"])
+            b.ls1 = f32(sd.get(p + "ls1.gamma", torch.ones(dim)))
+            b.norm2_w, b.norm2_b = f32(sd[p + "norm2.weight"]), f32(sd[p + "norm2.bias"])
+            b.fc1_w, b.fc1_b = bf16(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"])
+            b.fc2_w, b.fc2_b = bf16(sd[p + "mlp.fc2.weight"]), f32(sd[p + "mlp.fc2.bias"])
+            b.ls2 = f32(sd.get(p + "ls2.gamma", torch.ones(dim)))
+        self.weights = w
+        self._ws = None
+        self._ws_batch = 0
+
+    def _workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or self._ws_batch < batch:
+            nbytes = int(_lib.lib().dvt_vit_workspace_bytes(C.byref(self.cfg), batch))
+            self._ws = torch.zeros(nbytes, device=self.device, dtype=torch.uint8)
+            self._ws_batch = batch
+        return self._ws
+
+    def forward_features(self, img: torch.Tensor, n_blocks: int | None = None,
+                         out: torch.Tensor | None = None, max_batch: int = 128) -> torch.Tensor:
+        """img [B,3,H,W] fp32 (normalised) -> [B, grid_h, grid_w, dim] fp32 (NHWC), the final-norm'ed
+        patch tokens after `n_blocks` blocks.  `out` may be a slice of the feature store."""
+        _lib.require_cuda(img)
+        cfg = self.cfg
+        if img.dtype != torch.float32 or tuple(img.shape[1:]) != (3, cfg.img_h, cfg.img_w):
+            raise _lib.DvtError(f"expected fp32 [B,3,{cfg.img_h},{cfg.img_w}], got {tuple(img.shape)} {img.dtype}")
+        img = img.contiguous()
+        B = img.shape[0]
+        n_blocks = cfg.depth if n_blocks is None else n_blocks
+        if out is None:
+            out = torch.empty((B, cfg.grid_h, cfg.grid_w, cfg.dim), device=self.device, dtype=torch.float32)
+        if not out.is_contiguous() or tuple(out.shape) != (B, cfg.grid_h, cfg.grid_w, cfg.dim):
+            raise _lib.DvtError("out must be a contiguous [B, grid_h, grid_w, dim] fp32 tensor")
+        ws = self._workspace(min(B, max_batch))
+        L = _lib.lib()
+        for b0 in range(0, B, max_batch):
+            nb = min(max_batch, B - b0)
+            _lib.check(L.dvt_vit_forward(C.byref(cfg), C.byref(self.weights), img[b0:].data_ptr(),
+                                         out[b0:].data_ptr(), nb, n_blocks, ws.data_ptr(),
+                                         _lib.stream()), "dvt_vit_forward")
+        return out
+

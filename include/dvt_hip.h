@@ -230,6 +230,23 @@ int dvt_fit_run(const DvtFitConfig* h_cfg, const DvtFitBuffers* h_bufs, int step
 int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float* xy, float* out,
                     float* workspace, int n, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * In-library profiling probes: hipEventRecord pairs on the LAUNCH stream around selected
+ * kernel launches, so that bench.py can report per-kernel durations measured inside its
+ * timed region (torch.cuda.Event only sees torch's current stream).
+ * ---------------------------------------------------------------------------------- */
+#define DVT_PROBE_ADAM 0      /* fused Adam launches; work = algorithmic bytes (24 B/param + grads) */
+#define DVT_PROBE_VIT_GEMM 1  /* bf16 MFMA GEMM launches of the ViT; work = 2*M*N*K flops */
+#define DVT_PROBE_VIT_ATTN 2  /* attention launches; work = 4*S*S*64*heads*batch flops */
+#define DVT_PROBE_FIT_GEMM 3  /* fp32 MFMA linear fwd/bwd launches; work = flops */
+#define DVT_PROBE_GRID 4      /* hash-grid fwd+bwd launches; work = algorithmic bytes */
+#define DVT_N_PROBES 8
+/* HOST: enable probes whose bit is set in mask (0 disables all); resets accumulated samples. */
+int dvt_prof_enable(unsigned mask);
+/* HOST: synchronises the recorded events of `probe` and returns the summed duration (ms), the
+ * number of launches sampled and the summed work units; clears the probe's samples.      */
+int dvt_prof_collect(int probe, double* h_total_ms, int64_t* h_count, double* h_work);
+
 #ifdef __cplusplus
 }
 #endif

