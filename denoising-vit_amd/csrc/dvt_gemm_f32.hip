@@ -24,10 +24,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int LDK = BK + 1;  // [row][k] layout
-constexpr int LDR = 64;      // [k][row] layout
-constexpr int TILE_FLOATS = 64 * LDK;  // 2112 >= 32*64
+constexpr int BK = 32;
+constexpr int LDK = BK + 1;  // [row][k] layout, conflict-free for scalar writes + fragment reads
 
 struct GemmArgs {
   const float* A;
@@ -44,58 +42,71 @@ struct GemmArgs {
   int atomic;  // accumulate into C with atomics
 };
 
-// ---- global -> register tile loads (2 float4 per thread per operand) ----
-template <bool KCONTIG>
-__device__ __forceinline__ void load_tile(const float* __restrict__ X, int ld, int r0, int R,
-                                          int k0, int kend, int tid, float4 regs[2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int f = tid + 256 * i;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KCONTIG) {
-      const int r = f >> 3, kq = f & 7;
-      const int gr = r0 + r, gk = k0 + 4 * kq;
-      if (gr < R && gk < kend) v = *reinterpret_cast<const float4*>(X + (size_t)gr * ld + gk);
-    } else {
-      const int k = f >> 4, rq = f & 15;
-      const int gk = k0 + k, gr = r0 + 4 * rq;
-      if (gk < kend && gr < R) v = *reinterpret_cast<const float4*>(X + (size_t)gk * ld + gr);
-    }
-    regs[i] = v;
-  }
-}
+// Operand tile of R rows x BK: R*BK/4 float4, spread over NT threads.
+template <bool KCONTIG, int R, int NT>
+struct Tile {
+  static constexpr int NF4 = R * BK / 4;
+  static constexpr int ITERS = (NF4 + NT - 1) / NT;
+  static constexpr int LDS_FLOATS = KCONTIG ? R * LDK : BK * R;
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 regs[2]) {
+  __device__ static __forceinline__ void load(const float* __restrict__ X, int ld, int r0, int Rmax,
+                                              int k0, int kend, int tid, float4 regs[ITERS]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int f = tid + 256 * i;
-    if (KCONTIG) {
-      const int r = f >> 3, kq = f & 7;
-      float* d = S + r * LDK + 4 * kq;  // bank = (r + 4kq + j) % 32: conflict-free
-      d[0] = regs[i].x;
-      d[1] = regs[i].y;
-      d[2] = regs[i].z;
-      d[3] = regs[i].w;
-    } else {
-      const int k = f >> 4, rq = f & 15;
-      *reinterpret_cast<float4*>(S + k * LDR + 4 * rq) = regs[i];
+    for (int i = 0; i < ITERS; ++i) {
+      const int f = tid + NT * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NF4 % NT == 0 || f < NF4) {
+        if (KCONTIG) {
+          const int r = f / (BK / 4), kq = f % (BK / 4);
+          const int gr = r0 + r, gk = k0 + 4 * kq;
+          if (gr < Rmax && gk < kend) v = *reinterpret_cast<const float4*>(X + (size_t)gr * ld + gk);
+        } else {
+          const int k = f / (R / 4), rq = f % (R / 4);
+          const int gk = k0 + k, gr = r0 + 4 * rq;
+          if (gk < kend && gr < Rmax) v = *reinterpret_cast<const float4*>(X + (size_t)gk * ld + gr);
+        }
+      }
+      regs[i] = v;
     }
   }
-}
 
-template <bool KCONTIG>
-__device__ __forceinline__ float frag(const float* __restrict__ S, int row, int k) {
-  return KCONTIG ? S[row * LDK + k] : S[k * LDR + row];
-}
+  __device__ static __forceinline__ void store(float* __restrict__ S, int tid,
+                                               const float4 regs[ITERS]) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int f = tid + NT * i;
+      if (NF4 % NT == 0 || f < NF4) {
+        if (KCONTIG) {
+          const int r = f / (BK / 4), kq = f % (BK / 4);
+          float* d = S + r * LDK + 4 * kq;  // bank = (r + 4kq + j) % 32: conflict-free
+          d[0] = regs[i].x;
+          d[1] = regs[i].y;
+          d[2] = regs[i].z;
+          d[3] = regs[i].w;
+        } else {
+          const int k = f / (R / 4), rq = f % (R / 4);
+          *reinterpret_cast<float4*>(S + k * R + 4 * rq) = regs[i];
+        }
+      }
+    }
+  }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[TILE_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[TILE_FLOATS];
+  __device__ static __forceinline__ float frag(const float* __restrict__ S, int row, int k) {
+    return KCONTIG ? S[row * LDK + k] : S[k * R + row];
+  }
+};
+
+// WM x WN waves, each owning one 32x32 accumulator: tile (32*WM) x (32*WN).
+template <bool A_KC, bool B_KC, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
+  constexpr int NT = 64 * WM * WN, BM = 32 * WM, BN = 32 * WN;
+  using TA = Tile<A_KC, BM, NT>;
+  using TB = Tile<B_KC, BN, NT>;
+  __shared__ __attribute__((aligned(16))) float As[TA::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[TB::LDS_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int kbeg = blockIdx.z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
@@ -107,27 +118,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   float csum = 0.f;
   const bool do_colsum = (!A_KC) && p.colsum != nullptr && blockIdx.x == 0;
 
-  float4 ra[2], rb[2];
-  load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
-  load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+  float4 ra[TA::ITERS], rb[TB::ITERS];
+  TA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
+  TB::load(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tile<A_KC>(As, tid, ra);
-    store_tile<B_KC>(Bs, tid, rb);
+    TA::store(As, tid, ra);
+    TB::store(Bs, tid, rb);
     __syncthreads();
     if (k0 + BK < kend) {  // prefetch the next tile while the MFMAs run
-      load_tile<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra);
-      load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb);
+      TA::load(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra);
+      TB::load(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb);
     }
     const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const float a = frag<A_KC>(As, ar, 2 * kk + kh);
-      const float b = frag<B_KC>(Bs, bc, 2 * kk + kh);
+      const float a = TA::frag(As, ar, 2 * kk + kh);
+      const float b = TB::frag(Bs, bc, 2 * kk + kh);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (do_colsum && tid < 64) {
+    if (do_colsum && tid < BM) {
 #pragma unroll 8
-      for (int k = 0; k < BK; ++k) csum += As[k * LDR + tid];
+      for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
     }
     __syncthreads();
   }
@@ -150,19 +161,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         *c = v;
     }
   }
-  if (do_colsum && tid < 64 && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
+  if (do_colsum && tid < BM && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
 }
 
-template <bool A_KC, bool B_KC>
-int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
-  dim3 grid(dvt_cdiv(a.N, BN), dvt_cdiv(a.M, BM), ksplits);
+// Tile configurations: 0 = 64x64 (4 waves), 1 = 32x64 (2 waves), 2 = 32x32 (1 wave), 3 = 64x32.
+int g_cfg_override = -1;
+
+struct TileCfg {
+  int bm, bn;
+};
+constexpr TileCfg kCfgs[4] = {{64, 64}, {32, 64}, {32, 32}, {64, 32}};
+
+// The batch is small (2048 rows): pick the largest tile that still yields >= ~2 workgroups
+// per CU worth of waves, so that barrier / load phases of one wave hide behind another's MFMAs.
+int pick_cfg(int M, int N, int ksplits) {
+  if (g_cfg_override >= 0 && g_cfg_override < 4) return g_cfg_override;
+  for (int c : {0, 1, 2}) {
+    const long long waves = (long long)dvt_cdiv(M, 32) * dvt_cdiv(N, 32) * ksplits;
+    const long long wgs = (long long)dvt_cdiv(M, kCfgs[c].bm) * dvt_cdiv(N, kCfgs[c].bn) * ksplits;
+    (void)waves;
+    if (wgs >= 512) return c;
+  }
+  return 2;
+}
+
+template <bool A_KC, bool B_KC, int WM, int WN>
+int launch_cfg(const GemmArgs& a, int ksplits, hipStream_t s) {
+  dim3 grid(dvt_cdiv(a.N, 32 * WN), dvt_cdiv(a.M, 32 * WM), ksplits);
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
-  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a);
   DVT_CHECK_LAUNCH();
   return 0;
 }
 
+template <bool A_KC, bool B_KC>
+int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
+  switch (pick_cfg(a.M, a.N, ksplits)) {
+    case 0: return launch_cfg<A_KC, B_KC, 2, 2>(a, ksplits, s);
+    case 1: return launch_cfg<A_KC, B_KC, 1, 2>(a, ksplits, s);
+    case 3: return launch_cfg<A_KC, B_KC, 2, 1>(a, ksplits, s);
+    default: return launch_cfg<A_KC, B_KC, 1, 1>(a, ksplits, s);
+  }
+}
+
 }  // namespace
+
+extern "C" int dvt_tune_set(int key, int value) {
+  if (key == 0) {
+    g_cfg_override = value;
+    return 0;
+  }
+  return DVT_E_BADARG;
+}
 
 extern "C" int dvt_linear_fwd(const float* x, const float* w, const float* b, float* y, int m,
                               int n, int k, int relu, void* stream) {
@@ -192,7 +242,7 @@ extern "C" int dvt_linear_bwd(const float* dy, const float* x, const float* w, f
     a.lda = n; a.ldb = k; a.ldc = k;
     a.colsum = db;
     a.atomic = 1;
-    const int tiles = dvt_cdiv(n, BM) * dvt_cdiv(k, BN);
+    const int tiles = dvt_cdiv(n, 64) * dvt_cdiv(k, 64);
     const int ktiles = dvt_cdiv(m, BK);
     int splits = dvt_cdiv(768, tiles);
     if (splits > ktiles / 2) splits = ktiles / 2;

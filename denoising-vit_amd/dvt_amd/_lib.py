@@ -147,6 +147,7 @@ _SIGNATURES = {
     "dvt_fit_workspace_floats": (C.c_int64, [C.POINTER(FitConfig)]),
     "dvt_fit_run": (_I, [C.POINTER(FitConfig), C.POINTER(FitBuffers), _I, _I, _P]),
     "dvt_field_infer": (_I, [C.POINTER(FitConfig), _P, _P, _P, _P, _I, _P]),
+    "dvt_tune_set": (_I, [_I, _I]),
     "dvt_prof_enable": (_I, [C.c_uint]),
     "dvt_prof_collect": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

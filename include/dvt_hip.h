@@ -230,6 +230,10 @@ int dvt_fit_run(const DvtFitConfig* h_cfg, const DvtFitBuffers* h_bufs, int step
 int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float* xy, float* out,
                     float* workspace, int n, void* stream);
 
+/* Tuning knob (developer use): key 0 = fp32 GEMM tile configuration override
+ * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup). */
+int dvt_tune_set(int key, int value);
+
 /* ------------------------------------------------------------------------------------
  * In-library profiling probes: hipEventRecord pairs on the LAUNCH stream around selected
  * kernel launches, so that bench.py can report per-kernel durations measured inside its

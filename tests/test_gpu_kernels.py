@@ -33,6 +33,21 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+_KEEP = []
+
+
+def P(t):
+    """Device pointer of `t` moved to the GPU; the device copy is kept alive until the end of
+    the test module (never take .data_ptr() of a temporary: the caching allocator would hand
+    its block to the next temporary before the kernel has run)."""
+    t = t.detach().to(DEV).contiguous()
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t.data_ptr()
+
+
 def edge_coords(n, seed=0):
     g = torch.Generator().manual_seed(seed)
     xy = torch.rand(n, 2, generator=g)
@@ -50,10 +65,9 @@ def test_grid_corners_bit_exact(L, cfg):
     otbl = hg.grid_table(*cfg)
     xy = edge_coords(3000)
     n = xy.shape[0]
-    d_xy = xy.to(DEV)
     idx = torch.empty((n, cfg[0], 4), device=DEV, dtype=torch.int32)
     w = torch.empty((n, cfg[0], 4), device=DEV, dtype=torch.float32)
-    assert L.dvt_grid_corners(C.byref(tbl), d_xy.data_ptr(), idx.data_ptr(), w.data_ptr(), n, _s()) == 0
+    assert L.dvt_grid_corners(C.byref(tbl), P(xy), idx.data_ptr(), w.data_ptr(), n, _s()) == 0
     oi, ow = hg.corners(otbl, xy.numpy())
     got_i = idx.cpu().numpy().astype(np.uint32)
     assert np.array_equal(got_i, oi), f"{(got_i != oi).sum()} corner indices differ"
@@ -71,13 +85,12 @@ def test_grid_fwd_bwd_vs_oracle(L):
     enc_o = hg.encode(otbl, params, xy)
     d_enc = torch.randn(n, 128)
     enc_o.backward(d_enc)
-    d_params, d_xy = params.detach().to(DEV), xy.to(DEV)
     enc = torch.empty((n, 128), device=DEV)
-    assert L.dvt_grid_fwd(C.byref(tbl), d_xy.data_ptr(), d_params.data_ptr(), enc.data_ptr(), n, _s()) == 0
+    assert L.dvt_grid_fwd(C.byref(tbl), P(xy), P(params), enc.data_ptr(), n, _s()) == 0
     assert relerr(enc, enc_o) < 2e-6
     g = torch.zeros(otbl.n_params, device=DEV)
     touched = torch.zeros((otbl.n_entries_total + 31) // 32, device=DEV, dtype=torch.int32)
-    assert L.dvt_grid_bwd(C.byref(tbl), d_xy.data_ptr(), d_enc.to(DEV).data_ptr(), g.data_ptr(),
+    assert L.dvt_grid_bwd(C.byref(tbl), P(xy), P(d_enc), g.data_ptr(),
                           touched.data_ptr(), n, _s()) == 0
     assert relerr(g, params.grad) < 2e-5
     # the bitmap marks exactly the entries any sample's corner refers to
@@ -123,14 +136,14 @@ def test_linear_bwd_relu_mask_and_transpose_detection(L):
     w = torch.arange(n * k, dtype=torch.float32).reshape(n, k) / 100.0
     x = torch.eye(64)
     Y = torch.empty((64, n), device=DEV)
-    assert L.dvt_linear_fwd(x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), None, Y.data_ptr(), 64, n, k, 0, _s()) == 0
+    assert L.dvt_linear_fwd(P(x), P(w), None, Y.data_ptr(), 64, n, k, 0, _s()) == 0
     assert torch.equal(Y.cpu(), w.t().contiguous())
     # dgrad with the fused relu mask
     torch.manual_seed(0)
     dy, W, mask = torch.randn(128, 96), torch.randn(96, 64), torch.randn(128, 64)
     DX = torch.empty((128, 64), device=DEV)
-    assert L.dvt_linear_bwd(dy.to(DEV).data_ptr(), None, W.to(DEV).data_ptr(), None, None, DX.data_ptr(),
-                            mask.to(DEV).data_ptr(), 128, 96, 64, _s()) == 0
+    assert L.dvt_linear_bwd(P(dy), None, P(W), None, None, DX.data_ptr(),
+                            P(mask), 128, 96, 64, _s()) == 0
     assert relerr(DX, (dy.double() @ W.double()) * (mask > 0)) < 2e-6
 
 
@@ -140,11 +153,11 @@ def test_gather_scatter_bilinear(L):
     src = torch.randn(500, 768)
     idx = torch.randint(0, 5000, (2048,), dtype=torch.int32)
     dst = torch.empty((2048, 768), device=DEV)
-    assert L.dvt_gather_rows(src.to(DEV).data_ptr(), idx.to(DEV).data_ptr(), dst.data_ptr(), 2048, 768, 500, _s()) == 0
+    assert L.dvt_gather_rows(P(src), P(idx), dst.data_ptr(), 2048, 768, 500, _s()) == 0
     assert torch.equal(dst.cpu(), src[(idx % 500).long()])
     acc = torch.zeros((500, 768), device=DEV)
     upd = torch.randn(2048, 768)
-    assert L.dvt_scatter_add_rows(upd.to(DEV).data_ptr(), idx.to(DEV).data_ptr(), acc.data_ptr(), 2048, 768, 500, _s()) == 0
+    assert L.dvt_scatter_add_rows(P(upd), P(idx), acc.data_ptr(), 2048, 768, 500, _s()) == 0
     want = torch.zeros(500, 768, dtype=torch.float64).index_add_(0, (idx % 500).long(), upd.double())
     assert relerr(acc, want) < 1e-5
     # bilinear == F.grid_sample(align_corners=True), generic coords + exact lattice coords
@@ -159,10 +172,10 @@ def test_gather_scatter_bilinear(L):
     ref.backward(dout)
     rows = G.detach().permute(0, 2, 3, 1).reshape(H * W, Cc).contiguous().to(DEV)
     out = torch.empty((n, Cc), device=DEV)
-    assert L.dvt_bilinear_rows_fwd(rows.data_ptr(), coords.to(DEV).data_ptr(), out.data_ptr(), n, Cc, H, W, _s()) == 0
+    assert L.dvt_bilinear_rows_fwd(rows.data_ptr(), P(coords), out.data_ptr(), n, Cc, H, W, _s()) == 0
     assert relerr(out, ref) < 2e-6
     dG = torch.zeros((H * W, Cc), device=DEV)
-    assert L.dvt_bilinear_rows_bwd(dout.to(DEV).data_ptr(), coords.to(DEV).data_ptr(), dG.data_ptr(), n, Cc, H, W, _s()) == 0
+    assert L.dvt_bilinear_rows_bwd(P(dout), P(coords), dG.data_ptr(), n, Cc, H, W, _s()) == 0
     assert relerr(dG, G.grad.permute(0, 2, 3, 1).reshape(H * W, Cc)) < 1e-5
 
 
@@ -188,11 +201,10 @@ def test_loss_fwd_bwd_vs_oracle(L, c, with_res):
         sp = 0.02 * Hm.abs().mean()
         loss = loss + rl + sp
     (loss * 1024.0).backward()
-    dv = lambda t: t.detach().to(DEV).contiguous()
     dF, dH = torch.empty((n, c), device=DEV), torch.empty((n, c), device=DEV)
     rows, out = torch.empty((n, 8), device=DEV), torch.zeros(8, device=DEV)
-    assert L.dvt_loss_fwd_bwd(dv(Fm).data_ptr(), dv(G).data_ptr(), gi.to(DEV).data_ptr(), lattice,
-                              dv(Hm).data_ptr() if with_res else None, dv(raw).data_ptr(), dF.data_ptr(),
+    assert L.dvt_loss_fwd_bwd(P(Fm), P(G), P(gi), lattice,
+                              P(Hm) if with_res else None, P(raw), dF.data_ptr(),
                               dH.data_ptr() if with_res else None, rows.data_ptr(), n, c, 1024.0, _s()) == 0
     assert L.dvt_loss_reduce(rows.data_ptr(), out.data_ptr(), n, c, int(with_res), _s()) == 0
     want = torch.stack([loss, l2, cos, rl, sp]).detach()
@@ -202,7 +214,7 @@ def test_loss_fwd_bwd_vs_oracle(L, c, with_res):
         assert relerr(dH, Hm.grad) < 1e-5
     # the G gradient is the row scatter of d_pred
     dG = torch.zeros((lattice, c), device=DEV)
-    assert L.dvt_scatter_add_rows(dF.data_ptr(), gi.to(DEV).data_ptr(), dG.data_ptr(), n, c, lattice, _s()) == 0
+    assert L.dvt_scatter_add_rows(dF.data_ptr(), P(gi), dG.data_ptr(), n, c, lattice, _s()) == 0
     assert relerr(dG, G.grad) < 1e-5
 
 

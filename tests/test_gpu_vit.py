@@ -21,6 +21,16 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+_KEEP = []
+
+
+def P(t):
+    """Device pointer with the device copy kept alive (no data_ptr() of temporaries)."""
+    t = t.detach().to(DEV).contiguous()
+    _KEEP.append(t)
+    return t.data_ptr()
+
+
 def rel(got, want):
     got, want = got.detach().double().cpu(), want.detach().double().cpu()
     return float((got - want).abs().max() / (want.abs().max() + 1e-30))
@@ -42,7 +52,7 @@ def test_gemm_bias_vs_torch(L, m, n, k):
     b = torch.randn(n)
     want = x.float() @ w.float().t() + b
     y = torch.empty((m, n), device=DEV, dtype=torch.bfloat16)
-    assert L.dvt_vit_gemm_bias(x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+    assert L.dvt_vit_gemm_bias(P(x), P(w), P(b),
                                y.data_ptr(), m, n, k, _s()) == 0
     assert rel(y.float(), want) < 6e-3, (m, n, k)
 
@@ -58,7 +68,7 @@ def test_layernorm_vs_torch(L, dim):
     x = torch.randn(300, dim) * 3 + 1.5
     w, b = torch.randn(dim), torch.randn(dim)
     y = torch.empty((300, dim), device=DEV, dtype=torch.bfloat16)
-    assert L.dvt_vit_layernorm(x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+    assert L.dvt_vit_layernorm(P(x), P(w), P(b),
                                y.data_ptr(), 300, dim, 1e-6, _s()) == 0
     assert rel(y.float(), F.layer_norm(x, (dim,), w, b, 1e-6)) < 5e-3
 
