@@ -51,3 +51,5 @@ struct DvtProbeScope {
     if (on) dvt_prof_end(probe, s, work);
   }
 };
+int dvt_vit_tune(int gemm_variant);
+int dvt_grid_tune(int lds_level_max);

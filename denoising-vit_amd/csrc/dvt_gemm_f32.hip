@@ -211,6 +211,8 @@ extern "C" int dvt_tune_set(int key, int value) {
     g_cfg_override = value;
     return 0;
   }
+  if (key == 1) return dvt_vit_tune(value);
+  if (key == 2) return dvt_grid_tune(value);
   return DVT_E_BADARG;
 }
 

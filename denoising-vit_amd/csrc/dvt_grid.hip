@@ -141,15 +141,13 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(DvtGridTable T, const flo
 //  * "direct levels" (fine, < 0.13 hits per entry): one lane per (sample, level, feature),
 //    global_atomic_add_f32, the 8 lanes of an entry hit one 32-B sector.
 // Both paths mark touched entries in the bitmap consumed by the fused Adam kernel.
-constexpr int LDS_CHUNK = 1024;        // entries per workgroup (32 KB of accumulators)
-constexpr int LDS_LEVEL_MAX = 40960;   // entries; levels above go the direct-atomic way
-constexpr int MAX_LDS_BLOCKS = 192;
+constexpr int LDS_CHUNK = 1024;  // entries per workgroup (32 KB of accumulators)
+int g_grid_lds_level_max = 40960;  // entries; levels above go the direct-atomic way (tunable)
 
 struct GridBwdPlan {
   int n_lds_blocks;
   int first_direct_level;  // levels [first_direct_level, L) use global atomics
-  unsigned short blk_level[MAX_LDS_BLOCKS];
-  unsigned int blk_e0[MAX_LDS_BLOCKS];  // first entry of the chunk, relative to the level
+  int chunk_start[DVT_MAX_LEVELS + 1];  // first LDS block of each LDS level (prefix sum)
 };
 
 __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdPlan plan,
@@ -163,9 +161,11 @@ __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdP
   const int L = T.n_levels;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < plan.n_lds_blocks) {
-    const int l = plan.blk_level[blockIdx.x];
-    const uint32_t abs0 = T.offset[l] + plan.blk_e0[blockIdx.x];  // first absolute entry
-    const uint32_t cnt = min((uint32_t)LDS_CHUNK, T.entries[l] - plan.blk_e0[blockIdx.x]);
+    int l = 0;
+    while (l + 1 < plan.first_direct_level && (int)blockIdx.x >= plan.chunk_start[l + 1]) ++l;
+    const uint32_t e0 = (uint32_t)((int)blockIdx.x - plan.chunk_start[l]) * LDS_CHUNK;
+    const uint32_t abs0 = T.offset[l] + e0;  // first absolute entry
+    const uint32_t cnt = min((uint32_t)LDS_CHUNK, T.entries[l] - e0);
     const uint32_t base32 = abs0 & ~31u;  // flags are kept in GLOBAL bitmap word alignment
     for (int i = tid; i < LDS_CHUNK * 8; i += 1024) acc[i] = 0.f;
     if (tid < LDS_CHUNK / 32 + 1) flags[tid] = 0u;
@@ -185,15 +185,15 @@ __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdP
       for (int c = 0; c < 4; ++c) {
         const uint32_t rel = idx[c] - abs0;
         if (rel < cnt) {
-          float* a = acc + rel * 8;
-          atomicAdd(a + 0, w[c] * g0.x);
-          atomicAdd(a + 1, w[c] * g0.y);
-          atomicAdd(a + 2, w[c] * g0.z);
-          atomicAdd(a + 3, w[c] * g0.w);
-          atomicAdd(a + 4, w[c] * g1.x);
-          atomicAdd(a + 5, w[c] * g1.y);
-          atomicAdd(a + 6, w[c] * g1.z);
-          atomicAdd(a + 7, w[c] * g1.w);
+          float* a = acc + rel;  // feature-major: bank = rel % 32, no stride-8 conflicts
+          atomicAdd(a + 0 * LDS_CHUNK, w[c] * g0.x);
+          atomicAdd(a + 1 * LDS_CHUNK, w[c] * g0.y);
+          atomicAdd(a + 2 * LDS_CHUNK, w[c] * g0.z);
+          atomicAdd(a + 3 * LDS_CHUNK, w[c] * g0.w);
+          atomicAdd(a + 4 * LDS_CHUNK, w[c] * g1.x);
+          atomicAdd(a + 5 * LDS_CHUNK, w[c] * g1.y);
+          atomicAdd(a + 6 * LDS_CHUNK, w[c] * g1.z);
+          atomicAdd(a + 7 * LDS_CHUNK, w[c] * g1.w);
           atomicOr(&flags[(idx[c] - base32) >> 5], 1u << (idx[c] & 31u));
         }
       }
@@ -202,11 +202,14 @@ __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdP
     for (uint32_t e = tid; e < cnt; e += 1024) {
       const uint32_t a = abs0 + e;
       if ((flags[(a - base32) >> 5] >> (a & 31u)) & 1u) {
-        const float4* src = reinterpret_cast<const float4*>(acc + e * 8);
         float4* dst = reinterpret_cast<float4*>(d_params + (size_t)a * 8);
         // single writer per entry within this launch: plain read-modify-write keeps the
         // documented "+=" semantics without atomics
-        const float4 o0 = dst[0], o1 = dst[1], s0 = src[0], s1 = src[1];
+        const float4 o0 = dst[0], o1 = dst[1];
+        const float4 s0 = make_float4(acc[e], acc[LDS_CHUNK + e], acc[2 * LDS_CHUNK + e],
+                                      acc[3 * LDS_CHUNK + e]);
+        const float4 s1 = make_float4(acc[4 * LDS_CHUNK + e], acc[5 * LDS_CHUNK + e],
+                                      acc[6 * LDS_CHUNK + e], acc[7 * LDS_CHUNK + e]);
         dst[0] = make_float4(o0.x + s0.x, o0.y + s0.y, o0.z + s0.z, o0.w + s0.w);
         dst[1] = make_float4(o1.x + s1.x, o1.y + s1.y, o1.z + s1.z, o1.w + s1.w);
       }
@@ -244,16 +247,17 @@ static void make_bwd_plan(const DvtGridTable& T, GridBwdPlan* plan) {
   plan->n_lds_blocks = 0;
   int l = 0;
   for (; l < T.n_levels; ++l) {
-    if (T.entries[l] > (uint32_t)LDS_LEVEL_MAX) break;
-    const int chunks = (int)((T.entries[l] + LDS_CHUNK - 1) / LDS_CHUNK);
-    if (plan->n_lds_blocks + chunks > MAX_LDS_BLOCKS) break;
-    for (int c = 0; c < chunks; ++c) {
-      plan->blk_level[plan->n_lds_blocks] = (unsigned short)l;
-      plan->blk_e0[plan->n_lds_blocks] = (unsigned int)c * LDS_CHUNK;
-      ++plan->n_lds_blocks;
-    }
+    if (T.entries[l] > (uint32_t)g_grid_lds_level_max) break;
+    plan->chunk_start[l] = plan->n_lds_blocks;
+    plan->n_lds_blocks += (int)((T.entries[l] + LDS_CHUNK - 1) / LDS_CHUNK);
   }
+  plan->chunk_start[l] = plan->n_lds_blocks;
   plan->first_direct_level = l;  // levels are sorted by size: the rest is fine
+}
+
+int dvt_grid_tune(int lds_level_max) {
+  g_grid_lds_level_max = lds_level_max;
+  return 0;
 }
 
 __global__ __launch_bounds__(256) void grid_corners_kernel(DvtGridTable T,

@@ -39,19 +39,22 @@ typedef unsigned short bf16_t;
 
 namespace {
 
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16, round-to-nearest-even, through the gfx950 conversion instruction
+// (v_cvt_pk_bf16_f32: one instruction per pair)
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  const hw_bf16x2 v = __builtin_convertvector((f32x2){a, b}, hw_bf16x2);
+  return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2(f, 0.f) & 0xffffu); }
 
 // ======================================================================================
 // GEMM  C[M,N] = A[M,K] . W[N,K]^T   (both operands K-contiguous bf16)
 // ======================================================================================
 constexpr int GBM = 128, GBN = 128, GBK = 64;
+int g_vit_gemm_variant = 0;  // 0: 256x128 3-stage when M % 256 == 0; 1: always 128x128 2-stage
 constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
 
 enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4 };
@@ -95,59 +98,10 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk)
   return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
+// Fused epilogues.  acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*(lane>>4) + r][n0 + wn*64 + j*16 + (lane&15)]
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs, so give every XCD a
-  // contiguous run of tiles (N fastest) -> the A row panel of a run stays in that XCD's L2.
-  const int ntn = p.N / GBN;
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int m0 = (bid / ntn) * GBM, n0 = (bid % ntn) * GBN;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / GBK;
-  stage_tile(p.A, p.K, m0, 0, smem, wave, lane);
-  stage_tile(p.W, p.K, n0, 0, smem + GBM * GBK * 2, wave, lane);
-  __syncthreads();  // waits vmcnt(0) for the LDS-DMA before releasing the workgroup
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-    if (kt + 1 < nk) {
-      stage_tile(p.A, p.K, m0, (kt + 1) * GBK, nxt, wave, lane);
-      stage_tile(p.W, p.K, n0, (kt + 1) * GBK, nxt + GBM * GBK * 2, wave, lane);
-    }
-    const char* As = cur;
-    const char* Bs = cur + GBM * GBK * 2;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
-      const int chunk = ks * 4 + (lane >> 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = read_frag(As, wm * 64 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = read_frag(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading `cur`
-  }
-
-  // ---- epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*(lane>>4) + r][n0 + wn*64 + j*16 + (lane&15)]
+__device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4][4], int m0, int n0,
+                                              int wm, int wn, int lane) {
   const int g = lane >> 4, lc = lane & 15;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -212,10 +166,153 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBArgs p) {
 }
 
 template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs, so give every XCD a
+  // contiguous run of tiles (N fastest) -> the A row panel of a run stays in that XCD's L2.
+  const int ntn = p.N / GBN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int m0 = (bid / ntn) * GBM, n0 = (bid % ntn) * GBN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GBK;
+  stage_tile(p.A, p.K, m0, 0, smem, wave, lane);
+  stage_tile(p.W, p.K, n0, 0, smem + GBM * GBK * 2, wave, lane);
+  __syncthreads();  // waits vmcnt(0) for the LDS-DMA before releasing the workgroup
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    if (kt + 1 < nk) {
+      stage_tile(p.A, p.K, m0, (kt + 1) * GBK, nxt, wave, lane);
+      stage_tile(p.W, p.K, n0, (kt + 1) * GBK, nxt + GBM * GBK * 2, wave, lane);
+    }
+    const char* As = cur;
+    const char* Bs = cur + GBM * GBK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+      const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = read_frag(As, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = read_frag(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading `cur`
+  }
+
+  gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ---- 256x128x64 tile, 8 waves (4 x 2, 64x64 each), 3 LDS stages, counted vmcnt -------------
+// The 2-stage kernel above drains its LDS-DMA queue (vmcnt(0)) at every barrier, so each
+// k-iteration costs one full L2/HBM load latency (measured 561 TF/s = 22 % of peak at K = 768).
+// Here the loads of stage kt+2 are issued while stage kt is being multiplied: one raw
+// s_barrier per iteration, `s_waitcnt vmcnt(6)` retires exactly the oldest stage (6 LDS-DMA
+// instructions per thread per stage: 4 for the 256-row A tile, 2 for the 128-row W tile).
+constexpr int G2_BM = 256, G2_STAGE = (G2_BM + GBN) * GBK * 2;  // 48 KB
+
+__device__ __forceinline__ void stage_tile_512(const bf16_t* __restrict__ X, int ld, int r0, int k0,
+                                               char* lds, int wave, int lane, int rows) {
+  const int iters = rows / 64;  // 512 threads move 64 rows (of 8 chunks) per pass
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (it < iters) {
+      const int s = it * 512 + wave * 64 + lane;
+      const int row = s >> 3, cp = s & 7;
+      const int c = cp ^ (row & 7);
+      glds16(X + (size_t)(r0 + row) * ld + k0 + c * 8, lds + (it * 512 + wave * 64) * 16);
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_kernel_256(GemmBArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * G2_STAGE];  // 144 KB, ONE LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = p.N / GBN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int m0 = (bid / ntn) * G2_BM, n0 = (bid % ntn) * GBN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GBK;
+#define G2_ISSUE(kt)                                                                            \
+  do {                                                                                          \
+    char* st_ = smem + ((kt) % 3) * G2_STAGE;                                                   \
+    stage_tile_512(p.A, p.K, m0, (kt) * GBK, st_, wave, lane, G2_BM);                           \
+    stage_tile_512(p.W, p.K, n0, (kt) * GBK, st_ + G2_BM * GBK * 2, wave, lane, GBN);           \
+  } while (0)
+  G2_ISSUE(0);
+  if (nk > 1) G2_ISSUE(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // retire stage kt (own loads), then meet: everyone's stage-kt data is in LDS and everyone
+    // has finished reading stage kt-1, whose buffer the next issue overwrites
+    if (kt + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk) G2_ISSUE(kt + 2);
+    const char* As = smem + (kt % 3) * G2_STAGE;
+    const char* Bs = As + G2_BM * GBK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+      const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = read_frag(As, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = read_frag(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef G2_ISSUE
+  gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int EPI>
 int launch_gemm(const GemmBArgs& a, hipStream_t s) {
   if (a.M % GBM || a.N % GBN || a.K % GBK || a.M <= 0) return DVT_E_BADARG;
-  const int tiles = (a.M / GBM) * (a.N / GBN);
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+  if (a.M % G2_BM == 0 && g_vit_gemm_variant != 1) {
+    const int tiles = (a.M / G2_BM) * (a.N / GBN);
+    hipLaunchKernelGGL((gemm_bf16_kernel_256<EPI>), dim3(tiles), dim3(512), 0, s, a);
+    DVT_CHECK_LAUNCH();
+    return 0;
+  }
+  const int tiles = (a.M / GBM) * (a.N / GBN);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(tiles), dim3(256), 0, s, a);
   DVT_CHECK_LAUNCH();
   return 0;
@@ -310,12 +407,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ======================================================================================
-// Attention (head_dim 64): one workgroup = 64 queries of one (image, head); 4 waves x 16 queries
+// Attention (head_dim 64): one workgroup = 128 queries of one (image, head); 8 waves x 16 queries
 // ======================================================================================
 constexpr int KV_TILE = 64;
 constexpr int VT_LD = 144;  // bytes per V^T row in LDS (128 + 16): conflict-free ds_read_b64
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qk,
+constexpr int ATT_Q = 128;  // queries per workgroup
+
+__global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict__ qk,
                                                         const bf16_t* __restrict__ vt,
                                                         bf16_t* __restrict__ out, int heads,
                                                         int s_pad, int n_valid) {
@@ -331,7 +430,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   // Pre-scaled by head_dim^-0.5 = 0.125 (exact in bf16).
   bf16x8 qf[2];
   {
-    const bf16_t* qrow = qk + (row0 + qb * 64 + wave * 16 + lc) * ldq + h * 64;
+    const bf16_t* qrow = qk + (row0 + qb * ATT_Q + wave * 16 + lc) * ldq + h * 64;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       union { bf16x8 v; uint32_t u[4]; } raw;
@@ -355,30 +454,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   const float LOG2E = 1.4426950408889634f;
 
   const int ntiles = (n_valid + KV_TILE - 1) / KV_TILE;
-  // register-staged K / V^T tiles: 2 x 16 B per thread per operand (chunk s = tid + 256*i)
-  const int sr0 = tid >> 3, sc = tid & 7, sr1 = sr0 + 32;
+  // register-staged K / V^T tiles: one 16-B chunk per thread per operand (512 chunks each)
+  const int sr0 = tid >> 3, sc = tid & 7;
   const bf16_t* kp0 = kbase + (size_t)sr0 * ldq + sc * 8;
-  const bf16_t* kp1 = kbase + (size_t)sr1 * ldq + sc * 8;
   const bf16_t* vp0 = vbase + (size_t)sr0 * s_pad + sc * 8;
-  const bf16_t* vp1 = vbase + (size_t)sr1 * s_pad + sc * 8;
   char* kd0 = Ks + sr0 * 128 + ((sc ^ (sr0 & 7)) << 4);
-  char* kd1 = Ks + sr1 * 128 + ((sc ^ (sr1 & 7)) << 4);
   char* vd0 = Vs + sr0 * VT_LD + sc * 16;
-  char* vd1 = Vs + sr1 * VT_LD + sc * 16;
-  uint4 kr0, kr1, vr0, vr1;
+  uint4 kr0, vr0;
 #define ATT_LOAD(kt)                                                                   \
   do {                                                                                 \
     kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq);         \
-    kr1 = *reinterpret_cast<const uint4*>(kp1 + (size_t)(kt) * KV_TILE * ldq);         \
     vr0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * KV_TILE);                       \
-    vr1 = *reinterpret_cast<const uint4*>(vp1 + (kt) * KV_TILE);                       \
   } while (0)
 #define ATT_STORE()                           \
   do {                                        \
     *reinterpret_cast<uint4*>(kd0) = kr0;     \
-    *reinterpret_cast<uint4*>(kd1) = kr1;     \
     *reinterpret_cast<uint4*>(vd0) = vr0;     \
-    *reinterpret_cast<uint4*>(vd1) = vr1;     \
   } while (0)
   ATT_LOAD(0);
   ATT_STORE();
@@ -399,15 +490,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     }
     // ---- online softmax over keys (a query's 64 keys live in the 4 lanes {lc + 16*g})
     const int kbase_idx = kt * KV_TILE;
-    float tmax = -1e30f;
+    if (kt == ntiles - 1) {  // only the last tile can contain padding keys (wave-uniform branch)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kbase_idx + mt * 16 + 4 * g + r;
-        if (key >= n_valid) s[mt][r] = -1e30f;
-        tmax = fmaxf(tmax, s[mt][r]);
-      }
+        for (int r = 0; r < 4; ++r)
+          if (kbase_idx + mt * 16 + 4 * g + r >= n_valid) s[mt][r] = -1e30f;
+    }
+    float tmax = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])),
+                             fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
@@ -462,7 +555,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
   // o[mt][r] = O[q = lc][d = 16*mt + 4*g + r]
-  bf16_t* orow = out + (row0 + qb * 64 + wave * 16 + lc) * dim + h * 64;
+  bf16_t* orow = out + (row0 + qb * ATT_Q + wave * 16 + lc) * dim + h * 64;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     uint2 pk;
@@ -507,6 +600,11 @@ int check_vit_cfg(const DvtVitConfig* c) {
 }
 
 }  // namespace
+
+int dvt_vit_tune(int gemm_variant) {
+  g_vit_gemm_variant = gemm_variant;
+  return 0;
+}
 
 extern "C" int dvt_vit_struct_sizes(int64_t* out) {
   if (!out) return DVT_E_BADARG;
@@ -565,11 +663,11 @@ extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b,
 
 extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads,
                                  int s_pad, int n_valid, void* stream) {
-  if (!qk || !vt || !out || batch <= 0 || heads <= 0 || s_pad % 64 || n_valid <= 0 || n_valid > s_pad)
+  if (!qk || !vt || !out || batch <= 0 || heads <= 0 || s_pad % ATT_Q || n_valid <= 0 || n_valid > s_pad)
     return DVT_E_BADARG;
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
                       4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
-  hipLaunchKernelGGL(attention_kernel, dim3(s_pad / 64, heads, batch), dim3(256), 0,
+  hipLaunchKernelGGL(attention_kernel, dim3(s_pad / ATT_Q, heads, batch), dim3(512), 0,
                      (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads,
                      s_pad, n_valid);
   DVT_CHECK_LAUNCH();

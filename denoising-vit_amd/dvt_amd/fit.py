@@ -198,7 +198,17 @@ class FitEngine:
         if idx is None:
             idx = self.sample_indices(cfg.n_rows, s.num_iters, s.pixel_bsz)
         if isinstance(idx, np.ndarray):
-            idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
+            # pinned staging buffer -> asynchronous H2D on the current stream (a pageable copy
+            # would block the host until everything queued before it has drained)
+            if getattr(self, "_idx_pin", None) is None:
+                self._idx_pin = torch.empty((s.num_iters, s.pixel_bsz), dtype=torch.int32,
+                                            pin_memory=True)
+                self._idx_free = torch.cuda.Event()
+                self._idx_free.record()
+            self._idx_free.synchronize()  # the previous upload from this buffer has finished
+            self._idx_pin.numpy()[...] = idx
+            idx = self._idx_pin.to(self.device, non_blocking=True)
+            self._idx_free.record()
         if idx.dtype != torch.int32 or tuple(idx.shape) != (s.num_iters, s.pixel_bsz):
             raise _lib.DvtError("idx must be int32 [num_iters, pixel_bsz]")
         self._idx = idx.contiguous()  # keep alive while kernels are in flight

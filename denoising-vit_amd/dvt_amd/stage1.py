@@ -82,11 +82,29 @@ def work_list(args) -> list[str]:
     return names[args.start_idx: args.start_idx + args.num_imgs]
 
 
-class Stage1:
-    """Holds everything that is reused across images on one GPU: ViT weights, the view /
-    feature / coordinate buffers (main_img_denoising.py:261-276) and the fit engine."""
+class _Slot:
+    """One image in flight: its views, coordinates, feature store and host output buffers."""
 
-    def __init__(self, args, device, vit: PretrainedViTWrapper | None = None):
+    def __init__(self, n, size, pos_h, pos_w, feat_dim, dev):
+        self.views = torch.zeros((n, 3, *size), device=dev)
+        self.coords = torch.zeros((n, pos_h, pos_w, 2), device=dev)
+        self.features = torch.zeros((n, pos_h, pos_w, feat_dim), device=dev)
+        self.raw_host = torch.empty((pos_h, pos_w, feat_dim), pin_memory=True)
+        self.den_host = torch.empty((1, pos_h, pos_w, feat_dim), pin_memory=True)
+        self.extracted = torch.cuda.Event()
+        self.fitted = torch.cuda.Event()
+        self.tag = None
+
+
+class Stage1:
+    """Everything that is reused across images on one GPU: ViT weights, the view / feature /
+    coordinate buffers (main_img_denoising.py:261-276) and the fit engine.
+
+    Images are pipelined over two HIP streams: the MFMA-bound extractor of image i+1 runs on
+    `s_vit` while the latency/HBM-bound fit of image i runs on the high-priority `s_fit`
+    (`depth` slots of buffers; depth=1 reproduces the reference's strictly serial flow)."""
+
+    def __init__(self, args, device, vit: PretrainedViTWrapper | None = None, depth: int = 2):
         self.args, self.device = args, torch.device(device)
         self.vit = vit or PretrainedViTWrapper(args.model, stride=args.stride_size,
                                                checkpoint_path=getattr(args, "vit_checkpoint", None),
@@ -98,9 +116,8 @@ class Stage1:
         self.feat_dim = v.n_output_dims
         n = args.num_views + 1
         dev = self.device
-        self.views = torch.zeros((n, 3, *args.input_size), device=dev)
-        self.coords = torch.zeros((n, self.pos_h, self.pos_w, 2), device=dev)
-        self.features = torch.zeros((n, self.pos_h, self.pos_w, self.feat_dim), device=dev)
+        self.slots = [_Slot(n, args.input_size, self.pos_h, self.pos_w, self.feat_dim, dev)
+                      for _ in range(max(1, depth))]
         s = FitSettings(feat_dim=self.feat_dim, noise_map_height=self.pos_h,
                         noise_map_width=self.pos_w, n_levels=args.n_levels,
                         num_iters=args.num_iters, warmup_iters=args.warmup_iters,
@@ -109,34 +126,84 @@ class Stage1:
                         pixel_bsz=args.pixel_bsz)
         self.engine = FitEngine(s, n * self.pos_h * self.pos_w, dev)
         self.gen = torch.Generator(device=dev).manual_seed(args.seed)
+        if len(self.slots) > 1:
+            self.s_vit = torch.cuda.Stream(device=dev)
+            self.s_fit = torch.cuda.Stream(device=dev, priority=-1)
+        else:
+            self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
         self.timings = []
 
-    def extract(self) -> None:
+    # -- single-image pieces (each enqueues on the CURRENT stream) -------------------------
+    def extract(self, slot: _Slot) -> None:
         """Feature extraction of all views into the feature store (:315-339), NHWC, no
         NCHW round trip; batches of 128 views keep every GEMM at M = 128*1408 rows."""
         with torch.no_grad():
-            self.vit.features_nhwc(self.views, self.layer_index, out=self.features)
+            self.vit.features_nhwc(slot.views, self.layer_index, out=slot.features)
 
-    def fit(self, log_every: int = 1000) -> torch.Tensor:
+    def fit(self, slot: _Slot, log_every: int = 1000) -> torch.Tensor:
         """denoise_an_image (:28-149): fresh models, the loop, then F on the original image's
         lattice (quirk Q7).  Returns denoised_feats [1, H, W, C] (device)."""
         e = self.engine
         e.reset(self.gen)
         C = self.feat_dim
-        e.fit(self.features.view(-1, C), self.coords.view(-1, 2), None, log_every=log_every)
-        return e.infer(self.coords[-1]).unsqueeze(0)
+        e.fit(slot.features.view(-1, C), slot.coords.view(-1, 2), None, log_every=log_every)
+        return e.infer(slot.coords[-1]).unsqueeze(0)
+
+    # -- the pipeline --------------------------------------------------------------------------
+    def run(self, jobs, on_result=None, log_every: int = 1000) -> int:
+        """jobs: iterable of (tag, set_views) with set_views(slot) filling slot.views / slot.coords
+        (called with `s_vit` current).  on_result(tag, raw_host, den_host) is called on the host
+        once an image's outputs have landed in pinned memory.  Returns the number of images."""
+        pending = []  # slots whose fit has been enqueued, in order
+        done = 0
+
+        def retire(slot):
+            nonlocal done
+            slot.fitted.synchronize()
+            if on_result is not None:
+                on_result(slot.tag, slot.raw_host.numpy(), slot.den_host.numpy())
+            done += 1
+
+        def enqueue_fit(slot):
+            with torch.cuda.stream(self.s_fit):
+                self.s_fit.wait_event(slot.extracted)
+                den = self.fit(slot, log_every)
+                slot.raw_host.copy_(slot.features[-1], non_blocking=True)
+                slot.den_host.copy_(den, non_blocking=True)
+                slot.fitted.record(self.s_fit)
+            pending.append(slot)
+
+        prev = None
+        for k, (tag, set_views) in enumerate(jobs):
+            slot = self.slots[k % len(self.slots)]
+            while slot in pending:  # the slot's previous image must have left the pipeline
+                retire(pending.pop(0))
+            slot.tag = tag
+            with torch.cuda.stream(self.s_vit):
+                set_views(slot)
+                self.extract(slot)
+                slot.extracted.record(self.s_vit)
+            # enqueue the extractor of image k BEFORE the (long, back-pressured) fit enqueue of k-1
+            if prev is not None:
+                enqueue_fit(prev)
+            prev = slot
+        if prev is not None:
+            enqueue_fit(prev)
+        while pending:
+            retire(pending.pop(0))
+        return done
 
     def process(self, set_views, save_paths=None):
-        """One image: set_views() fills self.views / self.coords; returns (raw, denoised) on
-        the host and records the reference's two timers (:341, :355)."""
-        set_views()
+        """Strictly serial single image (reference flow) with the two timers of :341, :355."""
+        slot = self.slots[0]
+        set_views(slot)
         torch.cuda.synchronize(self.device)
         t0 = time.time()
-        self.extract()
+        self.extract(slot)
         torch.cuda.synchronize(self.device)
         t1 = time.time()
-        den = self.fit()
-        raw_h = self.features[-1].float().cpu().numpy()
+        den = self.fit(slot)
+        raw_h = slot.features[-1].float().cpu().numpy()
         den_h = den.float().cpu().numpy()
         t2 = time.time()
         self.timings.append({"t_extract": t1 - t0, "t_fit": t2 - t1})
@@ -159,36 +226,44 @@ def main(args, rank: int = 0, world: int = 1):
     st = Stage1(args, device)
     norm = st.vit.transformation.transforms[-1]
     start = time.time()
-    done = 0
-    for idx, filename in enumerate(names):
-        filename = filename.strip().split(" ")[0]
-        paths = None
-        if args.data_root is not None:
-            filename = os.path.join(args.data_root, filename)
-            if misc.check_if_file_exists(args, filename):
-                print(f"Skipping {filename}")
-                continue
-            paths = misc.output_paths(args.save_root, args.model, args.data_root, filename)
 
-        def set_views():
-            if args.synthetic:
-                v, c = V.synthetic_views(args.num_views, args.input_size, st.pos_h, st.pos_w,
-                                         device, seed=args.seed + idx)
-                st.views.copy_(v)
-                st.coords.copy_(c)
-            else:
-                img = V.load_image(filename, args.input_size, norm.mean, norm.std, device)
-                boxes, coords = V.sample_view_boxes(args.num_views, args.input_size, st.pos_h, st.pos_w)
-                V.render_views(img, boxes, st.views)
-                st.coords.copy_(coords.to(device))
+    def jobs():
+        for idx, filename in enumerate(names):
+            filename = filename.strip().split(" ")[0]
+            paths = None
+            if args.data_root is not None:
+                filename = os.path.join(args.data_root, filename)
+                if misc.check_if_file_exists(args, filename):
+                    print(f"Skipping {filename}")
+                    continue
+                paths = misc.output_paths(args.save_root, args.model, args.data_root, filename)
 
-        st.process(set_views, paths)
-        done += 1
-        t = st.timings[-1]
-        print(f"[rank {rank}] [{idx + 1}/{len(names)}] {filename}: Feature extraction time: "
-              f"{t['t_extract']:.2f}s, Denoising time: {t['t_fit']:.2f}s")
+            def set_views(slot, filename=filename, idx=idx):
+                if args.synthetic:
+                    v, c = V.synthetic_views(args.num_views, args.input_size, st.pos_h, st.pos_w,
+                                             device, seed=args.seed + idx)
+                    slot.views.copy_(v)
+                    slot.coords.copy_(c)
+                else:
+                    img = V.load_image(filename, args.input_size, norm.mean, norm.std, device)
+                    boxes, coords = V.sample_view_boxes(args.num_views, args.input_size, st.pos_h,
+                                                        st.pos_w)
+                    V.render_views(img, boxes, slot.views)
+                    slot.coords.copy_(coords.to(device), non_blocking=True)
+
+            yield (filename, paths), set_views
+
+    def on_result(tag, raw_h, den_h):
+        filename, paths = tag
+        if paths is not None:
+            misc.atomic_save_npy(paths[0], raw_h.copy())  # [H, W, C]
+            misc.atomic_save_npy(paths[1], den_h.copy())  # [1, H, W, C]
+        el = time.time() - start
+        print(f"[rank {rank}] {filename}: done at {el:.2f}s")
         with open(os.path.join(args.output_dir, f"timings_rank{rank}.jsonl"), "a") as f:
-            f.write(json.dumps({"file": filename, **t}) + "\n")
+            f.write(json.dumps({"file": filename, "elapsed_s": el}) + "\n")
+
+    done = st.run(jobs(), on_result)
     print(f"[rank {rank}] {done} images in {time.time() - start:.1f}s")
     return done
 

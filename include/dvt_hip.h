@@ -231,7 +231,9 @@ int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float*
                     float* workspace, int n, void* stream);
 
 /* Tuning knob (developer use): key 0 = fp32 GEMM tile configuration override
- * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup). */
+ * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
+ * key 1 = ViT bf16 GEMM variant (0: 256x128 3-stage when M % 256 == 0, 1: always 128x128 2-stage);
+ * key 2 = grid backward: levels with more entries than `value` use global atomics (default 40960). */
 int dvt_tune_set(int key, int value);
 
 /* ------------------------------------------------------------------------------------

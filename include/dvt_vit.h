@@ -85,7 +85,7 @@ int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, void* y, int
 /* y (bf16) [rows, dim] = LayerNorm(x fp32 [rows, dim]) * w + b */
 int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int dim,
                       float eps, void* stream);
-/* out[b, s, h*64 + d] (bf16, [batch*s_pad, heads*64]) = softmax(q k^T / 8) v over the first
+/* s_pad % 128 == 0.  out[b, s, h*64 + d] (bf16, [batch*s_pad, heads*64]) = softmax(q k^T / 8) v over the first
  * n_valid keys; qk bf16 [batch*s_pad, 2*heads*64] (q then k), vt bf16 [batch, heads, 64, s_pad]. */
 int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
                       int n_valid, void* stream);
