@@ -21,7 +21,15 @@
 
 namespace {
 
+// 1: the sparse (hash-grid) gradient region is zero-WRITTEN every step, also where it was not
+// touched (+4 B/param of write traffic).  That keeps the gradient lines of the fine levels --
+// the last-streamed part of the grid -- resident in the memory-side cache, so the next
+// step's scattered atomics hit it instead of doing cold DRAM read-modify-writes
+// (measured: grid backward 190 us cold vs 13.5 us hot).
+int g_adam_zero_all = 1;
+
 struct AdamKArgs {
+  int zero_all;
   float one_m_b1, beta2, one_m_b2, eps, wd;
   long long q_sparse_end;  // float4 index
   int n_segs;
@@ -72,12 +80,17 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, float4* __restri
     P[q] = p;
     M[q] = m;
     V[q] = v;
-    if (has) G[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero_grad
+    if (has || (sparse && a.zero_all)) G[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero_grad
     if (sparse && word != 0u && lane == 0) touched[q0 >> 6] = 0u;
   }
 }
 
 }  // namespace
+
+int dvt_adam_tune(int zero_all) {
+  g_adam_zero_all = zero_all;
+  return 0;
+}
 
 extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v, float* g,
                              uint32_t* touched, void* stream) {
@@ -85,6 +98,7 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
     return DVT_E_BADARG;
   if ((h->sparse_end & 255) || (h->sparse_end > 0 && !touched)) return DVT_E_BADARG;
   AdamKArgs a{};
+  a.zero_all = g_adam_zero_all;
   // torch narrows the python doubles (1 - beta1), beta2, (1 - beta2), eps, wd to fp32 scalars
   a.one_m_b1 = (float)(1.0 - h->beta1);
   a.beta2 = (float)h->beta2;

@@ -53,3 +53,4 @@ struct DvtProbeScope {
 };
 int dvt_vit_tune(int gemm_variant);
 int dvt_grid_tune(int lds_level_max);
+int dvt_adam_tune(int zero_all);

@@ -113,21 +113,7 @@ extern "C" int dvt_field_infer(const DvtFitConfig* c, const float* params, const
                         c->hidden, 0, s);
 }
 
-extern "C" int dvt_fit_run(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin,
-                           int step_end, void* stream) {
-  int rc = check_cfg(c);
-  if (rc) return rc;
-  if (!b || !b->feat || !b->xy || !b->idx || !b->params || !b->adam_m || !b->adam_v ||
-      !b->grads || !b->touched || !b->workspace || !b->h_lr)
-    return DVT_E_BADARG;
-  if (step_begin < 0 || step_end > c->num_iters || step_begin > step_end) return DVT_E_BADARG;
-  hipStream_t s = (hipStream_t)stream;
-  Work w;
-  carve(c, b->workspace, &w);
-  const int B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
-  const int E = c->grid.n_levels * c->grid.n_features;
-  float* P = b->params;
-  float* Gd = b->grads;
+namespace {
 
 #define DVT_TRY(x)         \
   do {                     \
@@ -135,68 +121,117 @@ extern "C" int dvt_fit_run(const DvtFitConfig* c, const DvtFitBuffers* b, int st
     if (rc__) return rc__; \
   } while (0)
 
-  for (int step = step_begin; step < step_end; ++step) {
-    const int32_t* ridx = b->idx + (size_t)step * B;
-    const bool phase2 = step > c->switch_step;
-    const bool use_res = phase2 && c->enable_residual;
-    const bool log = b->losses != nullptr &&
-                     ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
+int check_bufs(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin, int step_end) {
+  int rc = check_cfg(c);
+  if (rc) return rc;
+  if (!b || !b->feat || !b->xy || !b->idx || !b->params || !b->adam_m || !b->adam_v ||
+      !b->grads || !b->touched || !b->workspace || !b->h_lr)
+    return DVT_E_BADARG;
+  if (step_begin < 0 || step_end > c->num_iters || step_begin > step_end) return DVT_E_BADARG;
+  return 0;
+}
 
-    // ---- forward ----
-    DVT_TRY(dvt_gather_rows(b->feat, ridx, w.raw, B, C, 0, s));
-    DVT_TRY(dvt_grid_fwd_idx(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, B, s));
-    DVT_TRY(dvt_linear_fwd(w.enc, P + c->off_w1, P + c->off_b1, w.h1, B, H, E, 1, s));
-    DVT_TRY(dvt_linear_fwd(w.h1, P + c->off_w2, P + c->off_b2, w.F, B, C, H, 0, s));
-    if (use_res) {
-      DVT_TRY(dvt_linear_fwd(w.raw, P + c->off_wh1, P + c->off_bh1, w.r1, B, R, C, 1, s));
-      DVT_TRY(dvt_linear_fwd(w.r1, P + c->off_wh2, P + c->off_bh2, w.r2, B, R, R, 1, s));
-      DVT_TRY(dvt_linear_fwd(w.r2, P + c->off_wh3, P + c->off_bh3, w.Hres, B, C, R, 0, s));
-    }
-    // ---- loss + d(pred), G gradient scattered in the same pass while G still trains ----
-    DVT_TRY(dvt_loss_launch(w.F, P + c->off_G, ridx, c->lattice, use_res ? w.Hres : nullptr, w.raw,
-                            w.dF, use_res ? w.dH : nullptr, phase2 ? nullptr : Gd + c->off_G,
-                            w.rows, B, C, (float)c->grad_scale, s));
-    if (log) DVT_TRY(dvt_loss_reduce(w.rows, b->losses + (size_t)step * 8, B, C, use_res, s));
-    // ---- backward: field MLP -> encoding -> hash grid ----
-    DVT_TRY(dvt_linear_bwd(w.dF, w.h1, P + c->off_w2, Gd + c->off_w2, Gd + c->off_b2, w.dh1, w.h1,
-                           B, C, H, s));
-    DVT_TRY(dvt_linear_bwd(w.dh1, w.enc, P + c->off_w1, Gd + c->off_w1, Gd + c->off_b1, w.denc,
-                           nullptr, B, H, E, s));
-    DVT_TRY(dvt_grid_bwd_idx(&c->grid, b->xy, ridx, w.denc, Gd + c->off_grid, b->touched, B, s));
-    if (use_res) {
-      DVT_TRY(dvt_linear_bwd(w.dH, w.r2, P + c->off_wh3, Gd + c->off_wh3, Gd + c->off_bh3, w.dr2,
-                             w.r2, B, C, R, s));
-      DVT_TRY(dvt_linear_bwd(w.dr2, w.r1, P + c->off_wh2, Gd + c->off_wh2, Gd + c->off_bh2, w.dr1,
-                             w.r1, B, R, R, s));
-      DVT_TRY(dvt_linear_bwd(w.dr1, w.raw, P + c->off_wh1, Gd + c->off_wh1, Gd + c->off_bh1,
-                             nullptr, nullptr, B, R, C, s));
-    }
-    // ---- Adam (dense) + zero_grad ----
-    DvtAdamArgs a{};
-    a.beta1 = c->beta1;
-    a.beta2 = c->beta2;
-    a.eps = c->eps;
-    a.weight_decay = c->weight_decay;
-    a.sparse_end = c->off_w1;
-    const double lr = b->h_lr[step];
-    auto seg = [&](int64_t beg, int64_t end, int t) {
-      DvtAdamSeg sg{};
-      sg.begin = beg;
-      sg.end = end;
-      sg.lr = lr;
-      sg.bias_correction1 = 1.0 - pow(c->beta1, (double)t);
-      sg.bias_correction2_sqrt = sqrt(1.0 - pow(c->beta2, (double)t));
-      sg.active = 1;
-      a.segs[a.n_segs++] = sg;
-    };
-    if (!phase2) {
-      seg(c->off_grid, c->off_wh1, step + 1);  // grid + field MLP + G
-    } else {
-      seg(c->off_grid, c->off_G, step + 1);  // grid + field MLP (G frozen: grad None)
-      if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
-    }
-    DVT_TRY(dvt_adam_step(&a, P, b->adam_m, b->adam_v, Gd, b->touched, s));
+// One Adam step of one image's fit, enqueued on stream s.
+int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int step, hipStream_t s) {
+  const int B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
+  const int E = c->grid.n_levels * c->grid.n_features;
+  float* P = b->params;
+  float* Gd = b->grads;
+  const int32_t* ridx = b->idx + (size_t)step * B;
+  const bool phase2 = step > c->switch_step;
+  const bool use_res = phase2 && c->enable_residual;
+  const bool log = b->losses != nullptr &&
+                   ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
+
+  // ---- forward ----
+  DVT_TRY(dvt_gather_rows(b->feat, ridx, w.raw, B, C, 0, s));
+  DVT_TRY(dvt_grid_fwd_idx(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, B, s));
+  DVT_TRY(dvt_linear_fwd(w.enc, P + c->off_w1, P + c->off_b1, w.h1, B, H, E, 1, s));
+  DVT_TRY(dvt_linear_fwd(w.h1, P + c->off_w2, P + c->off_b2, w.F, B, C, H, 0, s));
+  if (use_res) {
+    DVT_TRY(dvt_linear_fwd(w.raw, P + c->off_wh1, P + c->off_bh1, w.r1, B, R, C, 1, s));
+    DVT_TRY(dvt_linear_fwd(w.r1, P + c->off_wh2, P + c->off_bh2, w.r2, B, R, R, 1, s));
+    DVT_TRY(dvt_linear_fwd(w.r2, P + c->off_wh3, P + c->off_bh3, w.Hres, B, C, R, 0, s));
   }
+  // ---- loss + d(pred), G gradient scattered in the same pass while G still trains ----
+  DVT_TRY(dvt_loss_launch(w.F, P + c->off_G, ridx, c->lattice, use_res ? w.Hres : nullptr, w.raw,
+                          w.dF, use_res ? w.dH : nullptr, phase2 ? nullptr : Gd + c->off_G, w.rows,
+                          B, C, (float)c->grad_scale, s));
+  if (log) DVT_TRY(dvt_loss_reduce(w.rows, b->losses + (size_t)step * 8, B, C, use_res, s));
+  // ---- backward: field MLP -> encoding -> hash grid ----
+  DVT_TRY(dvt_linear_bwd(w.dF, w.h1, P + c->off_w2, Gd + c->off_w2, Gd + c->off_b2, w.dh1, w.h1, B,
+                         C, H, s));
+  DVT_TRY(dvt_linear_bwd(w.dh1, w.enc, P + c->off_w1, Gd + c->off_w1, Gd + c->off_b1, w.denc,
+                         nullptr, B, H, E, s));
+  DVT_TRY(dvt_grid_bwd_idx(&c->grid, b->xy, ridx, w.denc, Gd + c->off_grid, b->touched, B, s));
+  if (use_res) {
+    DVT_TRY(dvt_linear_bwd(w.dH, w.r2, P + c->off_wh3, Gd + c->off_wh3, Gd + c->off_bh3, w.dr2,
+                           w.r2, B, C, R, s));
+    DVT_TRY(dvt_linear_bwd(w.dr2, w.r1, P + c->off_wh2, Gd + c->off_wh2, Gd + c->off_bh2, w.dr1,
+                           w.r1, B, R, R, s));
+    DVT_TRY(dvt_linear_bwd(w.dr1, w.raw, P + c->off_wh1, Gd + c->off_wh1, Gd + c->off_bh1, nullptr,
+                           nullptr, B, R, C, s));
+  }
+  // ---- Adam (dense) + zero_grad ----
+  DvtAdamArgs a{};
+  a.beta1 = c->beta1;
+  a.beta2 = c->beta2;
+  a.eps = c->eps;
+  a.weight_decay = c->weight_decay;
+  a.sparse_end = c->off_w1;
+  const double lr = b->h_lr[step];
+  auto seg = [&](int64_t beg, int64_t end, int t) {
+    DvtAdamSeg sg{};
+    sg.begin = beg;
+    sg.end = end;
+    sg.lr = lr;
+    sg.bias_correction1 = 1.0 - pow(c->beta1, (double)t);
+    sg.bias_correction2_sqrt = sqrt(1.0 - pow(c->beta2, (double)t));
+    sg.active = 1;
+    a.segs[a.n_segs++] = sg;
+  };
+  if (!phase2) {
+    seg(c->off_grid, c->off_wh1, step + 1);  // grid + field MLP + G
+  } else {
+    seg(c->off_grid, c->off_G, step + 1);  // grid + field MLP (G frozen: grad None)
+    if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
+  }
+  return dvt_adam_step(&a, P, b->adam_m, b->adam_v, Gd, b->touched, s);
+}
 #undef DVT_TRY
+
+}  // namespace
+
+extern "C" int dvt_fit_run(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin,
+                           int step_end, void* stream) {
+  int rc = check_bufs(c, b, step_begin, step_end);
+  if (rc) return rc;
+  Work w;
+  carve(c, b->workspace, &w);
+  for (int step = step_begin; step < step_end; ++step) {
+    rc = fit_step(c, b, w, step, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// k independent fits (k images) advanced in lock step, fit j on streams[j]: their
+// latency-bound small kernels overlap on the GPU (config 3 of BASELINE.json: many concurrent
+// neural fields per GPU).  All fits must share num_iters.
+extern "C" int dvt_fit_run_multi(int k, const DvtFitConfig* const* cfgs,
+                                 const DvtFitBuffers* const* bufs, void* const* streams,
+                                 int step_begin, int step_end) {
+  if (k <= 0 || k > 16 || !cfgs || !bufs || !streams) return DVT_E_BADARG;
+  Work w[16];
+  for (int j = 0; j < k; ++j) {
+    int rc = check_bufs(cfgs[j], bufs[j], step_begin, step_end);
+    if (rc) return rc;
+    carve(cfgs[j], bufs[j]->workspace, &w[j]);
+  }
+  for (int step = step_begin; step < step_end; ++step)
+    for (int j = 0; j < k; ++j) {
+      int rc = fit_step(cfgs[j], bufs[j], w[j], step, (hipStream_t)streams[j]);
+      if (rc) return rc;
+    }
   return 0;
 }

@@ -213,6 +213,7 @@ extern "C" int dvt_tune_set(int key, int value) {
   }
   if (key == 1) return dvt_vit_tune(value);
   if (key == 2) return dvt_grid_tune(value);
+  if (key == 3) return dvt_adam_tune(value);
   return DVT_E_BADARG;
 }
 

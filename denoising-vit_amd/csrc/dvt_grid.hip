@@ -142,7 +142,11 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(DvtGridTable T, const flo
 //    global_atomic_add_f32, the 8 lanes of an entry hit one 32-B sector.
 // Both paths mark touched entries in the bitmap consumed by the fused Adam kernel.
 constexpr int LDS_CHUNK = 1024;  // entries per workgroup (32 KB of accumulators)
-int g_grid_lds_level_max = 40960;  // entries; levels above go the direct-atomic way (tunable)
+int g_grid_lds_level_max = 0;  // entries; levels above go the direct-atomic way (tunable).
+// Default 0 = every level by global atomics: ds_add_f32 serialises at ~176 cycles per wave
+// instruction under the 32-hits-per-entry load of the coarse levels (measured 86 us for the
+// level-0 workgroup alone), while the global atomics of ALL levels take 13.5 us once the
+// gradient lines are cache-resident (see dvt_adam.hip: zero_all).
 
 struct GridBwdPlan {
   int n_lds_blocks;

@@ -220,6 +220,97 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBArgs p) {
   gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- LDS-staged epilogue of the 256x128 kernel ---------------------------------------------
+// The accumulator layout gives every lane 4 rows x 1 column per 16x16 tile, i.e. 4-byte
+// global accesses in 64-B segments (measured: the K=768 proj GEMM spent 630 us where its MFMA
+// work is 85 us).  Each wave therefore parks its 64x64 fp32 block (+bias) in its own LDS
+// region (stride 68 floats) and reads it back row-wise: fp32 outputs move as float4 (a
+// 256-B row segment per 16 lanes), bf16 outputs as 8 columns = 16 B per lane.
+constexpr int EP_LD = 68;                      // floats per row of a wave's LDS block
+constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;  // 17408 B x 8 waves = 136 KB <= 144 KB
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&acc)[4][4], int m0,
+                                                  int n0, int wm, int wn, int wave, int lane,
+                                                  char* smem) {
+  const int g = lane >> 4, lc = lane & 15;
+  if (EPI == EPI_QKV && n0 >= 2 * p.dim) {  // V tiles keep the direct transposed store
+    gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+    return;
+  }
+  float* blk = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
+  const int nb = n0 + wn * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float bias = p.bias != nullptr ? p.bias[nb + j * 16 + lc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[(i * 16 + 4 * g + r) * EP_LD + j * 16 + lc] = acc[i][j][r] + bias;
+  }
+  // each wave only re-reads its own block: no workgroup barrier needed, only LDS completion
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int mb = m0 + wm * 64;
+  if (EPI == EPI_RESID || EPI == EPI_EMBED) {
+    const int c4 = lc * 4;  // 16 lanes x float4 = one 64-float row; 4 rows per pass
+    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_RESID) gm = *reinterpret_cast<const float4*>(p.gamma + nb + c4);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + g;
+      const float4 v = *reinterpret_cast<const float4*>(blk + row * EP_LD + c4);
+      const int t = mb + row;
+      float4* px = reinterpret_cast<float4*>(p.x + (size_t)t * p.N + nb + c4);
+      if (EPI == EPI_RESID) {
+        float4 o = *px;
+        o.x += gm.x * v.x;
+        o.y += gm.y * v.y;
+        o.z += gm.z * v.z;
+        o.w += gm.w * v.w;
+        *px = o;
+      } else {
+        const int sidx = t % p.s_pad;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sidx == 0) {
+          const float4 c = *reinterpret_cast<const float4*>(p.cls + nb + c4);
+          const float4 q = *reinterpret_cast<const float4*>(p.pos + nb + c4);
+          o = make_float4(c.x + q.x, c.y + q.y, c.z + q.z, c.w + q.w);
+        } else if (sidx < p.n_tokens) {
+          const float4 q = *reinterpret_cast<const float4*>(p.pos + (size_t)sidx * p.N + nb + c4);
+          o = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
+        }
+        *px = o;
+      }
+    }
+  } else {
+    const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
+    const int c8 = (lane & 7) * 8;  // 8 lanes x 8 columns = one row; 8 rows per pass
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      float4 a = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8);
+      float4 b = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8 + 4);
+      if (EPI == EPI_GELU) {
+        const float k = 0.70710678118654752f;
+        a.x = 0.5f * a.x * (1.0f + erff(a.x * k));
+        a.y = 0.5f * a.y * (1.0f + erff(a.y * k));
+        a.z = 0.5f * a.z * (1.0f + erff(a.z * k));
+        a.w = 0.5f * a.w * (1.0f + erff(a.w * k));
+        b.x = 0.5f * b.x * (1.0f + erff(b.x * k));
+        b.y = 0.5f * b.y * (1.0f + erff(b.y * k));
+        b.z = 0.5f * b.z * (1.0f + erff(b.z * k));
+        b.w = 0.5f * b.w * (1.0f + erff(b.w * k));
+      }
+      uint4 pk;
+      pk.x = pack2(a.x, a.y);
+      pk.y = pack2(a.z, a.w);
+      pk.z = pack2(b.x, b.y);
+      pk.w = pack2(b.z, b.w);
+      *reinterpret_cast<uint4*>(p.out + (size_t)(mb + row) * ldo + nb + c8) = pk;
+    }
+  }
+}
+
 // ---- 256x128x64 tile, 8 waves (4 x 2, 64x64 each), 3 LDS stages, counted vmcnt -------------
 // The 2-stage kernel above drains its LDS-DMA queue (vmcnt(0)) at every barrier, so each
 // k-iteration costs one full L2/HBM load latency (measured 561 TF/s = 22 % of peak at K = 768).
@@ -299,7 +390,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_256(GemmBArgs p) {
     }
   }
 #undef G2_ISSUE
-  gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+  __syncthreads();  // every wave is done with the operand stages: the buffers become epilogue space
+  gemm_epilogue_lds<EPI>(p, acc, m0, n0, wm, wn, wave, lane, smem);
 }
 
 template <int EPI>

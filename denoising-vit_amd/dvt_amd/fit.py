@@ -179,13 +179,10 @@ class FitEngine:
         One [num_iters, B] draw consumes the stream exactly like num_iters successive draws."""
         return np.random.randint(0, n_rows, (num_iters, batch)).astype(np.int32)
 
-    def fit(self, feat: torch.Tensor, xy: torch.Tensor, idx: torch.Tensor | np.ndarray | None = None,
-            log_every: int = 1000, step_begin: int = 0, step_end: int | None = None) -> None:
-        """Enqueue Adam steps [step_begin, step_end) on the current stream (asynchronous).
-
-        feat [n_rows, C] fp32 = all_raw_features.reshape(-1, C); xy [n_rows, 2] fp32 =
-        all_pixel_coords.reshape(-1, 2); idx [num_iters, pixel_bsz] int32 row indices
-        (default: the reference's numpy stream)."""
+    def buffers(self, feat: torch.Tensor, xy: torch.Tensor,
+                idx: torch.Tensor | np.ndarray | None = None, log_every: int = 1000):
+        """Validate the inputs, upload the index stream (on the current stream) and return the
+        DvtFitBuffers descriptor of this fit."""
         s, cfg = self.s, self.cfg
         _lib.require_cuda(feat, xy)
         if feat.dtype != torch.float32 or xy.dtype != torch.float32:
@@ -221,9 +218,19 @@ class FitEngine:
         b.workspace, b.losses = self.workspace.data_ptr(), self.losses.data_ptr()
         b.h_lr = self.h_lr.ctypes.data
         b.log_every = int(log_every)
-        end = s.num_iters if step_end is None else step_end
-        _lib.check(_lib.lib().dvt_fit_run(C.byref(cfg), C.byref(b), step_begin, end, _lib.stream()),
-                   "dvt_fit_run")
+        return b
+
+    def fit(self, feat: torch.Tensor, xy: torch.Tensor, idx: torch.Tensor | np.ndarray | None = None,
+            log_every: int = 1000, step_begin: int = 0, step_end: int | None = None) -> None:
+        """Enqueue Adam steps [step_begin, step_end) on the current stream (asynchronous).
+
+        feat [n_rows, C] fp32 = all_raw_features.reshape(-1, C); xy [n_rows, 2] fp32 =
+        all_pixel_coords.reshape(-1, 2); idx [num_iters, pixel_bsz] int32 row indices
+        (default: the reference's numpy stream)."""
+        b = self.buffers(feat, xy, idx, log_every)
+        end = self.s.num_iters if step_end is None else step_end
+        _lib.check(_lib.lib().dvt_fit_run(C.byref(self.cfg), C.byref(b), step_begin, end,
+                                          _lib.stream()), "dvt_fit_run")
 
     def infer(self, xy: torch.Tensor) -> torch.Tensor:
         """F(xy): the denoised features saved by the reference (quirk Q7) -- the field evaluated
@@ -250,3 +257,19 @@ class FitEngine:
                 "residual_sparsity_loss")
         return {i: dict(zip(keys, map(float, host[i, :5]))) for i in range(host.shape[0])
                 if host[i, 0] != 0.0}
+
+
+def fit_many(engines, feats, xys, streams, log_every: int = 1000) -> None:
+    """Advance k independent fits in lock step, fit j on streams[j] (torch.cuda.Stream): the
+    small latency-bound kernels of different images overlap on the GPU (`dvt_fit_run_multi`).
+    Index streams are drawn in engine order from the reference's numpy RNG."""
+    k = len(engines)
+    bufs = []
+    for e, f, x, st in zip(engines, feats, xys, streams):
+        with torch.cuda.stream(st):
+            bufs.append(e.buffers(f, x, None, log_every))
+    cfg_arr = (C.POINTER(_lib.FitConfig) * k)(*[C.pointer(e.cfg) for e in engines])
+    buf_arr = (C.POINTER(_lib.FitBuffers) * k)(*[C.pointer(b) for b in bufs])
+    st_arr = (C.c_void_p * k)(*[st.cuda_stream for st in streams])
+    _lib.check(_lib.lib().dvt_fit_run_multi(k, cfg_arr, buf_arr, st_arr, 0, engines[0].s.num_iters),
+               "dvt_fit_run_multi")

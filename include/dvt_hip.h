@@ -226,6 +226,12 @@ int64_t dvt_fit_workspace_floats(const DvtFitConfig* h_cfg);
 int dvt_fit_run(const DvtFitConfig* h_cfg, const DvtFitBuffers* h_bufs, int step_begin,
                 int step_end, void* stream);
 
+/* k independent fits advanced in lock step, fit j enqueued on h_streams[j] (hipStream_t as
+ * void*): the latency-bound small kernels of different images overlap on the GPU
+ * (BASELINE.json configs[2]: many concurrent neural fields per GPU).  k <= 16. */
+int dvt_fit_run_multi(int k, const DvtFitConfig* const* h_cfgs, const DvtFitBuffers* const* h_bufs,
+                      void* const* h_streams, int step_begin, int step_end);
+
 /* out[n, C] = field(xy[n,2]) using arena params; workspace >= n*(L*F + hidden) floats. */
 int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float* xy, float* out,
                     float* workspace, int n, void* stream);
@@ -233,7 +239,8 @@ int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float*
 /* Tuning knob (developer use): key 0 = fp32 GEMM tile configuration override
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
  * key 1 = ViT bf16 GEMM variant (0: 256x128 3-stage when M % 256 == 0, 1: always 128x128 2-stage);
- * key 2 = grid backward: levels with more entries than `value` use global atomics (default 40960). */
+ * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
+ * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);
 
 /* ------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ def L(built_lib):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 192), (384, 768, 768), (128, 2304, 768),
-                                   (1408, 768, 3072), (256, 128, 640)])
+                                   (1408, 768, 3072), (256, 128, 640), (512, 256, 128), (2816, 768, 768)])
 def test_gemm_bias_vs_torch(L, m, n, k):
     torch.manual_seed(m + n + k)
     # asymmetric operands: catches transposed / permuted fragment layouts
