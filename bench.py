@@ -144,6 +144,10 @@ def main():
     st.process(lambda slot: None)
     split = st.timings[-1]
     prof_iso = {n: _lib.prof_collect(n) for n in probes}
+    # inside the timed region only the three heavy kernels are probed (~2.5 k event pairs per
+    # image); probing all ~15 k small fit launches costs ~100 us/step (measured) and would
+    # distort the metric
+    probes = [n for n in probes if n in ("adam", "vit_gemm", "vit_attn")]
     _lib.prof_enable(probes)
     barrier()
     t0 = time.perf_counter()

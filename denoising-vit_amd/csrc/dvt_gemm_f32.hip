@@ -10,10 +10,10 @@
 //   forward  y = x . w^T      A = x  [m][k] k-contiguous   B = w  [n][k] k-contiguous
 //   dgrad    dx = dy . w      A = dy [m][n] k-contiguous   B = w  [n][k] row-contiguous
 //   wgrad    dw = dy^T . x    A = dy [b][n] row-contiguous B = x  [b][k] row-contiguous
-// Tile 64x64x32 per 256-thread workgroup (4 waves, each one 32x32 accumulator = 16 VGPRs);
+// Tile 64x64x64 per 256-thread workgroup (4 waves, each one 32x32 accumulator = 16 VGPRs);
 // tiles are staged through LDS so that global reads are 16-B coalesced and the MFMA
 // fragment reads (lane l: A[l&31][l>>5], B[l>>5][l&31]) are conflict-free:
-//   k-contiguous operand  -> LDS [row][k] with leading dimension 33
+//   k-contiguous operand  -> LDS [row][k] with leading dimension BK+1
 //   row-contiguous operand-> LDS [k][row] with leading dimension 64
 // The small batch (2048 rows) yields few tiles, so wgrad splits the batch reduction over
 // blockIdx.z and accumulates with fp32 atomics into a gradient buffer that the fused Adam
@@ -24,7 +24,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
+// BK = 64: 32 MFMAs (2048 cycles) per staged tile -- with BK = 32 every k-tile cost ~1 us, twice
+// its MFMA time, because the single prefetched tile's L2 latency was only half hidden.
+constexpr int BK = 64;
 constexpr int LDK = BK + 1;  // [row][k] layout, conflict-free for scalar writes + fragment reads
 
 struct GemmArgs {
@@ -247,7 +249,7 @@ extern "C" int dvt_linear_bwd(const float* dy, const float* x, const float* w, f
     a.atomic = 1;
     const int tiles = dvt_cdiv(n, 64) * dvt_cdiv(k, 64);
     const int ktiles = dvt_cdiv(m, BK);
-    int splits = dvt_cdiv(768, tiles);
+    int splits = dvt_cdiv(384, tiles);  // every split costs one fp32 atomic per output element
     if (splits > ktiles / 2) splits = ktiles / 2;
     if (splits < 1) splits = 1;
     a.kchunk = dvt_cdiv(ktiles, splits) * BK;

@@ -142,16 +142,19 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(DvtGridTable T, const flo
 //    global_atomic_add_f32, the 8 lanes of an entry hit one 32-B sector.
 // Both paths mark touched entries in the bitmap consumed by the fused Adam kernel.
 constexpr int LDS_CHUNK = 1024;  // entries per workgroup (32 KB of accumulators)
-int g_grid_lds_level_max = 0;  // entries; levels above go the direct-atomic way (tunable).
-// Default 0 = every level by global atomics: ds_add_f32 serialises at ~176 cycles per wave
-// instruction under the 32-hits-per-entry load of the coarse levels (measured 86 us for the
-// level-0 workgroup alone), while the global atomics of ALL levels take 13.5 us once the
-// gradient lines are cache-resident (see dvt_adam.hip: zero_all).
+int g_grid_lds_level_max = 40960;  // entries; levels above go the direct-atomic way (tunable)
+// ds_add_f32 retires only ~1 lane per 2.75 cycles (measured: the single level-0 workgroup, 65 536
+// lane-atomics, took 86 us), so the samples of a coarse level are split over several workgroups,
+// each with a private LDS accumulator of its chunk; split chunks are flushed with global atomics
+// (<= 16 adds per address, into the few-MB, cache-resident coarse region), unsplit ones with
+// plain stores.
+int g_grid_lds_atomics_per_block = 4096;  // target LDS lane-atomics per workgroup
 
 struct GridBwdPlan {
   int n_lds_blocks;
   int first_direct_level;  // levels [first_direct_level, L) use global atomics
   int chunk_start[DVT_MAX_LEVELS + 1];  // first LDS block of each LDS level (prefix sum)
+  int splits[DVT_MAX_LEVELS];           // sample slices per chunk of that level
 };
 
 __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdPlan plan,
@@ -167,14 +170,19 @@ __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdP
   if ((int)blockIdx.x < plan.n_lds_blocks) {
     int l = 0;
     while (l + 1 < plan.first_direct_level && (int)blockIdx.x >= plan.chunk_start[l + 1]) ++l;
-    const uint32_t e0 = (uint32_t)((int)blockIdx.x - plan.chunk_start[l]) * LDS_CHUNK;
+    const int nsplit = plan.splits[l];
+    const int local = (int)blockIdx.x - plan.chunk_start[l];
+    const int split = local % nsplit;
+    const uint32_t e0 = (uint32_t)(local / nsplit) * LDS_CHUNK;
+    const int per = (n + nsplit - 1) / nsplit;  // samples of this slice
+    const int b_begin = split * per, b_end = min(n, b_begin + per);
     const uint32_t abs0 = T.offset[l] + e0;  // first absolute entry
     const uint32_t cnt = min((uint32_t)LDS_CHUNK, T.entries[l] - e0);
     const uint32_t base32 = abs0 & ~31u;  // flags are kept in GLOBAL bitmap word alignment
     for (int i = tid; i < LDS_CHUNK * 8; i += 1024) acc[i] = 0.f;
     if (tid < LDS_CHUNK / 32 + 1) flags[tid] = 0u;
     __syncthreads();
-    for (int b = tid; b < n; b += 1024) {
+    for (int b = b_begin + tid; b < b_end; b += 1024) {
       const float2 p = xy[ridx != nullptr ? ridx[b] : b];
       uint32_t idx[4];
       float w[4];
@@ -207,6 +215,12 @@ __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdP
       const uint32_t a = abs0 + e;
       if ((flags[(a - base32) >> 5] >> (a & 31u)) & 1u) {
         float4* dst = reinterpret_cast<float4*>(d_params + (size_t)a * 8);
+        if (nsplit > 1) {  // several slices own this entry: combine with global atomics
+          float* d = d_params + (size_t)a * 8;
+#pragma unroll
+          for (int f = 0; f < 8; ++f) atomic_add_f32(d + f, acc[f * LDS_CHUNK + e]);
+          continue;
+        }
         // single writer per entry within this launch: plain read-modify-write keeps the
         // documented "+=" semantics without atomics
         const float4 o0 = dst[0], o1 = dst[1];
@@ -247,19 +261,29 @@ __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdP
   }
 }
 
-static void make_bwd_plan(const DvtGridTable& T, GridBwdPlan* plan) {
+static void make_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan) {
   plan->n_lds_blocks = 0;
   int l = 0;
   for (; l < T.n_levels; ++l) {
     if (T.entries[l] > (uint32_t)g_grid_lds_level_max) break;
+    const int chunks = (int)((T.entries[l] + LDS_CHUNK - 1) / LDS_CHUNK);
+    // expected LDS lane-atomics per chunk workgroup = n * 4 corners * 8 features / chunks
+    long long per_chunk = (long long)n * 32 / chunks;
+    int sp = (int)((per_chunk + g_grid_lds_atomics_per_block - 1) / g_grid_lds_atomics_per_block);
+    sp = sp < 1 ? 1 : (sp > 16 ? 16 : sp);
+    plan->splits[l] = sp;
     plan->chunk_start[l] = plan->n_lds_blocks;
-    plan->n_lds_blocks += (int)((T.entries[l] + LDS_CHUNK - 1) / LDS_CHUNK);
+    plan->n_lds_blocks += chunks * sp;
   }
   plan->chunk_start[l] = plan->n_lds_blocks;
   plan->first_direct_level = l;  // levels are sorted by size: the rest is fine
 }
 
 int dvt_grid_tune(int lds_level_max) {
+  if (lds_level_max < 0) {  // negative: set the per-block LDS atomics target instead
+    g_grid_lds_atomics_per_block = -lds_level_max;
+    return 0;
+  }
   g_grid_lds_level_max = lds_level_max;
   return 0;
 }
@@ -303,7 +327,7 @@ int dvt_grid_bwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ri
   if (!tbl || !xy || !d_enc || !d_params || n < 0 || tbl->n_features != 8) return DVT_E_BADARG;
   if (n == 0) return 0;
   GridBwdPlan plan;
-  make_bwd_plan(*tbl, &plan);
+  make_bwd_plan(*tbl, n, &plan);
   const long long threads = (long long)n * (tbl->n_levels - plan.first_direct_level) * 8;
   const int blocks = plan.n_lds_blocks + dvt_cdiv(threads, 1024);
   // algorithmic bytes: 32 B read + 4 corners x 32 B read-modify-write per (sample, level)

@@ -29,25 +29,38 @@ s = FitSettings(num_iters=a.iters, warmup_iters=a.iters // 10)
 L = _lib.lib()
 np.random.seed(0)
 eng = FitEngine(s, n_rows, dev)
-for zero_all, lds_max in ((1, 0), (0, 0), (1, 40960), (0, 40960)):
-    L.dvt_tune_set(3, zero_all)
-    L.dvt_tune_set(2, lds_max)
+def run_once(tag):
     for rep in range(a.reps):
         eng.reset(g)
         idx = torch.from_numpy(FitEngine.sample_indices(n_rows, a.iters, 2048)).to(dev)
-        _lib.prof_enable(["adam", "grid", "fit_gemm"])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.fit(feat, xy, idx, log_every=1000)
-        t_launch = time.perf_counter() - t0
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
-        pr = {n: _lib.prof_collect(n) for n in ("adam", "grid", "fit_gemm")}
-        _lib.prof_enable([])
-    print(f"zero_all={zero_all} lds_max={lds_max}: {t/a.iters*1e6:.1f} us/step (host enqueue {t_launch*1e3:.0f} ms); "
-          + ", ".join(f"{n} {p['total_ms']/a.iters*1e3:.1f} us/step" for n, p in pr.items()), flush=True)
-L.dvt_tune_set(3, 1)
-L.dvt_tune_set(2, 0)
+    print(f"{tag}: {t/a.iters*1e6:.1f} us/step", flush=True)
+    return idx
+
+
+for lds_max in (40960, 0, 300, 1500, 5000, 400000):
+    L.dvt_tune_set(2, lds_max)
+    idx = run_once(f"grid lds_level_max={lds_max}")
+L.dvt_tune_set(2, 40960)
+for target in (1024, 16384):
+    L.dvt_tune_set(2, -target)
+    run_once(f"grid lds atomics/block target={target}")
+L.dvt_tune_set(2, -4096)
+for cfg in (0, 1, 2):
+    L.dvt_tune_set(0, cfg)
+    run_once(f"f32 gemm tile cfg={cfg}")
+L.dvt_tune_set(0, -1)
+eng.reset(g)
+_lib.prof_enable(["adam", "grid", "fit_gemm"])
+eng.fit(feat, xy, idx, log_every=1000)
+torch.cuda.synchronize()
+print("probed (inflated by event overhead): " + ", ".join(
+    f"{n} {_lib.prof_collect(n)['total_ms']/a.iters*1e3:.1f} us/step" for n in ("adam", "grid", "fit_gemm")), flush=True)
+_lib.prof_enable([])
 # host-side enqueue cost with the GPU idle-ish: tiny number of steps
 eng.reset(g)
 torch.cuda.synchronize()
@@ -55,19 +68,4 @@ t0 = time.perf_counter()
 eng.fit(feat, xy, idx, log_every=0, step_begin=0, step_end=50)
 print(f"host enqueue of 50 steps (queue not full): {(time.perf_counter()-t0)/50*1e6:.1f} us/step", flush=True)
 torch.cuda.synchronize()
-# k concurrent fits on k streams
-k = a.concurrent
-engines = [eng] + [FitEngine(s, n_rows, dev) for _ in range(k - 1)]
-streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
-for rep in range(a.reps):
-    for e, st in zip(engines, streams):
-        with torch.cuda.stream(st):
-            e.reset(g)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fit_many(engines, [feat] * k, [xy] * k, streams, log_every=1000)
-    t_launch = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    t = time.perf_counter() - t0
-    print(f"{k} concurrent fits: {t*1e3:.1f} ms total = {t/k*1e3:.1f} ms per image ({t/a.iters*1e6:.1f} us per lock-step), host enqueue {t_launch*1e3:.0f} ms", flush=True)
-print({i: v for i, v in engines[-1].loss_log().items()})
+print({i: v for i, v in eng.loss_log().items()})
