@@ -27,7 +27,8 @@ namespace {
 // BK = 64: 32 MFMAs (2048 cycles) per staged tile -- with BK = 32 every k-tile cost ~1 us, twice
 // its MFMA time, because the single prefetched tile's L2 latency was only half hidden.
 constexpr int BK = 64;
-constexpr int LDK = BK + 1;  // [row][k] layout, conflict-free for scalar writes + fragment reads
+constexpr int LDK = BK + 4;  // [row][k] layout: rows stay 16-B aligned for b128 accesses; a 16-lane
+                            // group reading 16 B at a 272-B row stride covers all 16 bank slots
 
 struct GemmArgs {
   const float* A;
@@ -80,11 +81,7 @@ struct Tile {
       if (NF4 % NT == 0 || f < NF4) {
         if (KCONTIG) {
           const int r = f / (BK / 4), kq = f % (BK / 4);
-          float* d = S + r * LDK + 4 * kq;  // bank = (r + 4kq + j) % 32: conflict-free
-          d[0] = regs[i].x;
-          d[1] = regs[i].y;
-          d[2] = regs[i].z;
-          d[3] = regs[i].w;
+          *reinterpret_cast<float4*>(S + r * LDK + 4 * kq) = regs[i];
         } else {
           const int k = f / (R / 4), rq = f % (R / 4);
           *reinterpret_cast<float4*>(S + k * R + 4 * rq) = regs[i];
@@ -93,8 +90,25 @@ struct Tile {
     }
   }
 
-  __device__ static __forceinline__ float frag(const float* __restrict__ S, int row, int k) {
-    return KCONTIG ? S[row * LDK + k] : S[k * R + row];
+  // All BK/2 = 32 fragment values of one lane for this tile.  MFMA step kk uses k index
+  // kh*32 + kk (kh = lane >> 5): any bijection of k is valid as long as A and B agree, and this
+  // one makes a lane's values CONTIGUOUS in the k-contiguous layout (8 x ds_read_b128).
+  __device__ static __forceinline__ void frags(const float* __restrict__ S, int row, int kh,
+                                               float (&f)[BK / 2]) {
+    if (KCONTIG) {
+      const float4* p = reinterpret_cast<const float4*>(S + row * LDK + kh * (BK / 2));
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        const float4 v = p[q];
+        f[4 * q + 0] = v.x;
+        f[4 * q + 1] = v.y;
+        f[4 * q + 2] = v.z;
+        f[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) f[kk] = S[(kh * (BK / 2) + kk) * R + row];
+    }
   }
 };
 
@@ -131,13 +145,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
       TA::load(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra);
       TB::load(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb);
     }
+    // Fragments of the whole tile first, then 32 MFMAs back to back: the compiler otherwise
+    // re-used one register pair and waited lgkmcnt(0) on a fresh ds_read every 2 dependent
+    // MFMAs (each k-tile cost ~2x its MFMA time).
     const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    float fa[BK / 2], fb[BK / 2];
+    TA::frags(As, ar, kh, fa);
+    TB::frags(Bs, bc, kh, fb);
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const float a = TA::frag(As, ar, 2 * kk + kh);
-      const float b = TB::frag(Bs, bc, 2 * kk + kh);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
+    for (int kk = 0; kk < BK / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
     if (do_colsum && tid < BM) {
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
@@ -177,14 +194,13 @@ constexpr TileCfg kCfgs[4] = {{64, 64}, {32, 64}, {32, 32}, {64, 32}};
 // The batch is small (2048 rows): pick the largest tile that still yields >= ~2 workgroups
 // per CU worth of waves, so that barrier / load phases of one wave hide behind another's MFMAs.
 int pick_cfg(int M, int N, int ksplits) {
+  // Measured at the fit's shapes (M = 2048, N, K <= 768): the per-tile time is set by the
+  // staging latency, not by the number of workgroups -- 64x64 wins everywhere (322.6 us/step vs
+  // 340.2 / 333.1 for 32x64 / 32x32), so it is the default; smaller tiles only for tiny outputs.
   if (g_cfg_override >= 0 && g_cfg_override < 4) return g_cfg_override;
-  for (int c : {0, 1, 2}) {
-    const long long waves = (long long)dvt_cdiv(M, 32) * dvt_cdiv(N, 32) * ksplits;
-    const long long wgs = (long long)dvt_cdiv(M, kCfgs[c].bm) * dvt_cdiv(N, kCfgs[c].bn) * ksplits;
-    (void)waves;
-    if (wgs >= 512) return c;
-  }
-  return 2;
+  (void)ksplits;
+  if (M <= 32 || N <= 32) return 2;
+  return 0;
 }
 
 template <bool A_KC, bool B_KC, int WM, int WN>
