@@ -83,107 +83,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, float4* __restri
   }
 }
 
-// ---- exact lazy Adam for the sparse (hash-grid) region -----------------------------------
-// One wave per bitmap word (32 entries = 64 float4, the same lane <-> float4 mapping as the
-// dense kernel).  MODE 0 (catch-up, before the forward pass): entries marked in the bitmap are
-// replayed from last_step[e] to `t` with a zero data gradient (g = wd * p), i.e. exactly the
-// steps the dense sweep would have applied to them.  MODE 1 (after the backward pass): step t
-// with the accumulated gradient, zero_grad, last_step = t + 1, clear the word.  MODE 2 =
-// MODE 0 + clear the word (used outside the loop).  ALL != 0: ignore the bitmap, every entry.
-struct LazyArgs {
-  float one_m_b1, beta2, one_m_b2, eps, wd;
-  int t;                    // MODE 0/2: replay through step t-1; MODE 1: apply step t
-  float neg_step, bc2s;     // MODE 1 scalars of step t
-  const float* table;       // [num_iters][2] = {neg_step_s, bc2s_s}
-  long long n_words;
-};
-
-template <int MODE, int ALL>
-__global__ __launch_bounds__(256) void adam_lazy_kernel(LazyArgs a, float4* __restrict__ P,
-                                                        float4* __restrict__ M, float4* __restrict__ V,
-                                                        float4* __restrict__ G,
-                                                        uint32_t* __restrict__ touched,
-                                                        int32_t* __restrict__ last) {
-  const int lane = threadIdx.x & 63;
-  const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long wave_stride = (long long)gridDim.x * 4;
-  for (long long w = wave_global; w < a.n_words; w += wave_stride) {
-    uint32_t word = ALL ? 0xffffffffu : touched[w];
-    if (word == 0u) continue;
-    const bool has = (word >> (lane >> 1)) & 1u;
-    const long long q = w * 64 + lane;
-    const long long e = q >> 1;
-    if (has) {
-      float4 p = P[q], m = M[q], v = V[q];
-      if (MODE == 1) {
-        const float4 g = G[q];
-        adam1(p.x, m.x, v.x, g.x, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, a.bc2s, a.eps, a.neg_step);
-        adam1(p.y, m.y, v.y, g.y, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, a.bc2s, a.eps, a.neg_step);
-        adam1(p.z, m.z, v.z, g.z, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, a.bc2s, a.eps, a.neg_step);
-        adam1(p.w, m.w, v.w, g.w, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, a.bc2s, a.eps, a.neg_step);
-        P[q] = p;
-        M[q] = m;
-        V[q] = v;
-        G[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((lane & 1) == 0) last[e] = a.t + 1;
-      } else {
-        const int from = last[e];
-        if (from < a.t) {
-          for (int s = from; s < a.t; ++s) {
-            const float ns = a.table[2 * s], bc = a.table[2 * s + 1];
-            adam1(p.x, m.x, v.x, 0.f, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, bc, a.eps, ns);
-            adam1(p.y, m.y, v.y, 0.f, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, bc, a.eps, ns);
-            adam1(p.z, m.z, v.z, 0.f, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, bc, a.eps, ns);
-            adam1(p.w, m.w, v.w, 0.f, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, bc, a.eps, ns);
-          }
-          P[q] = p;
-          M[q] = m;
-          V[q] = v;
-          // both lanes of the entry have read `from` above (same wave instruction)
-          if ((lane & 1) == 0) last[e] = a.t;
-        }
-      }
-    }
-    if (!ALL && (MODE == 1 || MODE == 2) && lane == 0) touched[w] = 0u;
-  }
-}
-
 }  // namespace
-
-// mode 0: catch-up of marked entries through step t-1; 1: apply step t to marked entries (+clear);
-// 2: catch-up + clear; 3: catch-up of ALL entries.
-int dvt_adam_lazy(int mode, const DvtAdamArgs* h, const DvtAdamSeg* sg, int t, const float* table,
-                  float* p, float* m, float* v, float* g, uint32_t* touched, int32_t* last,
-                  long long n_words, hipStream_t stream) {
-  if (!h || !p || !m || !v || !g || !touched || !last || !table || n_words <= 0) return DVT_E_BADARG;
-  LazyArgs a{};
-  a.one_m_b1 = (float)(1.0 - h->beta1);
-  a.beta2 = (float)h->beta2;
-  a.one_m_b2 = (float)(1.0 - h->beta2);
-  a.eps = (float)h->eps;
-  a.wd = (float)h->weight_decay;
-  a.t = t;
-  a.table = table;
-  a.n_words = n_words;
-  if (sg) {
-    a.neg_step = (float)(-(sg->lr / sg->bias_correction1));
-    a.bc2s = (float)sg->bias_correction2_sqrt;
-  }
-  long long blocks = (n_words + 3) / 4;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  const dim3 grid((unsigned)blocks), block(256);
-  // algorithmic bytes of the dense sweep this replaces (24 B/param) are credited to MODE 1 only
-  DvtProbeScope probe(DVT_PROBE_ADAM, stream, mode == 1 ? 24.0 * 256.0 * (double)n_words : 0.0);
-  switch (mode) {
-    case 0: hipLaunchKernelGGL((adam_lazy_kernel<0, 0>), grid, block, 0, stream, a, (float4*)p, (float4*)m, (float4*)v, (float4*)g, touched, last); break;
-    case 1: hipLaunchKernelGGL((adam_lazy_kernel<1, 0>), grid, block, 0, stream, a, (float4*)p, (float4*)m, (float4*)v, (float4*)g, touched, last); break;
-    case 2: hipLaunchKernelGGL((adam_lazy_kernel<2, 0>), grid, block, 0, stream, a, (float4*)p, (float4*)m, (float4*)v, (float4*)g, touched, last); break;
-    case 3: hipLaunchKernelGGL((adam_lazy_kernel<0, 1>), grid, block, 0, stream, a, (float4*)p, (float4*)m, (float4*)v, (float4*)g, touched, last); break;
-    default: return DVT_E_BADARG;
-  }
-  DVT_CHECK_LAUNCH();
-  return 0;
-}
 
 int dvt_adam_tune(int zero_all) {
   g_adam_zero_all = zero_all;

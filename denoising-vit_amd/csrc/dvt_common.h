@@ -54,8 +54,3 @@ struct DvtProbeScope {
 int dvt_vit_tune(int gemm_variant);
 int dvt_grid_tune(int lds_level_max);
 int dvt_adam_tune(int zero_all);
-int dvt_grid_mark_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ridx,
-                      uint32_t* touched, int n, hipStream_t stream);
-int dvt_adam_lazy(int mode, const DvtAdamArgs* h, const DvtAdamSeg* sg, int t, const float* table,
-                  float* p, float* m, float* v, float* g, uint32_t* touched, int32_t* last,
-                  long long n_words, hipStream_t stream);

@@ -124,7 +124,6 @@ namespace {
 int check_bufs(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin, int step_end) {
   int rc = check_cfg(c);
   if (rc) return rc;
-  if (b && c->lazy_adam && (!b->last_step || !b->step_table)) return DVT_E_BADARG;
   if (!b || !b->feat || !b->xy || !b->idx || !b->params || !b->adam_m || !b->adam_v ||
       !b->grads || !b->touched || !b->workspace || !b->h_lr)
     return DVT_E_BADARG;
@@ -144,19 +143,6 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
   const bool log = b->losses != nullptr &&
                    ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
 
-  const bool lazy = c->lazy_adam != 0;
-  const long long n_words = c->off_w1 / 256;
-  DvtAdamArgs a{};
-  a.beta1 = c->beta1;
-  a.beta2 = c->beta2;
-  a.eps = c->eps;
-  a.weight_decay = c->weight_decay;
-  if (lazy) {
-    // entries this step reads must first receive the dense steps they have not seen yet
-    DVT_TRY(dvt_grid_mark_idx(&c->grid, b->xy, ridx, b->touched, B, s));
-    DVT_TRY(dvt_adam_lazy(0, &a, nullptr, step, b->step_table, P, b->adam_m, b->adam_v, Gd,
-                          b->touched, b->last_step, n_words, s));
-  }
   // ---- forward ----
   DVT_TRY(dvt_gather_rows(b->feat, ridx, w.raw, B, C, 0, s));
   DVT_TRY(dvt_grid_fwd_idx(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, B, s));
@@ -186,10 +172,15 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
     DVT_TRY(dvt_linear_bwd(w.dr1, w.raw, P + c->off_wh1, Gd + c->off_wh1, Gd + c->off_bh1, nullptr,
                            nullptr, B, R, C, s));
   }
-  // ---- Adam + zero_grad ----
-  a.sparse_end = lazy ? 0 : c->off_w1;
+  // ---- Adam (dense) + zero_grad ----
+  DvtAdamArgs a{};
+  a.beta1 = c->beta1;
+  a.beta2 = c->beta2;
+  a.eps = c->eps;
+  a.weight_decay = c->weight_decay;
+  a.sparse_end = c->off_w1;
   const double lr = b->h_lr[step];
-  auto mkseg = [&](int64_t beg, int64_t end, int t) {
+  auto seg = [&](int64_t beg, int64_t end, int t) {
     DvtAdamSeg sg{};
     sg.begin = beg;
     sg.end = end;
@@ -197,21 +188,13 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
     sg.bias_correction1 = 1.0 - pow(c->beta1, (double)t);
     sg.bias_correction2_sqrt = sqrt(1.0 - pow(c->beta2, (double)t));
     sg.active = 1;
-    return sg;
+    a.segs[a.n_segs++] = sg;
   };
-  auto seg = [&](int64_t beg, int64_t end, int t) { a.segs[a.n_segs++] = mkseg(beg, end, t); };
-  // the dense tensors: field MLP (+ G in phase 1), and h with its own step count in phase 2
-  const int64_t dense_begin = lazy ? c->off_w1 : c->off_grid;
   if (!phase2) {
-    seg(dense_begin, c->off_wh1, step + 1);  // (grid +) field MLP + G
+    seg(c->off_grid, c->off_wh1, step + 1);  // grid + field MLP + G
   } else {
-    seg(dense_begin, c->off_G, step + 1);  // (grid +) field MLP (G frozen: grad None)
+    seg(c->off_grid, c->off_G, step + 1);  // grid + field MLP (G frozen: grad None)
     if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
-  }
-  if (lazy) {
-    const DvtAdamSeg gs = mkseg(0, c->off_w1, step + 1);
-    DVT_TRY(dvt_adam_lazy(1, &a, &gs, step, b->step_table, P, b->adam_m, b->adam_v, Gd, b->touched,
-                          b->last_step, n_words, s));
   }
   return dvt_adam_step(&a, P, b->adam_m, b->adam_v, Gd, b->touched, s);
 }
@@ -251,40 +234,4 @@ extern "C" int dvt_fit_run_multi(int k, const DvtFitConfig* const* cfgs,
       if (rc) return rc;
     }
   return 0;
-}
-
-extern "C" int dvt_fit_step_table(const DvtFitConfig* c, const double* h_lr, float* table) {
-  if (check_cfg(c) || !h_lr || !table) return DVT_E_BADARG;
-  for (int s = 0; s < c->num_iters; ++s) {
-    const int t = s + 1;
-    const double bc1 = 1.0 - pow(c->beta1, (double)t);
-    table[2 * s] = (float)(-(h_lr[s] / bc1));
-    table[2 * s + 1] = (float)sqrt(1.0 - pow(c->beta2, (double)t));
-  }
-  return 0;
-}
-
-extern "C" int dvt_fit_sync_entries(const DvtFitConfig* c, const DvtFitBuffers* b, const float* xy,
-                                    int n, int steps_done, void* stream) {
-  int rc = check_cfg(c);
-  if (rc) return rc;
-  if (!c->lazy_adam) return 0;
-  if (!b || !b->params || !b->adam_m || !b->adam_v || !b->grads || !b->touched || !b->last_step ||
-      !b->step_table || steps_done < 0 || steps_done > c->num_iters || n < 0)
-    return DVT_E_BADARG;
-  hipStream_t s = (hipStream_t)stream;
-  DvtAdamArgs a{};
-  a.beta1 = c->beta1;
-  a.beta2 = c->beta2;
-  a.eps = c->eps;
-  a.weight_decay = c->weight_decay;
-  const long long n_words = c->off_w1 / 256;
-  if (xy == nullptr)
-    return dvt_adam_lazy(3, &a, nullptr, steps_done, b->step_table, b->params, b->adam_m, b->adam_v,
-                         b->grads, b->touched, b->last_step, n_words, s);
-  if (n == 0) return 0;
-  rc = dvt_grid_mark_idx(&c->grid, xy, nullptr, b->touched, n, s);
-  if (rc) return rc;
-  return dvt_adam_lazy(2, &a, nullptr, steps_done, b->step_table, b->params, b->adam_m, b->adam_v,
-                       b->grads, b->touched, b->last_step, n_words, s);
 }

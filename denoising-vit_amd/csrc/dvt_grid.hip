@@ -20,7 +20,7 @@
 
 #include "dvt_common.h"
 
-extern "C" int dvt_abi_version(void) { return 2; }
+extern "C" int dvt_abi_version(void) { return 1; }
 
 extern "C" int dvt_struct_sizes(int64_t* out) {
   if (!out) return DVT_E_BADARG;
@@ -285,39 +285,6 @@ int dvt_grid_tune(int lds_level_max) {
     return 0;
   }
   g_grid_lds_level_max = lds_level_max;
-  return 0;
-}
-
-// Mark the entries the given samples will read/update in the touched bitmap (lazy Adam: the
-// marked entries are caught up BEFORE the forward pass reads them).
-__global__ __launch_bounds__(256) void grid_mark_kernel(DvtGridTable T, const float2* __restrict__ xy,
-                                                        const int32_t* __restrict__ ridx,
-                                                        uint32_t* __restrict__ touched, int n) {
-  const int L = T.n_levels;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * L) return;
-  const int b = t / L, l = t - b * L;
-  const float2 p = xy[ridx != nullptr ? ridx[b] : b];
-  uint32_t idx[4];
-  float w[4];
-  corners2d(T, l, p.x, p.y, idx, w);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const uint32_t bit = 1u << (idx[c] & 31u);
-    uint32_t* wp = touched + (idx[c] >> 5);
-    if ((__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0u)
-      __hip_atomic_fetch_or(wp, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-int dvt_grid_mark_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ridx,
-                      uint32_t* touched, int n, hipStream_t stream) {
-  if (!tbl || !xy || !touched || n < 0) return DVT_E_BADARG;
-  if (n == 0) return 0;
-  const long long threads = (long long)n * tbl->n_levels;
-  hipLaunchKernelGGL(grid_mark_kernel, dim3(dvt_cdiv(threads, 256)), dim3(256), 0, stream, *tbl,
-                     (const float2*)xy, ridx, touched, n);
-  DVT_CHECK_LAUNCH();
   return 0;
 }
 

@@ -83,7 +83,7 @@ class FitConfig(C.Structure):
         ("num_iters", C.c_int32),
         ("switch_step", C.c_int32),
         ("enable_residual", C.c_int32),
-        ("lazy_adam", C.c_int32),
+        ("pad0_", C.c_int32),
         ("grad_scale", C.c_double),
         ("beta1", C.c_double),
         ("beta2", C.c_double),
@@ -121,8 +121,6 @@ class FitBuffers(C.Structure):
         ("h_lr", C.c_void_p),
         ("log_every", C.c_int32),
         ("pad_", C.c_int32),
-        ("last_step", C.c_void_p),
-        ("step_table", C.c_void_p),
     ]
 
 
@@ -150,8 +148,6 @@ _SIGNATURES = {
     "dvt_fit_run": (_I, [C.POINTER(FitConfig), C.POINTER(FitBuffers), _I, _I, _P]),
     "dvt_fit_run_multi": (_I, [_I, C.POINTER(C.POINTER(FitConfig)), C.POINTER(C.POINTER(FitBuffers)),
                                C.POINTER(C.c_void_p), _I, _I]),
-    "dvt_fit_sync_entries": (_I, [C.POINTER(FitConfig), C.POINTER(FitBuffers), _P, _I, _I, _P]),
-    "dvt_fit_step_table": (_I, [C.POINTER(FitConfig), _P, _P]),
     "dvt_field_infer": (_I, [C.POINTER(FitConfig), _P, _P, _P, _P, _I, _P]),
     "dvt_tune_set": (_I, [_I, _I]),
     "dvt_prof_enable": (_I, [C.c_uint]),

@@ -44,9 +44,6 @@ class FitSettings:
     beta2: float = 0.99
     eps: float = 1e-15
     grid_seed: int = 1337
-    # exact lazy replay of the dense Adam for untouched hash-grid entries (include/dvt_hip.h);
-    # False = stream all 21.5 M parameters every step like torch does
-    lazy_adam: bool = True
 
     @property
     def lattice(self) -> int:
@@ -87,7 +84,6 @@ class FitEngine:
         cfg.num_iters = settings.num_iters
         cfg.switch_step = int(settings.freeze_shared_artifacts_after * settings.num_iters)
         cfg.enable_residual = int(settings.enable_residual_predictor)
-        cfg.lazy_adam = int(settings.lazy_adam)
         cfg.grad_scale = settings.grad_scale
         cfg.beta1, cfg.beta2 = settings.beta1, settings.beta2
         cfg.eps, cfg.weight_decay = settings.eps, settings.weight_decay
@@ -110,41 +106,6 @@ class FitEngine:
             [lr_schedule(i, settings.lr, settings.min_lr, settings.warmup_iters, settings.num_iters)
              for i in range(settings.num_iters)], dtype=np.float64)
         self._infer_ws = None
-        # lazy Adam state: steps already applied per grid entry + per-step scalar table
-        self.last_step = torch.zeros(int(cfg.off_w1) // 8, device=dev, dtype=torch.int32)
-        table = np.zeros((settings.num_iters, 2), dtype=np.float32)
-        _lib.check(L.dvt_fit_step_table(C.byref(cfg), self.h_lr.ctypes.data, table.ctypes.data),
-                   "dvt_fit_step_table")
-        self.step_table = torch.from_numpy(table).to(dev)
-        self.steps_done = 0
-        self._bufs = None
-
-    # ------------------------------------------------------------------ lazy-Adam bookkeeping
-    def _base_buffers(self):
-        b = _lib.FitBuffers()
-        b.params, b.adam_m, b.adam_v = (self.params.data_ptr(), self.adam_m.data_ptr(),
-                                        self.adam_v.data_ptr())
-        b.grads, b.touched = self.grads.data_ptr(), self.touched.data_ptr()
-        b.workspace, b.losses = self.workspace.data_ptr(), self.losses.data_ptr()
-        b.h_lr = self.h_lr.ctypes.data
-        b.last_step, b.step_table = self.last_step.data_ptr(), self.step_table.data_ptr()
-        return b
-
-    def sync_entries(self, xy: torch.Tensor | None = None) -> None:
-        """Lazy Adam: bring the grid entries read at `xy` (all entries when None) up to date
-        through the steps enqueued so far.  Required before reading `params` outside the loop."""
-        if not self.s.lazy_adam or self.steps_done == 0:
-            return
-        b = self._base_buffers()
-        if xy is None:
-            ptr, n = None, 0
-        else:
-            xy = xy.reshape(-1, 2).contiguous().float()
-            self._sync_xy = xy
-            ptr, n = xy.data_ptr(), xy.shape[0]
-        _lib.check(_lib.lib().dvt_fit_sync_entries(C.byref(self.cfg), C.byref(b), ptr, n,
-                                                   self.steps_done, _lib.stream()),
-                   "dvt_fit_sync_entries")
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name: str) -> torch.Tensor:
@@ -173,8 +134,6 @@ class FitEngine:
         self.adam_v.zero_()
         self.grads.zero_()
         self.touched.zero_()
-        self.last_step.zero_()
-        self.steps_done = 0
 
     def load_modules(self, denoiser, neural_field) -> None:
         """Copy the parameters of reference-style modules into the arena (and clear state)."""
@@ -196,11 +155,8 @@ class FitEngine:
         self.adam_v.zero_()
         self.grads.zero_()
         self.touched.zero_()
-        self.last_step.zero_()
-        self.steps_done = 0
 
     def export_modules(self, denoiser, neural_field) -> None:
-        self.sync_entries(None)  # lazy Adam: materialise every pending dense step first
         with torch.no_grad():
             neural_field.neural_field.params.copy_(self.view("grid"))
             neural_field.mlp[0].weight.copy_(self.view("w1"))
@@ -254,8 +210,13 @@ class FitEngine:
             raise _lib.DvtError("idx must be int32 [num_iters, pixel_bsz]")
         self._idx = idx.contiguous()  # keep alive while kernels are in flight
         self._feat, self._xy = feat, xy
-        b = self._base_buffers()
+        b = _lib.FitBuffers()
         b.feat, b.xy, b.idx = feat.data_ptr(), xy.data_ptr(), self._idx.data_ptr()
+        b.params, b.adam_m, b.adam_v = (self.params.data_ptr(), self.adam_m.data_ptr(),
+                                        self.adam_v.data_ptr())
+        b.grads, b.touched = self.grads.data_ptr(), self.touched.data_ptr()
+        b.workspace, b.losses = self.workspace.data_ptr(), self.losses.data_ptr()
+        b.h_lr = self.h_lr.ctypes.data
         b.log_every = int(log_every)
         return b
 
@@ -270,13 +231,11 @@ class FitEngine:
         end = self.s.num_iters if step_end is None else step_end
         _lib.check(_lib.lib().dvt_fit_run(C.byref(self.cfg), C.byref(b), step_begin, end,
                                           _lib.stream()), "dvt_fit_run")
-        self.steps_done = end
 
     def infer(self, xy: torch.Tensor) -> torch.Tensor:
         """F(xy): the denoised features saved by the reference (quirk Q7) -- the field evaluated
         on a coordinate lattice, main_img_denoising.py:121-130 / offline_denoiser.py:151."""
         _lib.require_cuda(xy)
-        self.sync_entries(xy)
         shape = xy.shape[:-1]
         xy2 = xy.reshape(-1, 2).contiguous().float()
         n = xy2.shape[0]
@@ -314,5 +273,3 @@ def fit_many(engines, feats, xys, streams, log_every: int = 1000) -> None:
     st_arr = (C.c_void_p * k)(*[st.cuda_stream for st in streams])
     _lib.check(_lib.lib().dvt_fit_run_multi(k, cfg_arr, buf_arr, st_arr, 0, engines[0].s.num_iters),
                "dvt_fit_run_multi")
-    for e in engines:
-        e.steps_done = e.s.num_iters

@@ -193,7 +193,7 @@ typedef struct DvtFitConfig {
   int32_t num_iters;
   int32_t switch_step;  /* int(freeze_shared_artifacts_after*num_iters); phase 2 iff step > switch_step */
   int32_t enable_residual; /* enable_residual_predictor */
-  int32_t lazy_adam;       /* 1: exact lazy replay of the dense Adam for the hash grid (see below) */
+  int32_t pad0_;
   double grad_scale;    /* 1024: GradScaler quirk, main_img_denoising.py:55,:88 */
   double beta1, beta2, eps, weight_decay;
   DvtGridTable grid;
@@ -216,26 +216,7 @@ typedef struct DvtFitBuffers {
   const double* h_lr;  /* HOST: lr per step (misc.adjust_learning_rate) */
   int32_t log_every;   /* 0: never */
   int32_t pad_;
-  /* lazy_adam only: */
-  int32_t* last_step;  /* [n_entries_total] number of Adam steps already applied to each grid entry */
-  float* step_table;   /* [num_iters, 2] device copy of {-(lr_s / bias_correction1_s), sqrt(bias_correction2_s)} */
 } DvtFitBuffers;
-
-/* Lazy Adam (lazy_adam = 1).  torch's Adam is DENSE: every grid entry is stepped every
- * iteration, also the ~95 % whose data gradient is exactly zero (their gradient is just
- * weight_decay * p).  Each element's (p, m, v) recurrence depends on no
- * other element, so the zero-data-gradient steps of an entry can be replayed later -- with the
- * identical fp32 arithmetic, in the identical order -- at the moment the entry is next needed
- * (read by the forward pass, or exported).  Per step only the <= 2048*16*4 touched entries move
- * through HBM (~25 MB instead of 515 MB); results are identical to the dense sweep.
- *   dvt_fit_sync_entries brings the entries touched by xy[n,2] (or ALL entries when xy == NULL)
- *   up to date through `steps_done` steps: needed before reading parameters outside dvt_fit_run
- *   (final inference, export). No-op for lazy_adam = 0. */
-int dvt_fit_sync_entries(const DvtFitConfig* h_cfg, const DvtFitBuffers* h_bufs, const float* xy,
-                         int n, int steps_done, void* stream);
-/* HOST: fill table[num_iters*2] (host memory) with the per-step scalars above for the grid
- * tensor group (t = step + 1). */
-int dvt_fit_step_table(const DvtFitConfig* h_cfg, const double* h_lr, float* h_table);
 
 /* HOST: fill the arena offsets of cfg from its dims (layout documented in DESIGN.md). */
 int dvt_fit_layout(DvtFitConfig* h_cfg);

@@ -50,9 +50,8 @@ def per_patch_cos(a, b):
     return torch.nn.functional.cosine_similarity(a, b, dim=-1)
 
 
-@pytest.mark.parametrize("lazy", [True, False])
 @pytest.mark.parametrize("num_iters,warmup", [(60, 6)])
-def test_fused_fit_matches_oracle(built_lib, num_iters, warmup, lazy):
+def test_fused_fit_matches_oracle(built_lib, num_iters, warmup):
     from dvt_amd.fit import FitEngine, FitSettings
     from dvt_amd.models import NeuralFeatureField, SingleImageDenoiser
     V, H, W, C, B = 9, 7, 7, 64, 256
@@ -63,8 +62,7 @@ def test_fused_fit_matches_oracle(built_lib, num_iters, warmup, lazy):
     f_o = NeuralFeatureFieldOracle(**kw)
     d_o = SingleImageDenoiserOracle(H, W, C, 3)
     s = FitSettings(feat_dim=C, noise_map_height=H, noise_map_width=W, n_levels=16,
-                    log2_hashmap_size=12, num_iters=num_iters, warmup_iters=warmup, pixel_bsz=B,
-                    lazy_adam=lazy)
+                    log2_hashmap_size=12, num_iters=num_iters, warmup_iters=warmup, pixel_bsz=B)
     n_rows = V * H * W
     eng = FitEngine(s, n_rows, DEV)
     # identical initial parameters: oracle modules -> reference-style HIP modules -> arena
@@ -128,9 +126,7 @@ def test_full_size_properties(built_lib):
     assert log[39]["patch_l2_loss"] < 0.9 * log[0]["patch_l2_loss"], "the fit must reduce the loss"
     assert float(eng.grads.abs().max()) == 0.0 and int(eng.touched.abs().max()) == 0
     assert bool(torch.isfinite(eng.params).all())
-    # dense Adam semantics: every real grid parameter moved (lazy mode: once materialised),
-    # alignment padding stayed exactly zero
-    eng.sync_entries(None)
+    # dense Adam: every real grid parameter moved, alignment padding stayed exactly zero
     grid0, grid1 = p0[:19741760], eng.view("grid")
     assert float((grid1 != grid0).float().mean()) > 0.99999
     assert float(eng.params[19741760:int(eng.cfg.off_w1)].abs().max()) == 0.0
@@ -148,50 +144,7 @@ def test_full_size_properties(built_lib):
     torch.cuda.synchronize()
     assert torch.equal(eng2.view("G"), G21) and not torch.equal(eng2.view("wh3"), h21)
     # determinism up to atomics order: two runs agree closely (same init, same stream)
-    eng2.sync_entries(None)
     d = (eng2.params - eng.params).abs()
     assert float(d.mean()) < 1e-4 and float(d.max()) < 0.1
     out = eng.infer(xy[-1].to(DEV))
     assert out.shape == (37, 37, 768) and bool(torch.isfinite(out).all())
-
-
-def test_lazy_adam_equals_dense_adam(built_lib):
-    """The lazy replay IS the dense sweep: with identical gradients the two modes must agree
-    BIT FOR BIT on every parameter and both moments.  Forcing the index stream to a small
-    subset of rows leaves most grid entries untouched for the whole run (pure replay), some
-    touched once in a while (replay + data steps), some every step."""
-    from dvt_amd.fit import FitEngine, FitSettings
-    V, H, W, C, B, T = 6, 8, 8, 64, 64, 30
-    feats, xy = synthetic_image(V, H, W, C, seed=3)
-    n_rows = V * H * W
-    rng = np.random.RandomState(0)
-    hot = rng.randint(0, n_rows, 40)
-    idx = hot[rng.randint(0, 40, (T, B))].astype(np.int32)
-    idx[::7] = rng.randint(0, n_rows, (len(idx[::7]), B))  # occasionally touch other entries
-    res = {}
-    for lazy in (False, True):
-        s = FitSettings(feat_dim=C, noise_map_height=H, noise_map_width=W, log2_hashmap_size=14,
-                        num_iters=T, warmup_iters=3, pixel_bsz=B, lazy_adam=lazy)
-        eng = FitEngine(s, n_rows, DEV)
-        eng.reset(torch.Generator(device=DEV).manual_seed(5))
-        # order-independent gradients: B=64 samples rarely share an entry on the fine levels, but
-        # atomics may still reorder sums -> compare with a tolerance of a few ulps on touched
-        # entries and EXACTLY on entries no sample ever touched
-        eng.fit(feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV), idx, log_every=0)
-        eng.sync_entries(None)
-        torch.cuda.synchronize()
-        res[lazy] = (eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.last_step.clone())
-    never = (res[True][3][: res[True][0].numel() // 8] == T)  # after sync every entry is at T
-    assert bool(never.all())
-    from oracle import hashgrid as hg
-    tbl = hg.grid_table(16, 8, 16, 1024, 14)
-    touched_entries = np.unique(hg.corners(tbl, xy.reshape(-1, 2)[np.unique(idx)].numpy())[0])
-    mask = torch.ones(tbl.n_entries_total, dtype=torch.bool)
-    mask[torch.from_numpy(touched_entries.astype(np.int64))] = False  # entries NEVER touched
-    assert int(mask.sum()) > 0.5 * tbl.n_entries_total
-    sel = mask.repeat_interleave(8).to(DEV)
-    n = sel.numel()
-    for a, b, name in zip(res[False][:3], res[True][:3], ("p", "m", "v")):
-        assert torch.equal(a[:n][sel], b[:n][sel]), f"{name}: pure replay must be bit-identical"
-        err = float((a - b).abs().max() / (a.abs().max() + 1e-30))
-        assert err < 1e-5, (name, err)
