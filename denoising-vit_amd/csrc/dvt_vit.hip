@@ -71,6 +71,7 @@ struct GemmBArgs {
   const float* pos;   // EPI_EMBED: pos_embed [n_tokens, N]
   const float* cls;   // EPI_EMBED: cls token [N]
   int dim, heads, s_pad, n_tokens;
+  int group;          // N tiles per L2-resident group (set by launch_gemm)
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -96,6 +97,34 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ X, int ld,
 
 __device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+// ---- L2-aware tile rasterisation ------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs (private 4 MiB L2 each), so (1) every XCD gets a
+// CONTIGUOUS run of the tile order, and (2) the order walks N in groups of `group` tiles whose W
+// slices (group * 128 * K * 2 B <= ~2.4 MB) stay L2-resident while all M panels stream past:
+//     order = (n_group, m_panel, n_in_group)
+// Plain "N fastest" re-streamed the whole W (4.7 MB for fc1/fc2 > L2) for every M panel:
+// ~3.6 GB of memory-side reads per fc1 launch instead of ~0.6 GB.
+struct TileMap {
+  int m, n;
+};
+__device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, int group) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;  // bijective
+  const int per_group = group * mt;
+  int g = id / per_group;
+  const int full = nt / group;
+  int width = group;
+  if (g >= full) {  // last, narrower group
+    g = full;
+    width = nt - full * group;
+  }
+  const int rem = id - g * per_group;
+  TileMap t;
+  t.m = rem / width;
+  t.n = g * group + rem % width;
+  return t;
 }
 
 // Fused epilogues.  acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*(lane>>4) + r][n0 + wn*64 + j*16 + (lane&15)]
@@ -170,16 +199,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs, so give every XCD a
-  // contiguous run of tiles (N fastest) -> the A row panel of a run stays in that XCD's L2.
-  const int ntn = p.N / GBN;
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int m0 = (bid / ntn) * GBM, n0 = (bid % ntn) * GBN;
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / GBM, p.N / GBN, p.group);
+  const int m0 = tm.m * GBM, n0 = tm.n * GBN;
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -338,14 +359,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_256(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[3 * G2_STAGE];  // 144 KB, ONE LDS object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = p.N / GBN;
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int m0 = (bid / ntn) * G2_BM, n0 = (bid % ntn) * GBN;
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / G2_BM, p.N / GBN, p.group);
+  const int m0 = tm.m * G2_BM, n0 = tm.n * GBN;
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -394,9 +409,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_256(GemmBArgs p) {
   gemm_epilogue_lds<EPI>(p, acc, m0, n0, wm, wn, wave, lane, smem);
 }
 
+int g_vit_group_bytes = 2400 * 1024;  // W bytes kept L2-resident per group (tunable)
+
 template <int EPI>
-int launch_gemm(const GemmBArgs& a, hipStream_t s) {
-  if (a.M % GBM || a.N % GBN || a.K % GBK || a.M <= 0) return DVT_E_BADARG;
+int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
+  if (a0.M % GBM || a0.N % GBN || a0.K % GBK || a0.M <= 0) return DVT_E_BADARG;
+  GemmBArgs a = a0;
+  {
+    const int nt = a.N / GBN;
+    int g = g_vit_group_bytes / (GBN * a.K * 2);
+    g = g < 1 ? 1 : (g > nt ? nt : g);
+    while (g > 1 && nt % g) --g;  // prefer a divisor of the tile count (equal groups)
+    a.group = g;
+  }
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
   if (a.M % G2_BM == 0 && g_vit_gemm_variant != 1) {
     const int tiles = (a.M / G2_BM) * (a.N / GBN);
@@ -514,7 +539,16 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
   __shared__ __attribute__((aligned(16))) char Vs[64 * VT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lc = lane & 15;
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid; XCD x gets a contiguous run of (image, head, query-block) triples so that the
+  // query blocks of one head share that XCD's L2 copy of K / V^T (round-robin placement would
+  // spread them over all 8 L2s: 8x the K/V traffic)
+  const int nqb = s_pad / ATT_Q;
+  int id = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int qb = id % nqb, h = (id / nqb) % heads, b = id / (nqb * heads);
   const int dim = heads * 64, ldq = 2 * dim;
   const size_t row0 = (size_t)b * s_pad;
 
@@ -693,8 +727,12 @@ int check_vit_cfg(const DvtVitConfig* c) {
 
 }  // namespace
 
-int dvt_vit_tune(int gemm_variant) {
-  g_vit_gemm_variant = gemm_variant;
+int dvt_vit_tune(int v) {
+  if (v >= 16) {  // values >= 16: L2 group budget in KiB
+    g_vit_group_bytes = v * 1024;
+    return 0;
+  }
+  g_vit_gemm_variant = v;
   return 0;
 }
 
@@ -759,7 +797,7 @@ extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int 
     return DVT_E_BADARG;
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
                       4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
-  hipLaunchKernelGGL(attention_kernel, dim3(s_pad / ATT_Q, heads, batch), dim3(512), 0,
+  hipLaunchKernelGGL(attention_kernel, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
                      (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads,
                      s_pad, n_valid);
   DVT_CHECK_LAUNCH();
