@@ -17,4 +17,5 @@ run tcc TCC_HIT_sum TCC_MISS_sum
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 cd $GRAFT_REPO_ROOT
 for n in sq1 sq2 fetch write tcc grbm; do f=$(find gpurun_out/pmc/$n -name '*.db' | head -1); echo "== $n $f"; [ -n "$f" ] && python tools/pmc_stats.py $f > gpurun_out/pmc/$n.txt 2>&1; head -3 gpurun_out/pmc/$n.txt; done
+for n in sq1 sq2 fetch write tcc grbm; do rm -rf gpurun_out/pmc/$n; done   # keep the summaries only (merge limit 64 MiB)
 du -sh gpurun_out/pmc
