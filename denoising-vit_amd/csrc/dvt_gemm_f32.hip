@@ -183,6 +183,143 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
   if (do_colsum && tid < BM && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
 }
 
+// ==========================================================================================
+// 3-stage LDS-DMA variant (used when K % 64 == 0 and row-contiguous operands are 64-aligned).
+// PMC evidence for the register-staged kernel above at the fit's shapes: L2 hit rate 43 % (the
+// operands were just written by other XCDs' kernels), waves 45-54 % in s_waitcnt, MFMA pipe
+// ~13 % busy -> latency-bound with one tile in flight.  Here global_load_lds keeps TWO 32-KB
+// stages in flight per workgroup behind the one being multiplied: one raw s_barrier per
+// k-tile and a counted `s_waitcnt vmcnt(8)` (8 DMA instructions per thread per stage).
+// LDS image is lane-linear; for k-contiguous operands the 16-B chunk index of a 256-B row is
+// XOR-ed with (row & 15) through the SOURCE address, and the b128 fragment reads apply the
+// same XOR (conflict-free: the 16 rows of a lane group hit 16 distinct slots).
+// ==========================================================================================
+constexpr int G3_STAGE_FLOATS = 2 * 64 * BK;  // A tile + B tile, 64 rows/cols x 64 k = 32 KB
+
+__device__ __forceinline__ void glds16f(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void stage_f32(const float* __restrict__ X, int ld, int r0, int Rmax,
+                                          int k0, float* lds, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 256 + wave * 64 + lane;  // 16-B slot in the 16-KB tile
+    const float* src;
+    if (KCONTIG) {
+      const int row = s >> 4, cp = s & 15, c = cp ^ (row & 15);
+      src = X + (size_t)min(r0 + row, Rmax - 1) * ld + k0 + c * 4;  // rows >= Rmax: clamped, masked at the store
+    } else {
+      const int k = s >> 4, cq = s & 15;
+      src = X + (size_t)(k0 + k) * ld + r0 + cq * 4;
+    }
+    glds16f(src, lds + (it * 256 + wave * 64) * 4);
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void frags_f32(const float* __restrict__ S, int row, int kh,
+                                          float (&f)[BK / 2]) {
+  if (KCONTIG) {
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      const int chunk = (kh * (BK / 8) + q) ^ (row & 15);
+      const float4 v = *reinterpret_cast<const float4*>(S + row * BK + chunk * 4);
+      f[4 * q + 0] = v.x;
+      f[4 * q + 1] = v.y;
+      f[4 * q + 2] = v.z;
+      f[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) f[kk] = S[(kh * (BK / 2) + kk) * 64 + row];
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_glds_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * G3_STAGE_FLOATS];  // 96 KB, one LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  if (kbeg >= kend) return;
+  const int nk = (kend - kbeg) / BK;
+
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float csum = 0.f;
+  const bool do_colsum = (!A_KC) && p.colsum != nullptr && blockIdx.x == 0;
+
+#define G3_ISSUE(kt)                                                                          \
+  do {                                                                                        \
+    float* st_ = smem + ((kt) % 3) * G3_STAGE_FLOATS;                                         \
+    stage_f32<A_KC>(p.A, p.lda, m0, p.M, kbeg + (kt) * BK, st_, wave, lane);                  \
+    stage_f32<B_KC>(p.B, p.ldb, n0, p.N, kbeg + (kt) * BK, st_ + 64 * BK, wave, lane);        \
+  } while (0)
+  G3_ISSUE(0);
+  if (nk > 1) G3_ISSUE(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk) G3_ISSUE(kt + 2);
+    const float* As = smem + (kt % 3) * G3_STAGE_FLOATS;
+    const float* Bs = As + 64 * BK;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    float fa[BK / 2], fb[BK / 2];
+    frags_f32<A_KC>(As, ar, kh, fa);
+    frags_f32<B_KC>(Bs, bc, kh, fb);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
+    if (do_colsum && tid < 64) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) csum += As[k * 64 + tid];
+    }
+  }
+#undef G3_ISSUE
+
+  const int gn = n0 + wn * 32 + (lane & 31);
+  const float bias = (p.bias != nullptr && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int gm = m0 + wm * 32 + row;
+    if (gm < p.M && gn < p.N) {
+      float v = acc[r] + bias;
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.mask != nullptr) v = p.mask[(size_t)gm * p.ldmask + gn] > 0.f ? v : 0.f;
+      float* c = p.C + (size_t)gm * p.ldc + gn;
+      if (p.atomic)
+        atomic_add_f32(c, v);
+      else
+        *c = v;
+    }
+  }
+  if (do_colsum && tid < 64 && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
+}
+
+int g_f32_glds = 1;  // 0: always the register-staged kernel
+extern int g_cfg_override;
+
+// eligibility of the LDS-DMA kernel: whole k-tiles, and row-contiguous operands whose 64-wide
+// tile never runs past the row end (k-contiguous operands are clamped per row instead)
+template <bool A_KC, bool B_KC>
+bool glds_ok(const GemmArgs& a) {
+  if (!g_f32_glds || (a.K % BK) || (a.kchunk % BK) || g_cfg_override > 0) return false;
+  if (!A_KC && (a.M % 64)) return false;
+  if (!B_KC && (a.N % 64)) return false;
+  return a.M >= 1 && a.N >= 1;
+}
+
 // Tile configurations: 0 = 64x64 (4 waves), 1 = 32x64 (2 waves), 2 = 32x32 (1 wave), 3 = 64x32.
 int g_cfg_override = -1;
 
@@ -214,6 +351,13 @@ int launch_cfg(const GemmArgs& a, int ksplits, hipStream_t s) {
 
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
+  if (glds_ok<A_KC, B_KC>(a)) {
+    dim3 grid(dvt_cdiv(a.N, 64), dvt_cdiv(a.M, 64), ksplits);
+    DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+    DVT_CHECK_LAUNCH();
+    return 0;
+  }
   switch (pick_cfg(a.M, a.N, ksplits)) {
     case 0: return launch_cfg<A_KC, B_KC, 2, 2>(a, ksplits, s);
     case 1: return launch_cfg<A_KC, B_KC, 1, 2>(a, ksplits, s);
@@ -227,6 +371,10 @@ int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
 extern "C" int dvt_tune_set(int key, int value) {
   if (key == 0) {
     g_cfg_override = value;
+    return 0;
+  }
+  if (key == 4) {
+    g_f32_glds = value;
     return 0;
   }
   if (key == 1) return dvt_vit_tune(value);

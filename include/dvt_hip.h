@@ -241,6 +241,7 @@ int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float*
  * key 1 = ViT bf16 GEMM variant (0: 256x128 3-stage when M % 256 == 0, 1: always 128x128 2-stage;
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
+ * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);
 
