@@ -354,8 +354,9 @@ __device__ __forceinline__ void stage_tile_512(const bf16_t* __restrict__ X, int
   }
 }
 
+// 512 threads, one workgroup per CU (144 KB LDS) = 2 waves per SIMD: allow the full 256-VGPR budget
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_kernel_256(GemmBArgs p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_256(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[3 * G2_STAGE];  // 144 KB, ONE LDS object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -369,11 +370,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_256(GemmBArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / GBK;
-#define G2_ISSUE(kt)                                                                            \
-  do {                                                                                          \
-    char* st_ = smem + ((kt) % 3) * G2_STAGE;                                                   \
-    stage_tile_512(p.A, p.K, m0, (kt) * GBK, st_, wave, lane, G2_BM);                           \
-    stage_tile_512(p.W, p.K, n0, (kt) * GBK, st_ + G2_BM * GBK * 2, wave, lane, GBN);           \
+  // per-thread DMA source pointers (4 for the 256-row A tile, 2 for the 128-row W tile) are
+  // computed once; a k-step only adds GBK elements (PMC: ~7 VALU instructions per MFMA before)
+  const bf16_t* srcA[4];
+  const bf16_t* srcW[2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s_ = it * 512 + tid, row = s_ >> 3, c = (s_ & 7) ^ (row & 7);
+    srcA[it] = p.A + (size_t)(m0 + row) * p.K + c * 8;
+    if (it < 2) srcW[it] = p.W + (size_t)(n0 + row) * p.K + c * 8;
+  }
+  const int ldsw = wave * 1024;  // this wave's 1-KB window inside each 8-KB pass
+#define G2_ISSUE(kt)                                                                  \
+  do {                                                                                \
+    char* st_ = smem + ((kt) % 3) * G2_STAGE + ldsw;                                  \
+    const int ko_ = (kt) * GBK;                                                       \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                  \
+        glds16(srcA[it] + ko_, st_ + it * 8192);                                      \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it)                                  \
+        glds16(srcW[it] + ko_, st_ + G2_BM * GBK * 2 + it * 8192);                    \
   } while (0)
   G2_ISSUE(0);
   if (nk > 1) G2_ISSUE(1);
@@ -389,20 +404,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel_256(GemmBArgs p) {
     if (kt + 2 < nk) G2_ISSUE(kt + 2);
     const char* As = smem + (kt % 3) * G2_STAGE;
     const char* Bs = As + G2_BM * GBK * 2;
+    // fragments of k-substep 1 are fetched while the 16 MFMAs of substep 0 issue (explicit
+    // double buffer: the compiler otherwise re-uses the registers and drains lgkmcnt(0) twice
+    // per substep)
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+    const int rowa = wm * 64 + (lane & 15), rowb = wn * 64 + (lane & 15), cg = lane >> 4;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
-      const int chunk = ks * 4 + (lane >> 4);
+    for (int i = 0; i < 4; ++i) a0[i] = read_frag(As, rowa + i * 16, cg);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = read_frag(As, wm * 64 + i * 16 + (lane & 15), chunk);
+    for (int j = 0; j < 4; ++j) b0[j] = read_frag(Bs, rowb + j * 16, cg);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = read_frag(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
+    for (int i = 0; i < 4; ++i) a1[i] = read_frag(As, rowa + i * 16, 4 + cg);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) b1[j] = read_frag(Bs, rowb + j * 16, 4 + cg);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
   }
 #undef G2_ISSUE
   __syncthreads();  // every wave is done with the operand stages: the buffers become epilogue space
@@ -630,7 +654,8 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f((m_run - m_new) * LOG2E);
+    // v_exp_f32 directly: arguments are <= 0, results in [0, 1]; a flushed denormal is an exact 0
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
     const float mb = m_new * LOG2E;
     float psum = 0.f;
     float pv[4][4];
@@ -638,7 +663,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pv[mt][r] = exp2f(s[mt][r] * LOG2E - mb);
+        pv[mt][r] = __builtin_amdgcn_exp2f(fmaf(s[mt][r], LOG2E, -mb));
         psum += pv[mt][r];
       }
     // B operand of O^T = V^T.P^T: k slot j = 4*(mt&1) + r of k-step ks = mt>>1
@@ -648,14 +673,16 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
     pf1.u[0] = pack2(pv[2][0], pv[2][1]); pf1.u[1] = pack2(pv[2][2], pv[2][3]);
     pf1.u[2] = pack2(pv[3][0], pv[3][1]); pf1.u[3] = pack2(pv[3][2], pv[3][3]);
     l_run = l_run * alpha + psum;
-    m_run = m_new;
+    if (!__all(m_new == m_run)) {  // wave-uniform: the running max rarely moves after the first tiles
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      o[i][0] *= alpha;
-      o[i][1] *= alpha;
-      o[i][2] *= alpha;
-      o[i][3] *= alpha;
+      for (int i = 0; i < 4; ++i) {
+        o[i][0] *= alpha;
+        o[i][1] *= alpha;
+        o[i][2] *= alpha;
+        o[i][3] *= alpha;
+      }
     }
+    m_run = m_new;
     // ---- O^T[d][q] += V^T . P^T : A rows = d (16*mt + lc), k slots <-> keys 32*ks + 16*(j>>2) + 4*g + (j&3)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
