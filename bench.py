@@ -28,6 +28,12 @@ for _p in (ROOT, os.path.join(ROOT, "denoising-vit_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+# HBM bytes per launch from PMC counters, collected in separate rocprofv3 --pmc passes
+# (profiles/r01_pmc/{fetch,write}.txt; tools/gpu_pmc.sh on a 128-view batch + 60 fit steps):
+# (FETCH_SIZE x 2 [gfx950 wide-load correction, MI355X_MICROARCH.md HBM section] + WRITE_SIZE)
+# x 1024 B / launches.  Calibration: layernorm reads 830.6 MB/launch = its algorithmic 830 MB.
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"vit_gemm": 2518.2e6, "vit_attn": 1107.7e6, "adam": 349.6e6,
+                                "fit_gemm": 25.9e6, "grid": None}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA
@@ -195,7 +201,8 @@ def main():
                     peak = MFMA_F32_PEAK_TF if n == "fit_gemm" else MFMA_BF16_PEAK_TF
                     kern[n] = {"bound": "mfma", "achieved": p["work"] / sec / 1e12, "peak": peak,
                                "unit": "TFLOP/s"}
-                kern[n].update(frac=kern[n]["achieved"] / kern[n]["peak"], traffic=None,
+                kern[n].update(frac=kern[n]["achieved"] / kern[n]["peak"],
+                               traffic=PMC_TRAFFIC_BYTES_PER_LAUNCH.get(n),
                                launches=p["launches"], avg_us=1e3 * p["total_ms"] / p["launches"],
                                ms_per_image=p["total_ms"] / images)
             return kern
