@@ -54,7 +54,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2(f, 0.f) 
 // GEMM  C[M,N] = A[M,K] . W[N,K]^T   (both operands K-contiguous bf16)
 // ======================================================================================
 constexpr int GBM = 128, GBN = 128, GBK = 64;
-int g_vit_gemm_variant = 0;  // 0: 256x128 3-stage when M % 256 == 0; 1: always 128x128 2-stage
+int g_vit_gemm_variant = 0;  // 0: 256x128 ping-pong when M % 256 == 0; 1: always 128x128 2-stage;
+                             // 2: 256x128 lock-step 3-stage
 constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
 
 enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4 };
@@ -433,6 +434,106 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, acc, m0, n0, wm, wn, wave, lane, smem);
 }
 
+// ---- ping-pong variant of the 256x128x64 kernel -------------------------------------------
+// PMC on the kernel above: MFMA pipe 26-33 % busy, waves 35 % in s_waitcnt/barrier -- the two waves
+// of a SIMD run in lock step behind the single barrier per k-tile, so both want the matrix pipe in
+// the same window and both leave it idle while they stage/read the next tile.  Here every k-tile
+// has a LOAD segment (issue the DMA of tile kt+2, read all fragments of tile kt into registers)
+// and a COMPUTE segment (32 MFMAs), each closed by a barrier, and waves 4-7 ("group B") execute
+// ONE extra barrier up front: for the whole loop group B is one segment behind group A, i.e. one
+// group's MFMAs run beside the other group's DMA issue + ds_reads (the 8-phase idea of the CDNA
+// guide, reduced to two phases).  Correctness of the hand-off: a wave waits for its own stage-
+// (kt+1) DMA (`vmcnt(6)`) and its fragment reads (`lgkmcnt(0)`) at the END of LOAD(kt), so by the
+// time any wave starts LOAD(kt+1) both groups have passed a barrier behind those waits; the DMA
+// into buffer (kt+2) % 3 is issued one barrier after the last read of tile kt-1 by either group.
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_pp(GemmBArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * G2_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool group_b = wave >= 4;
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / G2_BM, p.N / GBN, p.group);
+  const int m0 = tm.m * G2_BM, n0 = tm.n * GBN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GBK;
+  const bf16_t* srcA[4];
+  const bf16_t* srcW[2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s_ = it * 512 + tid, row = s_ >> 3, c = (s_ & 7) ^ (row & 7);
+    srcA[it] = p.A + (size_t)(m0 + row) * p.K + c * 8;
+    if (it < 2) srcW[it] = p.W + (size_t)(n0 + row) * p.K + c * 8;
+  }
+  const int ldsw = wave * 1024;
+#define PP_ISSUE(kt)                                                                  \
+  do {                                                                                \
+    char* st_ = smem + ((kt) % 3) * G2_STAGE + ldsw;                                  \
+    const int ko_ = (kt) * GBK;                                                       \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                  \
+        glds16(srcA[it] + ko_, st_ + it * 8192);                                      \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it)                                  \
+        glds16(srcW[it] + ko_, st_ + G2_BM * GBK * 2 + it * 8192);                    \
+  } while (0)
+  PP_ISSUE(0);
+  if (nk > 1) {
+    PP_ISSUE(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();           // tile 0 is in LDS for everybody
+  if (group_b) __builtin_amdgcn_s_barrier();  // group B: one segment behind from here on
+  const int rowa = wm * 64 + (lane & 15), rowb = wn * 64 + (lane & 15), cg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---------------- LOAD segment ----------------
+    if (kt + 2 < nk) PP_ISSUE(kt + 2);
+    const char* As = smem + (kt % 3) * G2_STAGE;
+    const char* Bs = As + G2_BM * GBK * 2;
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0[i] = read_frag(As, rowa + i * 16, cg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = read_frag(Bs, rowb + j * 16, cg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = read_frag(As, rowa + i * 16, 4 + cg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1[j] = read_frag(Bs, rowb + j * 16, 4 + cg);
+    if (kt + 2 < nk)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // own DMA of tile kt+1 has landed
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- COMPUTE segment ----------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef PP_ISSUE
+  if (!group_b) __builtin_amdgcn_s_barrier();  // group A: balance group B's extra barrier
+  __syncthreads();  // every wave is done with the operand stages: the buffers become epilogue space
+  gemm_epilogue_lds<EPI>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+}
+
 int g_vit_group_bytes = 2400 * 1024;  // W bytes kept L2-resident per group (tunable)
 
 template <int EPI>
@@ -449,7 +550,10 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
   if (a.M % G2_BM == 0 && g_vit_gemm_variant != 1) {
     const int tiles = (a.M / G2_BM) * (a.N / GBN);
-    hipLaunchKernelGGL((gemm_bf16_kernel_256<EPI>), dim3(tiles), dim3(512), 0, s, a);
+    if (g_vit_gemm_variant == 2)
+      hipLaunchKernelGGL((gemm_bf16_kernel_256<EPI>), dim3(tiles), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel_pp<EPI>), dim3(tiles), dim3(512), 0, s, a);
     DVT_CHECK_LAUNCH();
     return 0;
   }

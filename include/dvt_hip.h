@@ -238,7 +238,8 @@ int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float*
 
 /* Tuning knob (developer use): key 0 = fp32 GEMM tile configuration override
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
- * key 1 = ViT bf16 GEMM variant (0: 256x128 3-stage when M % 256 == 0, 1: always 128x128 2-stage;
+ * key 1 = ViT bf16 GEMM variant (0: 256x128 ping-pong when M % 256 == 0, 1: always 128x128 2-stage,
+ *         2: 256x128 lock-step 3-stage;
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
