@@ -54,8 +54,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2(f, 0.f) 
 // GEMM  C[M,N] = A[M,K] . W[N,K]^T   (both operands K-contiguous bf16)
 // ======================================================================================
 constexpr int GBM = 128, GBN = 128, GBK = 64;
-int g_vit_gemm_variant = 0;  // 0: 256x128 ping-pong when M % 256 == 0; 1: always 128x128 2-stage;
-                             // 2: 256x128 lock-step 3-stage
+int g_vit_gemm_variant = 0;  // 0: 256x256 when M, N % 256 == 0 (else 256x128 ping-pong); 1: always
+                             // 128x128 2-stage; 2: 256x128 lock-step 3-stage; 3: 256x128 ping-pong
 constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
 
 enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4 };
@@ -73,6 +73,7 @@ struct GemmBArgs {
   const float* cls;   // EPI_EMBED: cls token [N]
   int dim, heads, s_pad, n_tokens;
   int group;          // N tiles per L2-resident group (set by launch_gemm)
+  int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -534,12 +535,88 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, acc, m0, n0, wm, wn, wave, lane, smem);
 }
 
+// ---- 256x256x64 tile ("sq"): fewer operand bytes per flop -----------------------------------
+// Ping-pong scheduling of the 256x128 kernel bought only +5 %: the k-loop is INGEST-bound.  A CU
+// can keep ~100 KB of LDS-DMA in flight at ~2 us of loaded L2/MALL latency, i.e. ~16 B/clk, while
+// a 256x128 tile needs 48 KB per 64-deep k-step (M*N*K*2*(1/BM + 1/BN) = 9.96 GB per fc1 launch,
+// which IS its measured time).  A 256x256 tile needs 64 KB per k-step for twice the flops (-33 %
+// bytes/flop).  8 waves as 2 (M) x 4 (N), each 128x64 = 8x4 MFMA accumulators (128 VGPRs); two
+// 64-KB stages (prefetch distance 1, plain __syncthreads per k-tile -- the matrix pipe has slack
+// once ingest is the limit); epilogue through LDS in two 64-row halves per wave.
+constexpr int G4_STAGE = (256 + 256) * GBK * 2;  // 64 KB
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_sq(GemmBArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 2 stages (128 KB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / 256, p.N / 256, p.group);
+  const int m0 = tm.m * 256, n0 = tm.n * 256;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GBK;
+  const bf16_t* srcA[4];
+  const bf16_t* srcW[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s_ = it * 512 + tid, row = s_ >> 3, c = (s_ & 7) ^ (row & 7);
+    srcA[it] = p.A + (size_t)(m0 + row) * p.K + c * 8;
+    srcW[it] = p.W + (size_t)(n0 + row) * p.K + c * 8;
+  }
+  const int ldsw = wave * 1024;
+#define SQ_ISSUE(kt)                                                                  \
+  do {                                                                                \
+    char* st_ = smem + ((kt) & 1) * G4_STAGE + ldsw;                                  \
+    const int ko_ = (kt) * GBK;                                                       \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                  \
+        glds16(srcA[it] + ko_, st_ + it * 8192);                                      \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                  \
+        glds16(srcW[it] + ko_, st_ + 32768 + it * 8192);                              \
+  } while (0)
+  SQ_ISSUE(0);
+  __syncthreads();  // vmcnt(0) + barrier
+  const int rowa = wm * 128 + (lane & 15), rowb = wn * 64 + (lane & 15), cg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) SQ_ISSUE(kt + 1);
+    const char* As = smem + (kt & 1) * G4_STAGE;
+    const char* Bs = As + 32768;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[8], b[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = read_frag(As, rowa + i * 16, ks * 4 + cg);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = read_frag(Bs, rowb + j * 16, ks * 4 + cg);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next stage landed, everyone done reading this one
+  }
+#undef SQ_ISSUE
+  // epilogue: two 64-row halves through this wave's LDS block
+  f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
+  f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
+  gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own reads of the block are complete
+  gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
+}
+
 int g_vit_group_bytes = 2400 * 1024;  // W bytes kept L2-resident per group (tunable)
 
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   if (a0.M % GBM || a0.N % GBN || a0.K % GBK || a0.M <= 0) return DVT_E_BADARG;
   GemmBArgs a = a0;
+  a.dim_ok_sq = (EPI != EPI_QKV) || (a.dim % 256 == 0);
   {
     const int nt = a.N / GBN;
     int g = g_vit_group_bytes / (GBN * a.K * 2);
@@ -548,6 +625,16 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.group = g;
   }
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+  if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && g_vit_gemm_variant == 0) {
+    const int nt = a.N / 256;
+    int g = g_vit_group_bytes / (256 * a.K * 2);
+    g = g < 1 ? 1 : (g > nt ? nt : g);
+    while (g > 1 && nt % g) --g;
+    a.group = g;
+    hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+    DVT_CHECK_LAUNCH();
+    return 0;
+  }
   if (a.M % G2_BM == 0 && g_vit_gemm_variant != 1) {
     const int tiles = (a.M / G2_BM) * (a.N / GBN);
     if (g_vit_gemm_variant == 2)

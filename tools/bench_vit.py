@@ -18,8 +18,8 @@ with warnings.catch_warnings():
 x = torch.randn(256, 3, 518, 518, device=dev)
 out = torch.empty(256, 37, 37, 768, device=dev)
 L = _lib.lib()
-for kib in (0, 2, 0, 2):
-    L.dvt_tune_set(1, kib)  # GEMM variant: 0 = ping-pong, 2 = lock-step 3-stage
+for kib in (0, 3, 0, 3):
+    L.dvt_tune_set(1, kib)  # GEMM variant: 0 = 256x256, 3 = 256x128 ping-pong
     vit.features_nhwc(x, out=out)
     torch.cuda.synchronize()
     _lib.prof_enable(["vit_gemm", "vit_attn"])
