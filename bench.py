@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--views", type=int, default=768)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-probes", action="store_true")
+    p.add_argument("--tune", type=str, default="", help="developer knobs: key=value,... for dvt_tune_set")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="images in flight per GPU (1 = strictly serial reference flow)")
     return p.parse_args()
@@ -119,6 +120,9 @@ def main():
     from dvt_amd.utils import misc
 
     _lib.lib()
+    for kv in filter(None, a.tune.split(",")):
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().dvt_tune_set(int(k), int(v)), f"dvt_tune_set({k},{v})")
     misc.fix_random_seeds(rank)
     sa = stage1_args(a)
     with warnings.catch_warnings():

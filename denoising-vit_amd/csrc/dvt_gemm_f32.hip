@@ -45,9 +45,13 @@ struct GemmArgs {
   int atomic;  // accumulate into C with atomics
 };
 
-// Operand tile of R rows x BK: R*BK/4 float4, spread over NT threads.
-template <bool KCONTIG, int R, int NT>
+// Operand tile of R rows x BK: R*BK/4 float4, spread over NT threads.  BK is a template
+// parameter of the register-staged kernel: 64 by default, 16 (10 KB of LDS per workgroup) when
+// the fit shares the GPU with the ViT extractor, whose 136-144 KB workgroups leave only 16-24 KB
+// of a CU's LDS free (co-residency instead of waiting for CUs to drain).
+template <bool KCONTIG, int R, int NT, int BK>
 struct Tile {
+  static constexpr int LDK = BK + 4;
   static constexpr int NF4 = R * BK / 4;
   static constexpr int ITERS = (NF4 + NT - 1) / NT;
   static constexpr int LDS_FLOATS = KCONTIG ? R * LDK : BK * R;
@@ -113,11 +117,11 @@ struct Tile {
 };
 
 // WM x WN waves, each owning one 32x32 accumulator: tile (32*WM) x (32*WN).
-template <bool A_KC, bool B_KC, int WM, int WN>
+template <bool A_KC, bool B_KC, int WM, int WN, int BK>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
   constexpr int NT = 64 * WM * WN, BM = 32 * WM, BN = 32 * WN;
-  using TA = Tile<A_KC, BM, NT>;
-  using TB = Tile<B_KC, BN, NT>;
+  using TA = Tile<A_KC, BM, NT, BK>;
+  using TB = Tile<B_KC, BN, NT, BK>;
   __shared__ __attribute__((aligned(16))) float As[TA::LDS_FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[TB::LDS_FLOATS];
   const int tid = threadIdx.x;
@@ -340,29 +344,34 @@ int pick_cfg(int M, int N, int ksplits) {
   return 0;
 }
 
-template <bool A_KC, bool B_KC, int WM, int WN>
+int g_f32_bk = 64;  // k-depth of the register-staged kernel: 64, 32 or 16 (10 KB of LDS)
+
+template <bool A_KC, bool B_KC, int WM, int WN, int BKT>
 int launch_cfg(const GemmArgs& a, int ksplits, hipStream_t s) {
   dim3 grid(dvt_cdiv(a.N, 32 * WN), dvt_cdiv(a.M, 32 * WM), ksplits);
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
-  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a);
+  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, WM, WN, BKT>), grid, dim3(64 * WM * WN), 0, s, a);
   DVT_CHECK_LAUNCH();
   return 0;
 }
 
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
-  if (glds_ok<A_KC, B_KC>(a)) {
+  if (g_f32_bk == 64 && glds_ok<A_KC, B_KC>(a)) {
     dim3 grid(dvt_cdiv(a.N, 64), dvt_cdiv(a.M, 64), ksplits);
     DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
     hipLaunchKernelGGL((gemm_f32_glds_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
     DVT_CHECK_LAUNCH();
     return 0;
   }
-  switch (pick_cfg(a.M, a.N, ksplits)) {
-    case 0: return launch_cfg<A_KC, B_KC, 2, 2>(a, ksplits, s);
-    case 1: return launch_cfg<A_KC, B_KC, 1, 2>(a, ksplits, s);
-    case 3: return launch_cfg<A_KC, B_KC, 2, 1>(a, ksplits, s);
-    default: return launch_cfg<A_KC, B_KC, 1, 1>(a, ksplits, s);
+  const int cfg = pick_cfg(a.M, a.N, ksplits);
+  if (g_f32_bk == 16) return launch_cfg<A_KC, B_KC, 2, 2, 16>(a, ksplits, s);
+  if (g_f32_bk == 32) return launch_cfg<A_KC, B_KC, 2, 2, 32>(a, ksplits, s);
+  switch (cfg) {
+    case 0: return launch_cfg<A_KC, B_KC, 2, 2, 64>(a, ksplits, s);
+    case 1: return launch_cfg<A_KC, B_KC, 1, 2, 64>(a, ksplits, s);
+    case 3: return launch_cfg<A_KC, B_KC, 2, 1, 64>(a, ksplits, s);
+    default: return launch_cfg<A_KC, B_KC, 1, 1, 64>(a, ksplits, s);
   }
 }
 
@@ -375,6 +384,11 @@ extern "C" int dvt_tune_set(int key, int value) {
   }
   if (key == 4) {
     g_f32_glds = value;
+    return 0;
+  }
+  if (key == 5) {
+    if (value != 16 && value != 32 && value != 64) return DVT_E_BADARG;
+    g_f32_bk = value;
     return 0;
   }
   if (key == 1) return dvt_vit_tune(value);

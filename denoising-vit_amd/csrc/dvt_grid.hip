@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(DvtGridTable T, const flo
 //  * "direct levels" (fine, < 0.13 hits per entry): one lane per (sample, level, feature),
 //    global_atomic_add_f32, the 8 lanes of an entry hit one 32-B sector.
 // Both paths mark touched entries in the bitmap consumed by the fused Adam kernel.
-constexpr int LDS_CHUNK = 1024;  // entries per workgroup (32 KB of accumulators)
+constexpr int LDS_CHUNK_BIG = 1024;  // entries per workgroup (32 KB of accumulators)
+constexpr int LDS_CHUNK_SMALL = 256;  // 8 KB: co-resides with the ViT extractor's 136-144 KB workgroups
+int g_grid_lds_chunk = LDS_CHUNK_BIG;
 int g_grid_lds_level_max = 40960;  // entries; levels above go the direct-atomic way (tunable)
 // ds_add_f32 retires only ~1 lane per 2.75 cycles (measured: the single level-0 workgroup, 65 536
 // lane-atomics, took 86 us), so the samples of a coarse level are split over several workgroups,
@@ -157,6 +159,7 @@ struct GridBwdPlan {
   int splits[DVT_MAX_LEVELS];           // sample slices per chunk of that level
 };
 
+template <int LDS_CHUNK>
 __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdPlan plan,
                                                         const float2* __restrict__ xy,
                                                         const int32_t* __restrict__ ridx,
@@ -266,6 +269,7 @@ static void make_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan) {
   int l = 0;
   for (; l < T.n_levels; ++l) {
     if (T.entries[l] > (uint32_t)g_grid_lds_level_max) break;
+    const int LDS_CHUNK = g_grid_lds_chunk;
     const int chunks = (int)((T.entries[l] + LDS_CHUNK - 1) / LDS_CHUNK);
     // expected LDS lane-atomics per chunk workgroup = n * 4 corners * 8 features / chunks
     long long per_chunk = (long long)n * 32 / chunks;
@@ -280,7 +284,11 @@ static void make_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan) {
 }
 
 int dvt_grid_tune(int lds_level_max) {
-  if (lds_level_max < 0) {  // negative: set the per-block LDS atomics target instead
+  if (lds_level_max == -256 || lds_level_max == -1024) {  // chunk size selector
+    g_grid_lds_chunk = -lds_level_max;
+    return 0;
+  }
+  if (lds_level_max < 0) {  // other negatives: the per-block LDS atomics target
     g_grid_lds_atomics_per_block = -lds_level_max;
     return 0;
   }
@@ -332,8 +340,12 @@ int dvt_grid_bwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ri
   const int blocks = plan.n_lds_blocks + dvt_cdiv(threads, 1024);
   // algorithmic bytes: 32 B read + 4 corners x 32 B read-modify-write per (sample, level)
   DvtProbeScope probe(DVT_PROBE_GRID, stream, (double)n * tbl->n_levels * (32 + 4 * 64));
-  hipLaunchKernelGGL(grid_bwd_kernel, dim3(blocks), dim3(1024), 0, stream, *tbl, plan,
-                     (const float2*)xy, ridx, d_enc, d_params, touched, n);
+  if (g_grid_lds_chunk == LDS_CHUNK_SMALL)
+    hipLaunchKernelGGL(grid_bwd_kernel<LDS_CHUNK_SMALL>, dim3(blocks), dim3(1024), 0, stream, *tbl,
+                       plan, (const float2*)xy, ridx, d_enc, d_params, touched, n);
+  else
+    hipLaunchKernelGGL(grid_bwd_kernel<LDS_CHUNK_BIG>, dim3(blocks), dim3(1024), 0, stream, *tbl,
+                       plan, (const float2*)xy, ridx, d_enc, d_params, touched, n);
   DVT_CHECK_LAUNCH();
   return 0;
 }

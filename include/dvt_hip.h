@@ -242,6 +242,8 @@ int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float*
  *         2: 256x128 lock-step 3-stage;
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
+ * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
+ *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);
  * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);
