@@ -344,7 +344,11 @@ int pick_cfg(int M, int N, int ksplits) {
   return 0;
 }
 
-int g_f32_bk = 64;  // k-depth of the register-staged kernel: 64, 32 or 16 (10 KB of LDS)
+// k-depth of the register-staged kernel: 64, 32 or 16.  Default 32 (17 KB of LDS per workgroup):
+// in the pipelined driver the fit shares every CU with a 136-KB ViT GEMM workgroup, and a fit
+// kernel that does not fit beside it has to wait for CUs to drain (measured: 1.55 -> 1.72 images/s;
+// the serial fit time is unchanged, 0.345 s).  64 re-enables the 96-KB LDS-DMA kernel.
+int g_f32_bk = 32;
 
 template <bool A_KC, bool B_KC, int WM, int WN, int BKT>
 int launch_cfg(const GemmArgs& a, int ksplits, hipStream_t s) {

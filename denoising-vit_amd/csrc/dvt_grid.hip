@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(DvtGridTable T, const flo
 // Both paths mark touched entries in the bitmap consumed by the fused Adam kernel.
 constexpr int LDS_CHUNK_BIG = 1024;  // entries per workgroup (32 KB of accumulators)
 constexpr int LDS_CHUNK_SMALL = 256;  // 8 KB: co-resides with the ViT extractor's 136-144 KB workgroups
-int g_grid_lds_chunk = LDS_CHUNK_BIG;
+int g_grid_lds_chunk = LDS_CHUNK_SMALL;  // same reason as g_f32_bk in dvt_gemm_f32.hip
 int g_grid_lds_level_max = 40960;  // entries; levels above go the direct-atomic way (tunable)
 // ds_add_f32 retires only ~1 lane per 2.75 cycles (measured: the single level-0 workgroup, 65 536
 // lane-atomics, took 86 us), so the samples of a coarse level are split over several workgroups,
