@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--views", type=int, default=768)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-probes", action="store_true")
+    p.add_argument("--vit-cus-per-32", type=int, default=32,
+                   help="CUs (of every 32) the extractor stream may use; <32 keeps some free for the fit")
     p.add_argument("--tune", type=str, default="", help="developer knobs: key=value,... for dvt_tune_set")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="images in flight per GPU (1 = strictly serial reference flow)")
@@ -128,7 +130,7 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")  # random-init weights: there is no network for checkpoints
         vit = PretrainedViTWrapper(a.model, stride=14)
-    st = Stage1(sa, device, vit=vit, depth=a.pipeline_depth)
+    st = Stage1(sa, device, vit=vit, depth=a.pipeline_depth, vit_cus_per_32=a.vit_cus_per_32)
     for k, slot in enumerate(st.slots):  # inputs resident in HBM before the timed region
         views, coords = V.synthetic_views(a.views, sa.input_size, st.pos_h, st.pos_w, device,
                                           seed=100 * rank + k)

@@ -82,6 +82,23 @@ def work_list(args) -> list[str]:
     return names[args.start_idx: args.start_idx + args.num_imgs]
 
 
+def _cu_masked_stream(device, keep_per_32: int):
+    """A HIP stream whose kernels may only run on `keep_per_32` of every 32 CUs
+    (hipExtStreamCreateWithCUMask), wrapped for torch.  Leaves a few CUs permanently free of the
+    extractor's long-running workgroups so that the fit's short dependent launches start at once."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)(*([(1 << keep_per_32) - 1] * words))
+    stream = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(stream.value, device=device)
+
+
 class _Slot:
     """One image in flight: its views, coordinates, feature store and host output buffers."""
 
@@ -104,7 +121,8 @@ class Stage1:
     `s_vit` while the latency/HBM-bound fit of image i runs on the high-priority `s_fit`
     (`depth` slots of buffers; depth=1 reproduces the reference's strictly serial flow)."""
 
-    def __init__(self, args, device, vit: PretrainedViTWrapper | None = None, depth: int = 2):
+    def __init__(self, args, device, vit: PretrainedViTWrapper | None = None, depth: int = 2,
+                 vit_cus_per_32: int = 32):
         self.args, self.device = args, torch.device(device)
         self.vit = vit or PretrainedViTWrapper(args.model, stride=args.stride_size,
                                                checkpoint_path=getattr(args, "vit_checkpoint", None),
@@ -127,7 +145,8 @@ class Stage1:
         self.engine = FitEngine(s, n * self.pos_h * self.pos_w, dev)
         self.gen = torch.Generator(device=dev).manual_seed(args.seed)
         if len(self.slots) > 1:
-            self.s_vit = torch.cuda.Stream(device=dev)
+            self.s_vit = (torch.cuda.Stream(device=dev) if vit_cus_per_32 >= 32
+                          else _cu_masked_stream(dev, vit_cus_per_32))
             self.s_fit = torch.cuda.Stream(device=dev, priority=-1)
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
