@@ -17,4 +17,4 @@ for n,s,e,st in rows: bys[st].append((s,e))
 for st,iv in bys.items():
     print("stream",st,"kernels",len(iv),"busy ms",sum(e-s for s,e in iv)/1e6, "span ms",(max(e for s,e in iv)-min(s for s,e in iv))/1e6)
 PY
-rm -rf gpurun_out/prof_pipe
+python tools/gap_attrib.py gpurun_out/prof_pipe; rm -rf gpurun_out/prof_pipe
