@@ -54,3 +54,19 @@ struct DvtProbeScope {
 int dvt_vit_tune(int gemm_variant);
 int dvt_grid_tune(int lds_level_max);
 int dvt_adam_tune(int zero_all);
+
+// One linear-layer contraction for the grouped launch (dvt_gemm_f32.hip).
+struct DvtLinearOp {
+  int kind;  // 0: y = act(x.w^T + b); 1: dw += dy^T.x (+ db); 2: dx = dy.w (* relu_mask > 0)
+  const float* x;
+  const float* w;
+  const float* b;
+  const float* dy;
+  const float* relu_mask;
+  float* y;
+  float* dw;
+  float* db;
+  float* dx;
+  int m, n, k, relu;
+};
+int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s);

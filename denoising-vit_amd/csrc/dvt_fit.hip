@@ -146,31 +146,57 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
   // ---- forward ----
   DVT_TRY(dvt_gather_rows(b->feat, ridx, w.raw, B, C, 0, s));
   DVT_TRY(dvt_grid_fwd_idx(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, B, s));
-  DVT_TRY(dvt_linear_fwd(w.enc, P + c->off_w1, P + c->off_b1, w.h1, B, H, E, 1, s));
-  DVT_TRY(dvt_linear_fwd(w.h1, P + c->off_w2, P + c->off_b2, w.F, B, C, H, 0, s));
-  if (use_res) {
-    DVT_TRY(dvt_linear_fwd(w.raw, P + c->off_wh1, P + c->off_bh1, w.r1, B, R, C, 1, s));
-    DVT_TRY(dvt_linear_fwd(w.r1, P + c->off_wh2, P + c->off_bh2, w.r2, B, R, R, 1, s));
-    DVT_TRY(dvt_linear_fwd(w.r2, P + c->off_wh3, P + c->off_bh3, w.Hres, B, C, R, 0, s));
+  // Linear layers go out as GROUPED launches: independent GEMMs of the step (field branch and
+  // residual branch, weight- and data-gradient of one layer) share one grid.
+  auto fwd_op = [&](const float* x, int64_t ow, int64_t ob, float* y, int n, int k, int relu) {
+    DvtLinearOp o{};
+    o.kind = 0; o.x = x; o.w = P + ow; o.b = P + ob; o.y = y; o.m = B; o.n = n; o.k = k; o.relu = relu;
+    return o;
+  };
+  auto wgrad_op = [&](const float* dy, const float* x, int64_t ow, int64_t ob, int n, int k) {
+    DvtLinearOp o{};
+    o.kind = 1; o.dy = dy; o.x = x; o.dw = Gd + ow; o.db = Gd + ob; o.m = B; o.n = n; o.k = k;
+    return o;
+  };
+  auto dgrad_op = [&](const float* dy, int64_t ow, float* dx, const float* mask, int n, int k) {
+    DvtLinearOp o{};
+    o.kind = 2; o.dy = dy; o.w = P + ow; o.dx = dx; o.relu_mask = mask; o.m = B; o.n = n; o.k = k;
+    return o;
+  };
+  {
+    DvtLinearOp g1[2] = {fwd_op(w.enc, c->off_w1, c->off_b1, w.h1, H, E, 1),
+                         fwd_op(w.raw, c->off_wh1, c->off_bh1, w.r1, R, C, 1)};
+    DVT_TRY(dvt_linear_group(g1, use_res ? 2 : 1, s));
+    DvtLinearOp g2[2] = {fwd_op(w.h1, c->off_w2, c->off_b2, w.F, C, H, 0),
+                         fwd_op(w.r1, c->off_wh2, c->off_bh2, w.r2, R, R, 1)};
+    DVT_TRY(dvt_linear_group(g2, use_res ? 2 : 1, s));
+    if (use_res) {
+      DvtLinearOp g3[1] = {fwd_op(w.r2, c->off_wh3, c->off_bh3, w.Hres, C, R, 0)};
+      DVT_TRY(dvt_linear_group(g3, 1, s));
+    }
   }
   // ---- loss + d(pred), G gradient scattered in the same pass while G still trains ----
   DVT_TRY(dvt_loss_launch(w.F, P + c->off_G, ridx, c->lattice, use_res ? w.Hres : nullptr, w.raw,
                           w.dF, use_res ? w.dH : nullptr, phase2 ? nullptr : Gd + c->off_G, w.rows,
                           B, C, (float)c->grad_scale, s));
   if (log) DVT_TRY(dvt_loss_reduce(w.rows, b->losses + (size_t)step * 8, B, C, use_res, s));
-  // ---- backward: field MLP -> encoding -> hash grid ----
-  DVT_TRY(dvt_linear_bwd(w.dF, w.h1, P + c->off_w2, Gd + c->off_w2, Gd + c->off_b2, w.dh1, w.h1, B,
-                         C, H, s));
-  DVT_TRY(dvt_linear_bwd(w.dh1, w.enc, P + c->off_w1, Gd + c->off_w1, Gd + c->off_b1, w.denc,
-                         nullptr, B, H, E, s));
+  // ---- backward: {field layer 2, h layer 3}, {field layer 1, h layer 2}, hash grid, {h layer 1}
+  {
+    DvtLinearOp g4[4] = {dgrad_op(w.dF, c->off_w2, w.dh1, w.h1, C, H),
+                         wgrad_op(w.dF, w.h1, c->off_w2, c->off_b2, C, H),
+                         dgrad_op(w.dH, c->off_wh3, w.dr2, w.r2, C, R),
+                         wgrad_op(w.dH, w.r2, c->off_wh3, c->off_bh3, C, R)};
+    DVT_TRY(dvt_linear_group(g4, use_res ? 4 : 2, s));
+    DvtLinearOp g5[4] = {dgrad_op(w.dh1, c->off_w1, w.denc, nullptr, H, E),
+                         wgrad_op(w.dh1, w.enc, c->off_w1, c->off_b1, H, E),
+                         dgrad_op(w.dr2, c->off_wh2, w.dr1, w.r1, R, R),
+                         wgrad_op(w.dr2, w.r1, c->off_wh2, c->off_bh2, R, R)};
+    DVT_TRY(dvt_linear_group(g5, use_res ? 4 : 2, s));
+  }
   DVT_TRY(dvt_grid_bwd_idx(&c->grid, b->xy, ridx, w.denc, Gd + c->off_grid, b->touched, B, s));
   if (use_res) {
-    DVT_TRY(dvt_linear_bwd(w.dH, w.r2, P + c->off_wh3, Gd + c->off_wh3, Gd + c->off_bh3, w.dr2,
-                           w.r2, B, C, R, s));
-    DVT_TRY(dvt_linear_bwd(w.dr2, w.r1, P + c->off_wh2, Gd + c->off_wh2, Gd + c->off_bh2, w.dr1,
-                           w.r1, B, R, R, s));
-    DVT_TRY(dvt_linear_bwd(w.dr1, w.raw, P + c->off_wh1, Gd + c->off_wh1, Gd + c->off_bh1, nullptr,
-                           nullptr, B, R, C, s));
+    DvtLinearOp g6[1] = {wgrad_op(w.dr1, w.raw, c->off_wh1, c->off_bh1, R, C)};
+    DVT_TRY(dvt_linear_group(g6, 1, s));
   }
   // ---- Adam (dense) + zero_grad ----
   DvtAdamArgs a{};

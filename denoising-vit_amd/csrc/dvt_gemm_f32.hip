@@ -117,18 +117,18 @@ struct Tile {
 };
 
 // WM x WN waves, each owning one 32x32 accumulator: tile (32*WM) x (32*WN).
+// Body shared by the single-problem kernel and the grouped kernel (explicit block coordinates).
 template <bool A_KC, bool B_KC, int WM, int WN, int BK>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& p, int bx, int by, int bz,
+                                              float* __restrict__ As, float* __restrict__ Bs) {
   constexpr int NT = 64 * WM * WN, BM = 32 * WM, BN = 32 * WN;
   using TA = Tile<A_KC, BM, NT, BK>;
   using TB = Tile<B_KC, BN, NT, BK>;
-  __shared__ __attribute__((aligned(16))) float As[TA::LDS_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[TB::LDS_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int n0 = bx * BN, m0 = by * BM;
+  const int kbeg = bz * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   if (kbeg >= kend) return;
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float csum = 0.f;
-  const bool do_colsum = (!A_KC) && p.colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = (!A_KC) && p.colsum != nullptr && bx == 0;
 
   float4 ra[TA::ITERS], rb[TB::ITERS];
   TA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
@@ -185,6 +185,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
     }
   }
   if (do_colsum && tid < BM && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
+}
+
+template <bool A_KC, bool B_KC, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
+  constexpr int NT = 64 * WM * WN;
+  __shared__ __attribute__((aligned(16))) float As[Tile<A_KC, 32 * WM, NT, BK>::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[Tile<B_KC, 32 * WN, NT, BK>::LDS_FLOATS];
+  gemm_f32_body<A_KC, B_KC, WM, WN, BK>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// ---- grouped launch: up to 4 independent GEMMs in ONE grid -------------------------------------
+// At M = 2048 every GEMM of the fit fills only 96-430 workgroups and carries ~4.5 us of fixed
+// dependent-latency cost; kernels on different HIP streams did not overlap (measured: wgrad2 ||
+// dgrad2 on two streams = 59.8 us, the same as back to back).  Independent GEMMs of one step
+// (wgrad + dgrad of a layer, field branch + residual branch) are therefore packed into one
+// launch: a workgroup finds its problem from blockIdx.x, the operand layouts become a run-time
+// switch over the three instantiations of the same body.
+constexpr int MULTI_MAX = 4;
+struct MultiArgs {
+  int n;
+  int blk0[MULTI_MAX + 1];  // first block of each problem
+  int gx[MULTI_MAX], gy[MULTI_MAX];
+  int layout[MULTI_MAX];  // 0: A k-contig, B k-contig; 1: A k-contig, B row-contig; 2: both row-contig
+  GemmArgs g[MULTI_MAX];
+};
+
+template <int BK>
+__global__ __launch_bounds__(256) void gemm_f32_multi_kernel(MultiArgs m) {
+  __shared__ __attribute__((aligned(16))) float As[64 * (BK + 4)];  // >= BK * 64
+  __shared__ __attribute__((aligned(16))) float Bs[64 * (BK + 4)];
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < MULTI_MAX; ++j)
+    if (j < m.n && (int)blockIdx.x >= m.blk0[j]) i = j;
+  const int local = (int)blockIdx.x - m.blk0[i];
+  const int bx = local % m.gx[i], by = (local / m.gx[i]) % m.gy[i], bz = local / (m.gx[i] * m.gy[i]);
+  switch (m.layout[i]) {
+    case 0: gemm_f32_body<true, true, 2, 2, BK>(m.g[i], bx, by, bz, As, Bs); break;
+    case 1: gemm_f32_body<true, false, 2, 2, BK>(m.g[i], bx, by, bz, As, Bs); break;
+    default: gemm_f32_body<false, false, 2, 2, BK>(m.g[i], bx, by, bz, As, Bs); break;
+  }
 }
 
 // ==========================================================================================
@@ -379,8 +420,93 @@ int launch(const GemmArgs& a, int ksplits, hipStream_t s) {
   }
 }
 
+// ---- GemmArgs builders for the three contractions of a linear layer ----
+GemmArgs make_fwd(const float* x, const float* w, const float* b, float* y, int m, int n, int k,
+                  int relu) {
+  GemmArgs a{};
+  a.A = x; a.B = w; a.C = y;
+  a.M = m; a.N = n; a.K = k;
+  a.lda = k; a.ldb = k; a.ldc = n;
+  a.bias = b; a.relu = relu;
+  a.kchunk = (k + 63) / 64 * 64;
+  return a;
+}
+
+// dw[n,k] += sum_b dy[b,n] * x[b,k]; the batch reduction is split so that ~384 workgroups exist
+GemmArgs make_wgrad(const float* dy, const float* x, float* dw, float* db, int m, int n, int k,
+                    int* splits_out) {
+  GemmArgs a{};
+  a.A = dy; a.B = x; a.C = dw;
+  a.M = n; a.N = k; a.K = m;
+  a.lda = n; a.ldb = k; a.ldc = k;
+  a.colsum = db;
+  a.atomic = 1;
+  const int tiles = dvt_cdiv(n, 64) * dvt_cdiv(k, 64);
+  const int ktiles = dvt_cdiv(m, 64);
+  int splits = dvt_cdiv(384, tiles);  // every split costs one fp32 atomic per output element
+  if (splits > ktiles / 2) splits = ktiles / 2;
+  if (splits < 1) splits = 1;
+  a.kchunk = dvt_cdiv(ktiles, splits) * 64;
+  *splits_out = dvt_cdiv(m, a.kchunk);
+  return a;
+}
+
+GemmArgs make_dgrad(const float* dy, const float* w, float* dx, const float* relu_mask, int m,
+                    int n, int k) {
+  GemmArgs a{};
+  a.A = dy; a.B = w; a.C = dx;
+  a.M = m; a.N = k; a.K = n;
+  a.lda = n; a.ldb = k; a.ldc = k;
+  a.mask = relu_mask; a.ldmask = k;
+  a.kchunk = (n + 63) / 64 * 64;
+  return a;
+}
+
 }  // namespace
 
+int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s) {
+  if (!ops || n_ops < 1 || n_ops > MULTI_MAX) return DVT_E_BADARG;
+  MultiArgs m{};
+  m.n = n_ops;
+  int blocks = 0;
+  double flops = 0.0;
+  for (int i = 0; i < n_ops; ++i) {
+    const DvtLinearOp& o = ops[i];
+    if (o.m <= 0 || o.n <= 0 || o.k <= 0 || (o.n & 3) || (o.k & 3)) return DVT_E_BADARG;
+    int splits = 1;
+    if (o.kind == 0) {
+      m.g[i] = make_fwd(o.x, o.w, o.b, o.y, o.m, o.n, o.k, o.relu);
+      m.layout[i] = 0;
+    } else if (o.kind == 1) {
+      m.g[i] = make_wgrad(o.dy, o.x, o.dw, o.db, o.m, o.n, o.k, &splits);
+      m.layout[i] = 2;
+    } else if (o.kind == 2) {
+      m.g[i] = make_dgrad(o.dy, o.w, o.dx, o.relu_mask, o.m, o.n, o.k);
+      m.layout[i] = 1;
+    } else {
+      return DVT_E_BADARG;
+    }
+    m.gx[i] = dvt_cdiv(m.g[i].N, 64);
+    m.gy[i] = dvt_cdiv(m.g[i].M, 64);
+    m.blk0[i] = blocks;
+    blocks += m.gx[i] * m.gy[i] * splits;
+    flops += 2.0 * o.m * o.n * o.k;
+  }
+  m.blk0[n_ops] = blocks;
+  DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, flops);
+  if (g_f32_bk == 16)
+    hipLaunchKernelGGL(gemm_f32_multi_kernel<16>, dim3(blocks), dim3(256), 0, s, m);
+  else if (g_f32_bk == 32)
+    hipLaunchKernelGGL(gemm_f32_multi_kernel<32>, dim3(blocks), dim3(256), 0, s, m);
+  else
+    hipLaunchKernelGGL(gemm_f32_multi_kernel<64>, dim3(blocks), dim3(256), 0, s, m);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+namespace {
+extern int g_cfg_override;
+}
 extern "C" int dvt_tune_set(int key, int value) {
   if (key == 0) {
     g_cfg_override = value;
@@ -405,13 +531,7 @@ extern "C" int dvt_linear_fwd(const float* x, const float* w, const float* b, fl
                               int n, int k, int relu, void* stream) {
   if (!x || !w || !y || m < 0 || n <= 0 || k <= 0 || (k & 3) || (n & 3)) return DVT_E_BADARG;
   if (m == 0) return 0;
-  GemmArgs a{};
-  a.A = x; a.B = w; a.C = y;
-  a.M = m; a.N = n; a.K = k;
-  a.lda = k; a.ldb = k; a.ldc = n;
-  a.bias = b; a.relu = relu;
-  a.kchunk = (k + BK - 1) / BK * BK;
-  return launch<true, true>(a, 1, (hipStream_t)stream);
+  return launch<true, true>(make_fwd(x, w, b, y, m, n, k, relu), 1, (hipStream_t)stream);
 }
 
 extern "C" int dvt_linear_bwd(const float* dy, const float* x, const float* w, float* dw,
@@ -422,20 +542,8 @@ extern "C" int dvt_linear_bwd(const float* dy, const float* x, const float* w, f
   hipStream_t s = (hipStream_t)stream;
   if (dw != nullptr) {
     if (!x) return DVT_E_BADARG;
-    // dw[n,k] += sum_b dy[b,n] * x[b,k]; batch reduction split so that >= ~512 workgroups exist.
-    GemmArgs a{};
-    a.A = dy; a.B = x; a.C = dw;
-    a.M = n; a.N = k; a.K = m;
-    a.lda = n; a.ldb = k; a.ldc = k;
-    a.colsum = db;
-    a.atomic = 1;
-    const int tiles = dvt_cdiv(n, 64) * dvt_cdiv(k, 64);
-    const int ktiles = dvt_cdiv(m, BK);
-    int splits = dvt_cdiv(384, tiles);  // every split costs one fp32 atomic per output element
-    if (splits > ktiles / 2) splits = ktiles / 2;
-    if (splits < 1) splits = 1;
-    a.kchunk = dvt_cdiv(ktiles, splits) * BK;
-    splits = dvt_cdiv(m, a.kchunk);
+    int splits = 1;
+    const GemmArgs a = make_wgrad(dy, x, dw, db, m, n, k, &splits);
     int rc = launch<false, false>(a, splits, s);
     if (rc) return rc;
   } else if (db != nullptr) {
@@ -443,13 +551,7 @@ extern "C" int dvt_linear_bwd(const float* dy, const float* x, const float* w, f
   }
   if (dx != nullptr) {
     if (!w) return DVT_E_BADARG;
-    GemmArgs a{};
-    a.A = dy; a.B = w; a.C = dx;
-    a.M = m; a.N = k; a.K = n;
-    a.lda = n; a.ldb = k; a.ldc = k;
-    a.mask = relu_mask; a.ldmask = k;
-    a.kchunk = (n + BK - 1) / BK * BK;
-    int rc = launch<true, false>(a, 1, s);
+    int rc = launch<true, false>(make_dgrad(dy, w, dx, relu_mask, m, n, k), 1, s);
     if (rc) return rc;
   }
   return 0;
