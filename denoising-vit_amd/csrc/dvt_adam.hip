@@ -34,6 +34,9 @@ struct AdamKArgs {
   long long q_begin[DVT_ADAM_MAX_SEGS], q_end[DVT_ADAM_MAX_SEGS];
   float neg_step[DVT_ADAM_MAX_SEGS];  // -(lr / bias_correction1)
   float bc2s[DVT_ADAM_MAX_SEGS];      // sqrt(bias_correction2)
+  long long chunk0[DVT_ADAM_MAX_SEGS + 1];  // prefix sum of 256-float chunks over ACTIVE segments
+  int seg_of[DVT_ADAM_MAX_SEGS];            // active segment list
+  int n_active;
 };
 
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float wd,
@@ -46,20 +49,25 @@ __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, flo
   p = p + neg_step * (m / den);
 }
 
-// Each wave handles 64 consecutive float4 (256 floats, one bitmap word) per iteration.
+// Each wave handles 64 consecutive float4 (256 floats, one bitmap word) per iteration; all
+// active tensor groups (different step counts t) are covered by ONE launch.
 __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, float4* __restrict__ P,
                                                    float4* __restrict__ M, float4* __restrict__ V,
                                                    float4* __restrict__ G,
-                                                   uint32_t* __restrict__ touched, int seg,
-                                                   long long n_chunks) {
+                                                   uint32_t* __restrict__ touched) {
   const int lane = threadIdx.x & 63;
   const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long wave_stride = (long long)gridDim.x * 4;
   const float one_m_b1 = a.one_m_b1, one_m_b2 = a.one_m_b2;
-  const float neg_step = a.neg_step[seg], bc2s = a.bc2s[seg];
-  const long long qb = a.q_begin[seg];
+  const long long n_chunks = a.chunk0[a.n_active];
   for (long long ch = wave_global; ch < n_chunks; ch += wave_stride) {
-    const long long q0 = qb + ch * 64;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < DVT_ADAM_MAX_SEGS; ++j)
+      if (j < a.n_active && ch >= a.chunk0[j]) k = j;
+    const int seg = a.seg_of[k];
+    const float neg_step = a.neg_step[seg], bc2s = a.bc2s[seg];
+    const long long q0 = a.q_begin[seg] + (ch - a.chunk0[k]) * 64;
     const long long q = q0 + lane;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     bool has = true;
@@ -113,18 +121,27 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
     a.neg_step[s] = (float)(-(sg.lr / sg.bias_correction1));
     a.bc2s[s] = (float)sg.bias_correction2_sqrt;
   }
+  double work = 0.0;
+  a.n_active = 0;
+  a.chunk0[0] = 0;
   for (int s = 0; s < h->n_segs; ++s) {
     const DvtAdamSeg& sg = h->segs[s];
     if (!sg.active || sg.end == sg.begin) continue;
-    const long long n_chunks = (sg.end - sg.begin) / 256;
+    a.seg_of[a.n_active] = s;
+    a.chunk0[a.n_active + 1] = a.chunk0[a.n_active] + (sg.end - sg.begin) / 256;
+    ++a.n_active;
     // algorithmic bytes: p, m, v read + written once (24 B/param); dense-gradient part +8 B/param
     const double dense_floats = (double)(sg.end - (sg.begin > h->sparse_end ? sg.begin : (sg.end < h->sparse_end ? sg.end : h->sparse_end)));
-    DvtProbeScope probe(DVT_PROBE_ADAM, (hipStream_t)stream,
-                        24.0 * (double)(sg.end - sg.begin) + 8.0 * dense_floats);
-    long long blocks = (n_chunks + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    work += 24.0 * (double)(sg.end - sg.begin) + 8.0 * dense_floats;
+  }
+  if (a.n_active == 0) return 0;
+  const long long n_chunks = a.chunk0[a.n_active];
+  long long blocks = (n_chunks + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  {
+    DvtProbeScope probe(DVT_PROBE_ADAM, (hipStream_t)stream, work);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a,
-                       (float4*)p, (float4*)m, (float4*)v, (float4*)g, touched, s, n_chunks);
+                       (float4*)p, (float4*)m, (float4*)v, (float4*)g, touched);
     DVT_CHECK_LAUNCH();
   }
   return 0;

@@ -70,3 +70,5 @@ struct DvtLinearOp {
   int m, n, k, relu;
 };
 int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s);
+int dvt_fit_prep(const DvtGridTable* tbl, const float* xy, const int32_t* ridx, const float* params,
+                 float* enc, const float* feat, float* raw, int n, int c, hipStream_t stream);

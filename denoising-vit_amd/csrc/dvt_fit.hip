@@ -144,8 +144,7 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
                    ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
 
   // ---- forward ----
-  DVT_TRY(dvt_gather_rows(b->feat, ridx, w.raw, B, C, 0, s));
-  DVT_TRY(dvt_grid_fwd_idx(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, B, s));
+  DVT_TRY(dvt_fit_prep(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, b->feat, w.raw, B, C, s));
   // Linear layers go out as GROUPED launches: independent GEMMs of the step (field branch and
   // residual branch, weight- and data-gradient of one layer) share one grid.
   auto fwd_op = [&](const float* x, int64_t ow, int64_t ob, float* y, int n, int k, int relu) {

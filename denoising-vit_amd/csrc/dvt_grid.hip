@@ -350,6 +350,62 @@ int dvt_grid_bwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ri
   return 0;
 }
 
+// Fused step prologue of the fit: raw-row gather (one wave per row) and hash-grid forward in ONE
+// launch (blocks [0, gather_blocks) gather, the rest encode) -- two fewer dependent launches.
+__global__ __launch_bounds__(256) void fit_prep_kernel(DvtGridTable T, const float2* __restrict__ xy,
+                                                       const int32_t* __restrict__ ridx,
+                                                       const float4* __restrict__ params,
+                                                       float4* __restrict__ enc,
+                                                       const float4* __restrict__ feat,
+                                                       float4* __restrict__ raw, int n, int cq,
+                                                       int gather_blocks) {
+  if ((int)blockIdx.x < gather_blocks) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float4* s = feat + (size_t)ridx[row] * cq;
+    float4* d = raw + (size_t)row * cq;
+    for (int q = lane; q < cq; q += 64) d[q] = s[q];
+    return;
+  }
+  const int L = T.n_levels;
+  const int t = (blockIdx.x - gather_blocks) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  const int b = t / L, l = t - b * L;
+  const float2 p = xy[ridx[b]];
+  uint32_t idx[4];
+  float w[4];
+  corners2d(T, l, p.x, p.y, idx, w);
+  float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 a = params[(size_t)idx[c] * 2], bq = params[(size_t)idx[c] * 2 + 1];
+    lo.x = fmaf(w[c], a.x, lo.x);
+    lo.y = fmaf(w[c], a.y, lo.y);
+    lo.z = fmaf(w[c], a.z, lo.z);
+    lo.w = fmaf(w[c], a.w, lo.w);
+    hi.x = fmaf(w[c], bq.x, hi.x);
+    hi.y = fmaf(w[c], bq.y, hi.y);
+    hi.z = fmaf(w[c], bq.z, hi.z);
+    hi.w = fmaf(w[c], bq.w, hi.w);
+  }
+  enc[(size_t)t * 2] = lo;
+  enc[(size_t)t * 2 + 1] = hi;
+}
+
+int dvt_fit_prep(const DvtGridTable* tbl, const float* xy, const int32_t* ridx, const float* params,
+                 float* enc, const float* feat, float* raw, int n, int c, hipStream_t stream) {
+  if (!tbl || !xy || !ridx || !params || !enc || !feat || !raw || n <= 0 || (c & 3)) return DVT_E_BADARG;
+  const int gather_blocks = dvt_cdiv(n, 4);
+  const long long threads = (long long)n * tbl->n_levels;
+  DvtProbeScope probe(DVT_PROBE_GRID, stream, (double)threads * (4 * 32 + 32));
+  hipLaunchKernelGGL(fit_prep_kernel, dim3(gather_blocks + dvt_cdiv(threads, 256)), dim3(256), 0,
+                     stream, *tbl, (const float2*)xy, ridx, (const float4*)params, (float4*)enc,
+                     (const float4*)feat, (float4*)raw, n, c / 4, gather_blocks);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int dvt_grid_fwd(const DvtGridTable* tbl, const float* xy, const float* params,
                             float* enc, int n, void* stream) {
   return dvt_grid_fwd_idx(tbl, xy, nullptr, params, enc, n, (hipStream_t)stream);
