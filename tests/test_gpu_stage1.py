@@ -1,0 +1,99 @@
+"""GPU: the stage-1 driver end to end (reference main_img_denoising.py flow) on a real image
+file: CLI flags, view synthesis + coordinates, extractor, pipelined fit, output layout
+(`raw_features/<model>/...npy` [H,W,C], `denoised_features/...npy` [1,H,W,C]), resume."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_image(path, h=300, w=400):
+    from PIL import Image
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 / w), (yy * 255 / h), ((xx // 20 + yy // 20) % 2) * 200], -1).astype(np.uint8)
+    Image.fromarray(img).save(path)
+
+
+def test_stage1_driver_end_to_end(built_lib, tmp_path, capsys):
+    from dvt_amd import stage1
+    data_root = tmp_path / "data"
+    (data_root / "sub").mkdir(parents=True)
+    for name in ("sub/a.png", "b.png"):
+        _make_image(str(data_root / name))
+    lst = tmp_path / "list.txt"
+    lst.write_text("sub/a.png\nb.png extra-token\n")
+    argv = ["--img_path", str(lst), "--data_root", str(data_root), "--save_root", str(tmp_path / "out"),
+            "--output_dir", str(tmp_path / "work"), "--num_views", "63", "--num_iters", "60",
+            "--warmup_iters", "6", "--pixel_bsz", "512", "--num_imgs", "10"]
+    args = stage1.get_args(argv)
+    assert args.input_size == (518, 518) and args.n_levels == 16 and args.model.startswith("vit_base")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # random ViT weights (no checkpoint offline)
+        done = stage1.main(args)
+    assert done == 2
+    model = "vit_base_patch14_dinov2.lvd142m"
+    for rel in ("sub/a.npy", "b.npy"):
+        raw = np.load(tmp_path / "out" / "raw_features" / model / rel)
+        den = np.load(tmp_path / "out" / "denoised_features" / model / rel)
+        assert raw.shape == (37, 37, 768) and raw.dtype == np.float32
+        assert den.shape == (1, 37, 37, 768) and den.dtype == np.float32  # stage-2 loader squeezes it
+        assert np.isfinite(raw).all() and np.isfinite(den).all()
+        assert np.abs(den).max() > 0
+    # resume: both outputs exist -> skipped (misc.check_if_file_exists)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert stage1.main(args) == 0
+    assert "Skipping" in capsys.readouterr().out
+
+
+def test_views_match_torch_reference_semantics(built_lib):
+    """render_views: crop + bicubic-antialias resize + flip on the device; the last view is the
+    untouched image; flipped views are mirror images of the unflipped crop."""
+    from dvt_amd import views as V
+    dev = torch.device("cuda")
+    img = torch.randn(3, 518, 518, device=dev)
+    boxes = np.array([[10, 20, 200, 260, 0], [10, 20, 200, 260, 1], [0, 0, 518, 518, 0]])
+    out = torch.empty(3, 3, 518, 518, device=dev)
+    V.render_views(img, boxes, out)
+    assert torch.equal(out[2], img)
+    assert torch.equal(out[1], out[0].flip(-1))
+    ref = torch.nn.functional.interpolate(img[None, :, 10:210, 20:280], size=(518, 518), mode="bicubic",
+                                          antialias=True, align_corners=False)[0]
+    assert torch.allclose(out[0], ref)
+
+
+def test_vit_large_geometry(built_lib):
+    """BASELINE configs[2]: DINOv2 ViT-L/14 (dim 1024, 16 heads) through the same kernels;
+    2 blocks of random well-conditioned weights against the fp32 oracle."""
+    from dvt_amd.vit import HipViT, random_state_dict
+    from oracle import vit as ovit
+    sd = random_state_dict(1024, 2, 14, 1370, seed=7, well_conditioned=True)
+    x = torch.randn(2, 3, 518, 518, generator=torch.Generator().manual_seed(2))
+    want = ovit.forward_features(sd, x, 14, 14)
+    got = HipViT(sd, 14, 14, (518, 518), "cuda").forward_features(x.cuda()).cpu()
+    cos = torch.nn.functional.cosine_similarity(got.reshape(-1, 1024), want.reshape(-1, 1024), dim=-1)
+    print(f"ViT-L/14 geometry: cos mean {cos.mean():.6f} min {cos.min():.6f}")
+    assert got.shape == (2, 37, 37, 1024) and cos.min() > 0.999
+
+
+def test_fit_large_feature_dim(built_lib):
+    """ViT-L feature width (C = 1024: MLP 128->512->1024, h 1024->256->256->1024) through the
+    fused loop: finite, decreasing loss, invariants."""
+    from dvt_amd.fit import FitEngine, FitSettings
+    from tests.test_gpu_fit import synthetic_image
+    V_, H, W, C = 6, 37, 37, 1024
+    feats, xy = synthetic_image(V_, H, W, C, seed=4)
+    s = FitSettings(feat_dim=C, num_iters=30, warmup_iters=3)
+    eng = FitEngine(s, V_ * H * W, "cuda")
+    eng.reset(torch.Generator(device="cuda").manual_seed(0))
+    np.random.seed(0)
+    eng.fit(feats.reshape(-1, C).cuda(), xy.reshape(-1, 2).cuda(), None, log_every=1)
+    torch.cuda.synchronize()
+    log = eng.loss_log()
+    assert len(log) == 30 and log[29]["patch_l2_loss"] < log[0]["patch_l2_loss"]
+    assert float(eng.grads.abs().max()) == 0.0
+    assert eng.infer(xy[-1].cuda()).shape == (37, 37, 1024)
