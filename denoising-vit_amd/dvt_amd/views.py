@@ -11,9 +11,9 @@ dvt/dataset/single_image_dataset.py:12-51.
   top-left; otherwise the central crop clamped to the ratio range.
   coords (transform.py:55-66): linspace(i/H, (i+h)/H, h_patches) x linspace(j/W, (j+w)/W,
   w_patches) -- the crop EDGES, (x, y) order; flip mirrors x (transform.py:69-73).
-The crops themselves are resized with bicubic + antialias (transform.py:50-52); here that is
-`torch.nn.functional.interpolate(mode="bicubic", antialias=True)` on the device (an on-GPU
-hand-written resampler is SURVEY.md's next row N1).
+The crops themselves are resized with bicubic + antialias (transform.py:50-52) by the hand-written
+HIP resampler `dvt_render_views` (csrc/dvt_views.hip): all 769 views of an image in one launch,
+on the device, instead of 768 PIL resizes in 8 DataLoader worker processes.
 """
 from __future__ import annotations
 
@@ -90,17 +90,22 @@ def sample_view_boxes(num_views: int, size, h_patches: int, w_patches: int,
 
 
 @torch.no_grad()
-def render_views(image: torch.Tensor, boxes: np.ndarray, out: torch.Tensor, chunk: int = 64) -> None:
-    """image [3, H, W] (normalised, on the device) -> out [V+1, 3, H, W]: resized crops
-    (bicubic, antialias) and flips; the last box is the identity."""
+def render_views(image: torch.Tensor, boxes: np.ndarray, out: torch.Tensor) -> None:
+    """image [3, H, W] (normalised, on the device) -> out [V, 3, OH, OW]: resized crops (bicubic,
+    antialias) and flips, one HIP launch; a full-image box with OH x OW == H x W is the identity."""
+    from . import _lib
+    _lib.require_cuda(image, out)
+    image = image.contiguous().float()
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[1] != 3:
+        raise _lib.DvtError("out must be a contiguous fp32 [V, 3, OH, OW] tensor")
     H, W = image.shape[1:]
-    for v, (i, j, h, w, flip) in enumerate(boxes.tolist()):
-        if (i, j, h, w) == (0, 0, H, W):
-            view = image
-        else:
-            view = F.interpolate(image[None, :, i:i + h, j:j + w], size=(H, W), mode="bicubic",
-                                 antialias=True, align_corners=False)[0]
-        out[v] = view.flip(-1) if flip else view
+    b = np.ascontiguousarray(boxes, dtype=np.int32)
+    if (b[:, 0] < 0).any() or (b[:, 1] < 0).any() or (b[:, 0] + b[:, 2] > H).any() or (b[:, 1] + b[:, 3] > W).any():
+        raise _lib.DvtError("crop box outside the image")
+    dbox = torch.from_numpy(b).to(image.device)
+    V_, _, OH, OW = out.shape
+    _lib.check(_lib.lib().dvt_render_views(image.data_ptr(), H, W, dbox.data_ptr(), out.data_ptr(),
+                                           min(V_, len(b)), OH, OW, _lib.stream()), "dvt_render_views")
 
 
 def load_image(path: str, size, mean, std, device) -> torch.Tensor:
@@ -110,8 +115,14 @@ def load_image(path: str, size, mean, std, device) -> torch.Tensor:
 
     Image.MAX_IMAGE_PIXELS = None
     img = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
-    x = torch.from_numpy(img).to(device).permute(2, 0, 1).float() / 255.0
-    x = F.interpolate(x[None], size=tuple(size), mode="bicubic", antialias=True, align_corners=False)[0]
+    x = (torch.from_numpy(img).to(device).permute(2, 0, 1).float() / 255.0).contiguous()
+    h, w = x.shape[1:]
+    if h / size[0] <= 3.5 and w / size[1] <= 3.5:
+        base = torch.empty((1, 3, size[0], size[1]), device=device)
+        render_views(x, np.array([[0, 0, h, w, 0]]), base)  # base resize on the HIP resampler
+        x = base[0]
+    else:  # very large photos: beyond the kernel's 16-tap window
+        x = F.interpolate(x[None], size=tuple(size), mode="bicubic", antialias=True, align_corners=False)[0]
     m = torch.tensor(mean, device=device).view(3, 1, 1)
     s = torch.tensor(std, device=device).view(3, 1, 1)
     return (x - m) / s

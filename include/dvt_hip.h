@@ -236,6 +236,16 @@ int dvt_fit_run_multi(int k, const DvtFitConfig* const* h_cfgs, const DvtFitBuff
 int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float* xy, float* out,
                     float* workspace, int n, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * View synthesis (dvt/dataset/transform.py:48-52, :70; single_image_dataset.py:33-38)
+ * ---------------------------------------------------------------------------------- */
+/* out[v, 3, OH, OW] = hflip?(resize_bicubic_antialias(img[3, top:top+h, left:left+w] -> OH x OW)) for
+ * boxes[v] = {top, left, h, w, flip} (int32, device).  The box must lie inside the H x W image and
+ * h / OH, w / OW <= 3.5 (16 filter taps).  Semantics of torch/torchvision's anti-aliased bicubic
+ * (a = -0.5, align_corners = False, windows truncated at the crop border). */
+int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float* out, int V, int OH,
+                     int OW, void* stream);
+
 /* Tuning knob (developer use): key 0 = fp32 GEMM tile configuration override
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
  * key 1 = ViT bf16 GEMM variant (0: 256x128 ping-pong when M % 256 == 0, 1: always 128x128 2-stage,

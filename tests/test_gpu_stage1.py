@@ -50,20 +50,35 @@ def test_stage1_driver_end_to_end(built_lib, tmp_path, capsys):
     assert "Skipping" in capsys.readouterr().out
 
 
-def test_views_match_torch_reference_semantics(built_lib):
-    """render_views: crop + bicubic-antialias resize + flip on the device; the last view is the
-    untouched image; flipped views are mirror images of the unflipped crop."""
+def test_render_views_vs_torch_antialias_bicubic(built_lib):
+    """dvt_render_views against torch.nn.functional.interpolate(mode="bicubic", antialias=True) (the
+    op SURVEY.md 8c names as the oracle for transform.py:50-52): up-sampled random crops, border
+    crops, flips, the identity box and a down-scaling base resize."""
     from dvt_amd import views as V
+    import torch.nn.functional as F
     dev = torch.device("cuda")
-    img = torch.randn(3, 518, 518, device=dev)
-    boxes = np.array([[10, 20, 200, 260, 0], [10, 20, 200, 260, 1], [0, 0, 518, 518, 0]])
-    out = torch.empty(3, 3, 518, 518, device=dev)
-    V.render_views(img, boxes, out)
-    assert torch.equal(out[2], img)
-    assert torch.equal(out[1], out[0].flip(-1))
-    ref = torch.nn.functional.interpolate(img[None, :, 10:210, 20:280], size=(518, 518), mode="bicubic",
-                                          antialias=True, align_corners=False)[0]
-    assert torch.allclose(out[0], ref)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(3, 518, 518, generator=g)
+    rng = np.random.RandomState(1)
+    boxes, _ = V.sample_view_boxes(40, (518, 518), 37, 37, rng)
+    boxes = np.concatenate([boxes, [[0, 0, 200, 260, 1], [318, 258, 200, 260, 0], [100, 0, 418, 518, 1]]])
+    out = torch.empty(len(boxes), 3, 518, 518, device=dev)
+    V.render_views(img.to(dev), boxes, out)
+    got = out.cpu()
+    for v, (i, j, h, w, flip) in enumerate(boxes.tolist()):
+        ref = F.interpolate(img[None, :, i:i + h, j:j + w], size=(518, 518), mode="bicubic",
+                            antialias=True, align_corners=False)[0]
+        if flip:
+            ref = ref.flip(-1)
+        err = float((got[v] - ref).abs().max())
+        assert err < 2e-5, (v, (i, j, h, w, flip), err)
+    assert float((got[40] - img).abs().max()) < 1e-6  # the full-image box is the identity
+    # base resize with down-scaling (single_image_dataset.py:33-38): 900x700 -> 518x518
+    big = torch.randn(3, 900, 700, generator=g)
+    o2 = torch.empty(1, 3, 518, 518, device=dev)
+    V.render_views(big.to(dev), np.array([[0, 0, 900, 700, 0]]), o2)
+    ref = F.interpolate(big[None], size=(518, 518), mode="bicubic", antialias=True, align_corners=False)[0]
+    assert float((o2[0].cpu() - ref).abs().max()) < 2e-5
 
 
 def test_vit_large_geometry(built_lib):
