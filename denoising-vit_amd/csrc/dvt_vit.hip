@@ -74,6 +74,7 @@ struct GemmBArgs {
   int dim, heads, s_pad, n_tokens;
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
+  int dbg;
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -610,6 +611,180 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
 }
 
+
+// ---- 256x256x64 tile, 8-phase schedule ("8p") ------------------------------------------------
+// The `sq` kernel above drains its LDS-DMA queue at a __syncthreads per k-tile, so every k-tile
+// costs one loaded L2 latency (~1.7 us against 0.85 us of MFMA work).  Here the 64-KB k-tile is
+// split into four 16-KB HALF-TILES (A0, A1, B0, B1: 128 operand rows x 64 k each) that are
+// consumed and re-staged one per phase, so four half-tiles (64 KB per CU) are in flight at ALL
+// times and nothing ever waits for vmcnt(0):
+//   half h of A holds rows m0 + (r>>6)*128 + h*64 + (r&63), half h of W rows n0 + (r>>5)*64 +
+//   h*32 + (r&31) (r = local row): wave (wm, wn) still owns the contiguous 128 x 64 output block.
+//   phase   ds_read (-> regs)   MFMA quadrant     LDS-DMA issued        s_waitcnt (end of L)
+//   P1(t)   B0(t), A0(t)        (A0, B0)          B1(t+1)               vmcnt(8)  [B1(t) landed]
+//   P2(t)   B1(t)               (A0, B1)          A1(t+1)               vmcnt(8)  [A1(t)]
+//   P3(t)   A1(t)               (A1, B1)          A0(t+2)               --
+//   P4(t)   --                  (A1, B0)          B0(t+2)               vmcnt(8)  [A0, B0 (t+1)]
+// Every phase is {L: ds_reads + DMA issue + counted wait} barrier {M: 16 MFMAs} barrier; the
+// waves with wm == 1 run half a phase behind (one extra barrier up front), so on each SIMD one
+// wave is in its MFMA segment while the other one issues loads.  Hazards:
+//   WAR  a half-tile is re-staged two phases after the phase that read it: all reads of phase p
+//        (both groups) have retired at the second barrier of phase p.
+//   RAW  a half-tile is read one phase after the phase whose L segment waited for it: the waits
+//        of both groups precede the second barrier of that phase.
+template <int MODE>  // 0 steady state, 1 tile nk-2 (no issue in P3/P4), 2 tile nk-1 (no issue)
+struct P8Wait;
+template <> struct P8Wait<0> { static constexpr int w1 = 8, w2 = 8, w4 = 8; };
+template <> struct P8Wait<1> { static constexpr int w1 = 8, w2 = 8, w4 = 4; };
+template <> struct P8Wait<2> { static constexpr int w1 = 2, w2 = 0, w4 = -1; };
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#define P8_BAR()                         \
+  do {                                   \
+    __builtin_amdgcn_sched_barrier(0);   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+#define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// 16 MFMAs: 4 m-frags x 2 n-frags x 2 k-steps; dependent pairs are 8 issues apart
+#define P8_MFMA(IB, JB, AF, BF)                                                                   \
+  do {                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+        acc[IB + i][JB + j] =                                                                     \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][ks], BF[j][ks], acc[IB + i][JB + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                \
+  } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / 256, p.N / 256, p.group);
+  const int m0 = tm.m * 256, n0 = tm.n * 256;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GBK;
+  // DMA sources: [half][pass]; one pass = 512 threads x 16 B = 64 rows of a half-tile
+  const bf16_t* srcA[2][2];
+  const bf16_t* srcB[2][2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s_ = it * 512 + tid, r = s_ >> 3, c = (s_ & 7) ^ (r & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m0s = p.dbg == 1 ? 0 : m0, n0s = p.dbg == 1 ? 0 : n0;
+      srcA[h][it] = p.A + (size_t)(m0s + (r >> 6) * 128 + h * 64 + (r & 63)) * p.K + c * 8;
+      srcB[h][it] = p.W + (size_t)(n0s + (r >> 5) * 64 + h * 32 + (r & 31)) * p.K + c * 8;
+    }
+  }
+  constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
+  char* const ldsw = smem + wave * 1024;
+#define P8_STAGE(SRC, kt, off)                                   \
+  do { if (p.dbg != 2) {                                         \
+    glds16(SRC[0] + (size_t)(kt) * GBK, ldsw + (off));           \
+    glds16(SRC[1] + (size_t)(kt) * GBK, ldsw + (off) + 8192);    \
+  } } while (0)
+  // fragment read offsets inside a half-tile: row*128 + ((ks*4 + cg) ^ (row & 7))*16
+  const int cg = lane >> 4;
+  const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
+  const int oa0 = ra * 128 + (((0 + cg) ^ (ra & 7)) << 4), oa1 = ra * 128 + (((4 + cg) ^ (ra & 7)) << 4);
+  const int ob0 = rb * 128 + (((0 + cg) ^ (rb & 7)) << 4), ob1 = rb * 128 + (((4 + cg) ^ (rb & 7)) << 4);
+#define P8_RD(base, off) (*reinterpret_cast<const bf16x8*>((base) + (off)))
+
+  // prologue: A0 B0 B1 A1 of tile 0, A0 B0 of tile 1 -- the order the steady state continues
+  P8_STAGE(srcA[0], 0, OFF_A0);
+  P8_STAGE(srcB[0], 0, OFF_B0);
+  P8_STAGE(srcB[1], 0, OFF_B1);
+  P8_STAGE(srcA[1], 0, OFF_A1);
+  P8_STAGE(srcA[0], 1, BUF + OFF_A0);
+  P8_STAGE(srcB[0], 1, BUF + OFF_B0);
+  wait_vm<8>();
+  P8_BAR();
+  if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on
+
+  bf16x8 a[4][2], b0[2][2], b1[2][2];
+#define P8_TILE(MODE, t)                                                                          \
+  do {                                                                                            \
+    const int bo_ = ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                                             \
+    const char* base_ = smem + bo_;                                                               \
+    /* P1 */                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+      b0[j][0] = P8_RD(base_ + OFF_B0 + j * 2048, ob0);                                           \
+      b0[j][1] = P8_RD(base_ + OFF_B0 + j * 2048, ob1);                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      a[i][0] = P8_RD(base_ + OFF_A0 + i * 2048, oa0);                                            \
+      a[i][1] = P8_RD(base_ + OFF_A0 + i * 2048, oa1);                                            \
+    }                                                                                             \
+    if (MODE <= 1) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                                      \
+    wait_vm<P8Wait<MODE>::w1>();                                                                  \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(0, 0, a, b0);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P2 */                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+      b1[j][0] = P8_RD(base_ + OFF_B1 + j * 2048, ob0);                                           \
+      b1[j][1] = P8_RD(base_ + OFF_B1 + j * 2048, ob1);                                           \
+    }                                                                                             \
+    if (MODE <= 1) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                                      \
+    wait_vm<P8Wait<MODE>::w2>();                                                                  \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(0, 2, a, b1);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P3 */                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      a[i][0] = P8_RD(base_ + OFF_A1 + i * 2048, oa0);                                            \
+      a[i][1] = P8_RD(base_ + OFF_A1 + i * 2048, oa1);                                            \
+    }                                                                                             \
+    if (MODE == 0) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                                      \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(4, 2, a, b1);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P4 */                                                                                      \
+    if (MODE == 0) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                                      \
+    wait_vm<P8Wait<MODE>::w4>();                                                                  \
+    P8_BAR();                                                                                     \
+    P8_MFMA(4, 0, a, b0);                                                                         \
+    P8_BAR();                                                                                     \
+  } while (0)
+
+  int t = 0;
+  for (; t < nk - 2; ++t) P8_TILE(0, t);
+  P8_TILE(1, t);
+  ++t;
+  P8_TILE(2, t);
+#undef P8_TILE
+#undef P8_STAGE
+#undef P8_RD
+  if (wm == 0) P8_BAR();  // balance group 1's extra barrier
+  __syncthreads();        // operand buffers become epilogue space
+  f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
+  f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
+  gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
+}
+
 int g_vit_group_bytes = 2400 * 1024;  // W bytes kept L2-resident per group (tunable)
 
 template <int EPI>
@@ -625,13 +800,18 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.group = g;
   }
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
-  if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && g_vit_gemm_variant == 0) {
+  if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK &&
+      (g_vit_gemm_variant == 0 || g_vit_gemm_variant >= 4)) {
+    a.dbg = g_vit_gemm_variant - 4;
     const int nt = a.N / 256;
     int g = g_vit_group_bytes / (256 * a.K * 2);
     g = g < 1 ? 1 : (g > nt ? nt : g);
     while (g > 1 && nt % g) --g;
     a.group = g;
-    hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+    if (g_vit_gemm_variant >= 4)
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     DVT_CHECK_LAUNCH();
     return 0;
   }
