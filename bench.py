@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--vit-cus-per-32", type=int, default=32,
                    help="CUs (of every 32) the extractor stream may use; <32 keeps some free for the fit")
     p.add_argument("--tune", type=str, default="", help="developer knobs: key=value,... for dvt_tune_set")
+    p.add_argument("--pixel-bsz", type=int, default=2048,
+                   help="developer experiment only: anything but 2048 is not BASELINE's workload")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="images in flight per GPU (1 = strictly serial reference flow)")
     return p.parse_args()
@@ -63,7 +65,7 @@ def stage1_args(a):
         model=a.model, input_size=(518, 518), stride_size=14, layer_depth_ratio=1.0,
         num_views=a.views, num_iters=a.num_iters, warmup_iters=a.warmup_iters, n_levels=16,
         freeze_shared_artifacts_after=0.5, lr=0.01, min_lr=0.001, weight_decay=1e-5,
-        extract_bsz=32, pixel_bsz=2048, seed=0, vit_checkpoint=None)
+        extract_bsz=32, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None)
 
 
 def cpu_baseline(a):
@@ -186,7 +188,7 @@ def main():
                 "workload": "BASELINE configs[1]: DINOv2 ViT-B/14 518x518, 768 views + original, "
                             "1k-step per-image fit (B=2048, L=16, F=8, 2^20 hash) on 1 MI355X per rank",
                 "model": a.model, "views": a.views + 1, "num_iters": a.num_iters,
-                "warmup_iters": a.warmup_iters, "pixel_bsz": 2048,
+                "warmup_iters": a.warmup_iters, "pixel_bsz": a.pixel_bsz,
                 "arithmetic": "ViT: bf16 MFMA / fp32 accumulate; fit: fp32 (f32-input MFMA, fp32 Adam)",
                 "weights": "random init (no network for checkpoints)",
                 "t_extract_s_serial": t_ext / a.steps, "t_fit_s_serial": t_fit / a.steps,

@@ -54,8 +54,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2(f, 0.f) 
 // GEMM  C[M,N] = A[M,K] . W[N,K]^T   (both operands K-contiguous bf16)
 // ======================================================================================
 constexpr int GBM = 128, GBN = 128, GBK = 64;
-int g_vit_gemm_variant = 0;  // 0: 256x256 when M, N % 256 == 0 (else 256x128 ping-pong); 1: always
-                             // 128x128 2-stage; 2: 256x128 lock-step 3-stage; 3: 256x128 ping-pong
+int g_vit_dbg_pad = 0;
+// GEMM schedule (dvt_tune_set(1, v)); when M or N is not a multiple of 256 the 256x256 variants
+// fall back to 3.  4 (default): 256x256 8-phase half-tile ring; 0: 256x256 two-stage;
+// 1: always 128x128 two-stage; 2: 256x128 lock-step three-stage; 3: 256x128 ping-pong.
+// 5 / 6 are timing experiments of variant 4 that compute WRONG results (5: every tile reads the
+// operands of tile (0, 0) = all loads L2-hot; 6: no operand loads at all).
+int g_vit_gemm_variant = 4;
 constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
 
 enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4 };
@@ -75,6 +80,7 @@ struct GemmBArgs {
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int dbg;
+  int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -130,6 +136,22 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, in
   return t;
 }
 
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU(), timm Mlp) = max(x, 0) - 0.5 |x| E(|x|), where
+// E(|x|) = erfc(|x| / sqrt 2) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
+// rounding of the output): one v_rcp_f32 + one v_exp_f32 + 9 FMAs instead of libm erff's ~45
+// instructions (the fc1 epilogue was +27 % on top of the GEMM).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+  float q = fmaf(t, 1.061405429f, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  q *= t;
+  const float e = __builtin_amdgcn_exp2f(ax * ax * (-0.5f * 1.4426950408889634f));
+  return fmaf(-0.5f * ax, q * e, fmaxf(x, 0.f));
+}
+
 // Fused epilogues.  acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*(lane>>4) + r][n0 + wn*64 + j*16 + (lane&15)]
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4][4], int m0, int n0,
@@ -176,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4
       } else {
         if (EPI == EPI_GELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
         const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
         // pair adjacent columns across lanes (l, l^1): even lanes store rows r=0,1 of the
@@ -315,15 +337,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
       float4 a = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8);
       float4 b = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8 + 4);
       if (EPI == EPI_GELU) {
-        const float k = 0.70710678118654752f;
-        a.x = 0.5f * a.x * (1.0f + erff(a.x * k));
-        a.y = 0.5f * a.y * (1.0f + erff(a.y * k));
-        a.z = 0.5f * a.z * (1.0f + erff(a.z * k));
-        a.w = 0.5f * a.w * (1.0f + erff(a.w * k));
-        b.x = 0.5f * b.x * (1.0f + erff(b.x * k));
-        b.y = 0.5f * b.y * (1.0f + erff(b.y * k));
-        b.z = 0.5f * b.z * (1.0f + erff(b.z * k));
-        b.w = 0.5f * b.w * (1.0f + erff(b.w * k));
+        a.x = gelu_erf(a.x);
+        a.y = gelu_erf(a.y);
+        a.z = gelu_erf(a.z);
+        a.w = gelu_erf(a.w);
+        b.x = gelu_erf(b.x);
+        b.y = gelu_erf(b.y);
+        b.z = gelu_erf(b.z);
+        b.w = gelu_erf(b.w);
       }
       uint4 pk;
       pk.x = pack2(a.x, a.y);
@@ -333,6 +354,76 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
       *reinterpret_cast<uint4*>(p.out + (size_t)(mb + row) * ldo + nb + c8) = pk;
     }
   }
+}
+
+// EPI_RESID epilogue of the 256x256 kernels: x[m, n] += gamma[n] * (acc + bias[n]) on a wave's
+// 128 x 64 block.  The fp32 residual stream is a read-modify-write of 8 B per element (1.1 GB per
+// launch); with the loads issued four at a time inside the row loop a tile's epilogue took 4 x 2
+// rounds of memory latency -- longer than the whole K = 768 k-loop.  Here all 16 float4 rows of a
+// 64-row half are requested up front (64 VGPRs; the k-loop's fragment registers are dead), and the
+// second half's requests go out as soon as the first half's accumulators are parked in LDS.
+__device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4 (&acc)[8][4], int mb,
+                                                       int nb, int wave, int lane, char* smem) {
+  const int g = lane >> 4, lc = lane & 15, c4 = lc * 4;
+  float* blk = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
+  // buffer addressing: one resource (SGPRs) based at the block, ONE 32-bit lane offset and a
+  // scalar row offset per access -- 32 rows of 64-bit global addresses would cost 64 VGPRs
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      p.x + (size_t)mb * p.N + nb, 0, 0x7fffffff, 0x00020000);
+  const int loff = (g * p.N + c4) * 4;
+  const int rstep = p.N * 16;  // bytes per 4 rows
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+#define RS_LD(it) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, loff, (it) * rstep, 0))
+// Stores put the row offset into the VGPR offset (soffset = literal 0): with an SGPR soffset the
+// compiler assumes there is no ">64-bit store data overwritten by the next VALU" hazard and emits
+// no wait state, but gfx950 showed exactly that corruption (lanes 12-15 of each 16, one dword).
+#define RS_ST(it, v) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), xr, loff + (it) * rstep, 0, 0)
+  float4 xl[16], xh[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) xl[it] = RS_LD(it);
+  float bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = p.bias != nullptr ? p.bias[nb + j * 16 + lc] : 0.f;
+  const float4 gm = *reinterpret_cast<const float4*>(p.gamma + nb + c4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[(i * 16 + 4 * g + r) * EP_LD + j * 16 + lc] = acc[i][j][r] + bias[j];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) xh[it] = RS_LD(16 + it);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const float4 v = *reinterpret_cast<const float4*>(blk + (it * 4 + g) * EP_LD + c4);
+    float4 o = xl[it];
+    o.x += gm.x * v.x;
+    o.y += gm.y * v.y;
+    o.z += gm.z * v.z;
+    o.w += gm.w * v.w;
+    RS_ST(it, o);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own reads of the block are complete
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[(i * 16 + 4 * g + r) * EP_LD + j * 16 + lc] = acc[4 + i][j][r] + bias[j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const float4 v = *reinterpret_cast<const float4*>(blk + (it * 4 + g) * EP_LD + c4);
+    float4 o = xh[it];
+    o.x += gm.x * v.x;
+    o.y += gm.y * v.y;
+    o.z += gm.z * v.z;
+    o.w += gm.w * v.w;
+    RS_ST(16 + it, o);
+  }
+#undef RS_LD
+#undef RS_ST
 }
 
 // ---- 256x128x64 tile, 8 waves (4 x 2, 64x64 each), 3 LDS stages, counted vmcnt -------------
@@ -604,6 +695,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 #undef SQ_ISSUE
   // epilogue: two 64-row halves through this wave's LDS block
+  if constexpr (EPI == EPI_RESID) {
+    gemm_epilogue_resid_sq(p, acc, m0 + wm * 128, n0 + wn * 64, wave, lane, smem);
+    return;
+  }
   f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
   f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
   gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
@@ -617,7 +712,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // costs one loaded L2 latency (~1.7 us against 0.85 us of MFMA work).  Here the 64-KB k-tile is
 // split into four 16-KB HALF-TILES (A0, A1, B0, B1: 128 operand rows x 64 k each) that are
 // consumed and re-staged one per phase, so four half-tiles (64 KB per CU) are in flight at ALL
-// times and nothing ever waits for vmcnt(0):
+// times and nothing ever waits for vmcnt(0).  (A ten-slot ring over the whole 160-KB LDS with six
+// half-tiles in flight measured the same rate -- the k-loop is not bytes-in-flight bound -- and
+// would evict the co-resident fit kernels, so the ring stays at eight slots.)
 //   half h of A holds rows m0 + (r>>6)*128 + h*64 + (r&63), half h of W rows n0 + (r>>5)*64 +
 //   h*32 + (r&31) (r = local row): wave (wm, wn) still owns the contiguous 128 x 64 output block.
 //   phase   ds_read (-> regs)   MFMA quadrant     LDS-DMA issued        s_waitcnt (end of L)
@@ -690,8 +787,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int m0s = p.dbg == 1 ? 0 : m0, n0s = p.dbg == 1 ? 0 : n0;
-      srcA[h][it] = p.A + (size_t)(m0s + (r >> 6) * 128 + h * 64 + (r & 63)) * p.K + c * 8;
-      srcB[h][it] = p.W + (size_t)(n0s + (r >> 5) * 64 + h * 32 + (r & 31)) * p.K + c * 8;
+      srcA[h][it] = p.A + (size_t)(m0s + (r >> 6) * 128 + h * 64 + (r & 63)) * p.lda + c * 8;
+      srcB[h][it] = p.W + (size_t)(n0s + (r >> 5) * 64 + h * 32 + (r & 31)) * p.ldw + c * 8;
     }
   }
   constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
@@ -778,6 +875,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef P8_RD
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
   __syncthreads();        // operand buffers become epilogue space
+  if constexpr (EPI == EPI_RESID) {
+    gemm_epilogue_resid_sq(p, acc, m0 + wm * 128, n0 + wn * 64, wave, lane, smem);
+    return;
+  }
   f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
   f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
   gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
@@ -791,6 +892,8 @@ template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   if (a0.M % GBM || a0.N % GBN || a0.K % GBK || a0.M <= 0) return DVT_E_BADARG;
   GemmBArgs a = a0;
+  if (!a.lda) a.lda = a.K;
+  if (!a.ldw) a.ldw = a.K;
   a.dim_ok_sq = (EPI != EPI_QKV) || (a.dim % 256 == 0);
   {
     const int nt = a.N / GBN;
@@ -802,10 +905,13 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
   if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK &&
       (g_vit_gemm_variant == 0 || g_vit_gemm_variant >= 4)) {
-    a.dbg = g_vit_gemm_variant - 4;
+    a.dbg = g_vit_gemm_variant >= 4 ? g_vit_gemm_variant - 4 : 0;
     const int nt = a.N / 256;
+    // N tiles per group: W slices of a group stay L2-resident, but never fewer than 3 tiles share
+    // an A panel (K = 3072: one tile per group re-read A three times from HBM, 1.03 -> 1.23 PF/s)
     int g = g_vit_group_bytes / (256 * a.K * 2);
-    g = g < 1 ? 1 : (g > nt ? nt : g);
+    g = g < 3 ? 3 : g;
+    g = g > nt ? nt : g;
     while (g > 1 && nt % g) --g;
     a.group = g;
     if (g_vit_gemm_variant >= 4)
@@ -1130,6 +1236,10 @@ int dvt_vit_tune(int v) {
     g_vit_group_bytes = v * 1024;
     return 0;
   }
+  if (v < 0) {  // experiment: leading-dimension pad (elements) of dvt_vit_gemm_bias operands
+    g_vit_dbg_pad = -v - 1;
+    return 0;
+  }
   g_vit_gemm_variant = v;
   return 0;
 }
@@ -1176,7 +1286,17 @@ extern "C" int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, v
   GemmBArgs a{};
   a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
   a.bias = b; a.out = (bf16_t*)y;
+  a.lda = a.ldw = k + g_vit_dbg_pad;
   return launch_gemm<EPI_BIAS>(a, (hipStream_t)stream);
+}
+
+extern "C" int dvt_vit_gemm_residual(const void* a_in, const void* w, const float* b, const float* gamma,
+                                     float* x, int m, int n, int k, void* stream) {
+  if (!a_in || !w || !gamma || !x) return DVT_E_BADARG;
+  GemmBArgs a{};
+  a.A = (const bf16_t*)a_in; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
+  a.bias = b; a.x = x; a.gamma = gamma;
+  return launch_gemm<EPI_RESID>(a, (hipStream_t)stream);
 }
 
 extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows,

@@ -82,6 +82,10 @@ int dvt_vit_forward(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const f
 /* y[m, n] (bf16) = x[m, k] (bf16) . w[n, k]^T (bf16) + b[n]; m % 128 == n % 128 == k % 64 == 0 */
 int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, void* y, int m, int n, int k,
                       void* stream);
+/* x[m, n] (fp32, in place) += gamma[n] * (a[m, k] (bf16) . w[n, k]^T (bf16) + b[n]): the attention-proj /
+ * fc2 GEMM with the LayerScale + residual epilogue (timm Block.forward: x = x + ls(f(norm(x)))) */
+int dvt_vit_gemm_residual(const void* a, const void* w, const float* b, const float* gamma, float* x,
+                          int m, int n, int k, void* stream);
 /* y (bf16) [rows, dim] = LayerNorm(x fp32 [rows, dim]) * w + b */
 int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int dim,
                       float eps, void* stream);

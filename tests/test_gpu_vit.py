@@ -57,6 +57,48 @@ def test_gemm_bias_vs_torch(L, m, n, k):
     assert rel(y.float(), want) < 6e-3, (m, n, k)
 
 
+@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (2816, 768, 768), (1408, 768, 3072), (256, 384, 192)])
+def test_gemm_residual_vs_torch(L, m, n, k, variant):
+    """x += gamma * (a @ w^T + b) (LayerScale + residual epilogue) on every GEMM schedule: 0 = 256x256
+    two-stage, 4 = 256x256 8-phase ring, 3 = 256x128 ping-pong.  Every element is checked: the
+    epilogue once lost single dwords of a 16-byte store to a VGPR-overwrite hazard."""
+    torch.manual_seed(m + n + k)
+    a = torch.randn(m, k).bfloat16()
+    w = (torch.randn(n, k) / k ** 0.5).bfloat16()
+    b, gm, x0 = torch.randn(n), torch.randn(n), torch.randn(m, n)
+    want = x0 + gm * (a.float() @ w.float().t() + b)
+    x = x0.to(DEV).contiguous()
+    assert L.dvt_tune_set(1, variant) == 0
+    try:
+        assert L.dvt_vit_gemm_residual(P(a), P(w), P(b), P(gm), x.data_ptr(), m, n, k, _s()) == 0
+        torch.cuda.synchronize()
+    finally:
+        L.dvt_tune_set(1, 4)
+    err = (x.cpu() - want).abs()
+    assert float(err.max()) < 2e-3 * float(want.abs().max()), (variant, (m, n, k), float(err.max()))
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+def test_gemm_bias_variants(L, variant):
+    """the non-default GEMM schedules against torch on the four ViT-B shapes (one M panel pair each)"""
+    for n, k in [(2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 640)]:
+        torch.manual_seed(n + k)
+        m = 512
+        x = torch.randn(m, k).bfloat16()
+        w = (torch.randn(n, k) / k ** 0.5).bfloat16()
+        b = torch.randn(n)
+        want = x.float() @ w.float().t() + b
+        y = torch.empty((m, n), device=DEV, dtype=torch.bfloat16)
+        assert L.dvt_tune_set(1, variant) == 0
+        try:
+            assert L.dvt_vit_gemm_bias(P(x), P(w), P(b), y.data_ptr(), m, n, k, _s()) == 0
+            torch.cuda.synchronize()
+        finally:
+            L.dvt_tune_set(1, 4)
+        assert rel(y.float(), want) < 6e-3, (variant, n, k)
+
+
 def test_gemm_rejects_unaligned(L):
     assert L.dvt_vit_gemm_bias(1, 1, None, 1, 100, 128, 64, None) == -1
     assert L.dvt_vit_gemm_bias(1, 1, None, 1, 128, 128, 32, None) == -1

@@ -18,8 +18,8 @@ with warnings.catch_warnings():
 x = torch.randn(256, 3, 518, 518, device=dev)
 out = torch.empty(256, 37, 37, 768, device=dev)
 L = _lib.lib()
-for kib in (0, 3, 0, 3):
-    L.dvt_tune_set(1, kib)  # GEMM variant: 0 = 256x256, 3 = 256x128 ping-pong
+for kib in (0, 4, 0, 4):
+    L.dvt_tune_set(1, kib)  # GEMM variant: 0 = 256x256 2-stage, 4 = 256x256 8-phase
     vit.features_nhwc(x, out=out)
     torch.cuda.synchronize()
     _lib.prof_enable(["vit_gemm", "vit_attn"])
@@ -32,4 +32,4 @@ for kib in (0, 3, 0, 3):
     print(f"gemm variant {kib}: 256 views {t*1e3:7.1f} ms ({t/256*769*1e3:6.1f} ms per 769 views); "
           f"gemm {g['total_ms']:6.1f} ms {g['work']/g['total_ms']/1e9:6.1f} TF/s; attn {a['total_ms']:6.1f} ms "
           f"{a['work']/a['total_ms']/1e9:6.1f} TF/s", flush=True)
-L.dvt_tune_set(1, 0)
+L.dvt_tune_set(1, 4)
