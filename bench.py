@@ -53,6 +53,10 @@ def parse():
     p.add_argument("--vit-cus-per-32", type=int, default=32,
                    help="CUs (of every 32) the extractor stream may use; <32 keeps some free for the fit")
     p.add_argument("--tune", type=str, default="", help="developer knobs: key=value,... for dvt_tune_set")
+    p.add_argument("--fit-batch", type=int, default=1,
+                   help="images whose fits share launches (dvt_fit_run_batched); 1 = one fit at a time "
+                        "(measured: 1.94 / 1.93 / 1.87 images/s at 1 / 2 / 4 -- the step is throughput-, "
+                        "not launch-latency-bound)")
     p.add_argument("--pixel-bsz", type=int, default=2048,
                    help="developer experiment only: anything but 2048 is not BASELINE's workload")
     p.add_argument("--pipeline-depth", type=int, default=2,
@@ -132,7 +136,8 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")  # random-init weights: there is no network for checkpoints
         vit = PretrainedViTWrapper(a.model, stride=14)
-    st = Stage1(sa, device, vit=vit, depth=a.pipeline_depth, vit_cus_per_32=a.vit_cus_per_32)
+    st = Stage1(sa, device, vit=vit, depth=a.pipeline_depth, vit_cus_per_32=a.vit_cus_per_32,
+                fit_batch=a.fit_batch)
     for k, slot in enumerate(st.slots):  # inputs resident in HBM before the timed region
         views, coords = V.synthetic_views(a.views, sa.input_size, st.pos_h, st.pos_w, device,
                                           seed=100 * rank + k)
@@ -192,7 +197,7 @@ def main():
                 "arithmetic": "ViT: bf16 MFMA / fp32 accumulate; fit: fp32 (f32-input MFMA, fp32 Adam)",
                 "weights": "random init (no network for checkpoints)",
                 "t_extract_s_serial": t_ext / a.steps, "t_fit_s_serial": t_fit / a.steps,
-                "pipeline_depth": a.pipeline_depth,
+                "pipeline_depth": a.pipeline_depth, "fit_batch": a.fit_batch,
                 "images_per_rank": a.steps, "parallelism": f"images sharded over {world} GPU(s), no collective",
             },
         }

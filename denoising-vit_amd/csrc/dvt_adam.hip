@@ -51,10 +51,20 @@ __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, flo
 
 // Each wave handles 64 consecutive float4 (256 floats, one bitmap word) per iteration; all
 // active tensor groups (different step counts t) are covered by ONE launch.
-__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, float4* __restrict__ P,
-                                                   float4* __restrict__ M, float4* __restrict__ V,
-                                                   float4* __restrict__ G,
-                                                   uint32_t* __restrict__ touched) {
+struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
+  float4* P[DVT_FIT_BATCH_MAX];
+  float4* M[DVT_FIT_BATCH_MAX];
+  float4* V[DVT_FIT_BATCH_MAX];
+  float4* G[DVT_FIT_BATCH_MAX];
+  uint32_t* touched[DVT_FIT_BATCH_MAX];
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q) {
+  float4* __restrict__ P = q.P[blockIdx.y];
+  float4* __restrict__ M = q.M[blockIdx.y];
+  float4* __restrict__ V = q.V[blockIdx.y];
+  float4* __restrict__ G = q.G[blockIdx.y];
+  uint32_t* __restrict__ touched = q.touched[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long wave_stride = (long long)gridDim.x * 4;
@@ -100,9 +110,23 @@ int dvt_adam_tune(int zero_all) {
 
 extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v, float* g,
                              uint32_t* touched, void* stream) {
-  if (!h || !p || !m || !v || !g || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
+  return dvt_adam_step_k(h, 1, &p, &m, &v, &g, &touched, (hipStream_t)stream);
+}
+
+int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
+                    float* const* g, uint32_t* const* touched, hipStream_t stream) {
+  if (!h || k < 1 || k > DVT_FIT_BATCH_MAX || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
     return DVT_E_BADARG;
-  if ((h->sparse_end & 255) || (h->sparse_end > 0 && !touched)) return DVT_E_BADARG;
+  if (h->sparse_end & 255) return DVT_E_BADARG;
+  AdamPtrs q{};
+  for (int f = 0; f < k; ++f) {
+    if (!p[f] || !m[f] || !v[f] || !g[f] || (h->sparse_end > 0 && !touched[f])) return DVT_E_BADARG;
+    q.P[f] = (float4*)p[f];
+    q.M[f] = (float4*)m[f];
+    q.V[f] = (float4*)v[f];
+    q.G[f] = (float4*)g[f];
+    q.touched[f] = touched[f];
+  }
   AdamKArgs a{};
   a.zero_all = g_adam_zero_all;
   // torch narrows the python doubles (1 - beta1), beta2, (1 - beta2), eps, wd to fp32 scalars
@@ -139,9 +163,8 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
   long long blocks = (n_chunks + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   {
-    DvtProbeScope probe(DVT_PROBE_ADAM, (hipStream_t)stream, work);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a,
-                       (float4*)p, (float4*)m, (float4*)v, (float4*)g, touched);
+    DvtProbeScope probe(DVT_PROBE_ADAM, stream, work * k);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q);
     DVT_CHECK_LAUNCH();
   }
   return 0;

@@ -35,6 +35,23 @@ int dvt_loss_launch(const float* F, const float* G, const int32_t* g_idx, int la
                     const float* Hres, const float* raw_rows, float* d_pred, float* d_hres,
                     float* d_G, float* row_sums, int n, int c, float grad_scale, hipStream_t s);
 
+// ---- batched fits: k images advanced by the SAME launches (blockIdx.y = fit) ----
+// The per-image fit is a chain of ~10 small dependent launches per Adam step; each launch pays a
+// fixed dependent-launch latency (and, next to the extractor, a wait for free CU slots) that does
+// not grow when its grid covers several images.  The k fits share one configuration.
+int dvt_fit_prep_k(const DvtGridTable* tbl, int k, const float* const* xy, const int32_t* const* ridx,
+                   const float* const* params, float* const* enc, const float* const* feat,
+                   float* const* raw, int n, int c, hipStream_t stream);
+int dvt_grid_bwd_k(const DvtGridTable* tbl, int k, const float* const* xy, const int32_t* const* ridx,
+                   const float* const* d_enc, float* const* d_params, uint32_t* const* touched, int n,
+                   hipStream_t stream);
+int dvt_loss_launch_k(int k, const float* const* F, const float* const* G, const int32_t* const* g_idx,
+                      int lattice, const float* const* Hres, const float* const* raw_rows,
+                      float* const* d_pred, float* const* d_hres, float* const* d_G,
+                      float* const* row_sums, int n, int c, float grad_scale, hipStream_t s);
+int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
+                    float* const* g, uint32_t* const* touched, hipStream_t stream);
+
 // ---- profiling probes (dvt_prof.hip) ----
 extern unsigned g_dvt_prof_mask;
 void dvt_prof_begin(int probe, hipStream_t s);

@@ -131,71 +131,136 @@ int check_bufs(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin, in
   return 0;
 }
 
-// One Adam step of one image's fit, enqueued on stream s.
-int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int step, hipStream_t s) {
+// One Adam step of k images' fits (same configuration, same step), enqueued on stream s: every
+// launch covers all k fits (blockIdx.y = fit; the grouped GEMM launch simply carries k x the
+// problems).  k = 1 is the reference's per-image loop.
+int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const Work* ws, int step,
+             hipStream_t s) {
   const int B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
   const int E = c->grid.n_levels * c->grid.n_features;
-  float* P = b->params;
-  float* Gd = b->grads;
-  const int32_t* ridx = b->idx + (size_t)step * B;
   const bool phase2 = step > c->switch_step;
   const bool use_res = phase2 && c->enable_residual;
-  const bool log = b->losses != nullptr &&
-                   ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
+  constexpr int KM = DVT_FIT_BATCH_MAX;
+  const float* xy[KM];
+  const int32_t* ridx[KM];
+  const float* feat[KM];
+  float *P[KM], *Gd[KM], *M[KM], *V[KM];
+  uint32_t* touched[KM];
+  for (int f = 0; f < k; ++f) {
+    xy[f] = bs[f]->xy;
+    ridx[f] = bs[f]->idx + (size_t)step * B;
+    feat[f] = bs[f]->feat;
+    P[f] = bs[f]->params;
+    Gd[f] = bs[f]->grads;
+    M[f] = bs[f]->adam_m;
+    V[f] = bs[f]->adam_v;
+    touched[f] = bs[f]->touched;
+  }
+  // per-fit pointer tables: arena tensor at offset `off`, or a workspace member
+  auto at = [&](float* const* base, int64_t off, float** out) {
+    for (int f = 0; f < k; ++f) out[f] = base[f] + off;
+  };
+#define WS_TAB(name, member) \
+  float* name[KM];           \
+  for (int f = 0; f < k; ++f) name[f] = ws[f].member;
+  WS_TAB(enc, enc) WS_TAB(raw, raw) WS_TAB(Fp, F) WS_TAB(Hres, Hres) WS_TAB(dF, dF) WS_TAB(dH, dH)
+  WS_TAB(rows, rows) WS_TAB(denc, denc)
+#undef WS_TAB
 
   // ---- forward ----
-  DVT_TRY(dvt_fit_prep(&c->grid, b->xy, ridx, P + c->off_grid, w.enc, b->feat, w.raw, B, C, s));
-  // Linear layers go out as GROUPED launches: independent GEMMs of the step (field branch and
-  // residual branch, weight- and data-gradient of one layer) share one grid.
-  auto fwd_op = [&](const float* x, int64_t ow, int64_t ob, float* y, int n, int k, int relu) {
-    DvtLinearOp o{};
-    o.kind = 0; o.x = x; o.w = P + ow; o.b = P + ob; o.y = y; o.m = B; o.n = n; o.k = k; o.relu = relu;
-    return o;
-  };
-  auto wgrad_op = [&](const float* dy, const float* x, int64_t ow, int64_t ob, int n, int k) {
-    DvtLinearOp o{};
-    o.kind = 1; o.dy = dy; o.x = x; o.dw = Gd + ow; o.db = Gd + ob; o.m = B; o.n = n; o.k = k;
-    return o;
-  };
-  auto dgrad_op = [&](const float* dy, int64_t ow, float* dx, const float* mask, int n, int k) {
-    DvtLinearOp o{};
-    o.kind = 2; o.dy = dy; o.w = P + ow; o.dx = dx; o.relu_mask = mask; o.m = B; o.n = n; o.k = k;
-    return o;
-  };
   {
-    DvtLinearOp g1[2] = {fwd_op(w.enc, c->off_w1, c->off_b1, w.h1, H, E, 1),
-                         fwd_op(w.raw, c->off_wh1, c->off_bh1, w.r1, R, C, 1)};
-    DVT_TRY(dvt_linear_group(g1, use_res ? 2 : 1, s));
-    DvtLinearOp g2[2] = {fwd_op(w.h1, c->off_w2, c->off_b2, w.F, C, H, 0),
-                         fwd_op(w.r1, c->off_wh2, c->off_bh2, w.r2, R, R, 1)};
-    DVT_TRY(dvt_linear_group(g2, use_res ? 2 : 1, s));
-    if (use_res) {
-      DvtLinearOp g3[1] = {fwd_op(w.r2, c->off_wh3, c->off_bh3, w.Hres, C, R, 0)};
-      DVT_TRY(dvt_linear_group(g3, 1, s));
-    }
+    float* gridp[KM];
+    at(P, c->off_grid, gridp);
+    DVT_TRY(dvt_fit_prep_k(&c->grid, k, xy, ridx, gridp, enc, feat, raw, B, C, s));
+  }
+  // Linear layers go out as GROUPED launches: independent GEMMs of the step (field branch and
+  // residual branch, weight- and data-gradient of one layer, all k fits) share one grid.
+  auto fwd_op = [&](int f, const float* x, int64_t ow, int64_t ob, float* y, int n, int kk, int relu) {
+    DvtLinearOp o{};
+    o.kind = 0; o.x = x; o.w = P[f] + ow; o.b = P[f] + ob; o.y = y; o.m = B; o.n = n; o.k = kk; o.relu = relu;
+    return o;
+  };
+  auto wgrad_op = [&](int f, const float* dy, const float* x, int64_t ow, int64_t ob, int n, int kk) {
+    DvtLinearOp o{};
+    o.kind = 1; o.dy = dy; o.x = x; o.dw = Gd[f] + ow; o.db = Gd[f] + ob; o.m = B; o.n = n; o.k = kk;
+    return o;
+  };
+  auto dgrad_op = [&](int f, const float* dy, int64_t ow, float* dx, const float* mask, int n, int kk) {
+    DvtLinearOp o{};
+    o.kind = 2; o.dy = dy; o.w = P[f] + ow; o.dx = dx; o.relu_mask = mask; o.m = B; o.n = n; o.k = kk;
+    return o;
+  };
+  DvtLinearOp ops[4 * KM];
+  int n_ops;
+  auto launch = [&]() { return dvt_linear_group(ops, n_ops, s); };
+  n_ops = 0;
+  for (int f = 0; f < k; ++f) {
+    const Work& w = ws[f];
+    ops[n_ops++] = fwd_op(f, w.enc, c->off_w1, c->off_b1, w.h1, H, E, 1);
+    if (use_res) ops[n_ops++] = fwd_op(f, w.raw, c->off_wh1, c->off_bh1, w.r1, R, C, 1);
+  }
+  DVT_TRY(launch());
+  n_ops = 0;
+  for (int f = 0; f < k; ++f) {
+    const Work& w = ws[f];
+    ops[n_ops++] = fwd_op(f, w.h1, c->off_w2, c->off_b2, w.F, C, H, 0);
+    if (use_res) ops[n_ops++] = fwd_op(f, w.r1, c->off_wh2, c->off_bh2, w.r2, R, R, 1);
+  }
+  DVT_TRY(launch());
+  if (use_res) {
+    n_ops = 0;
+    for (int f = 0; f < k; ++f) ops[n_ops++] = fwd_op(f, ws[f].r2, c->off_wh3, c->off_bh3, ws[f].Hres, C, R, 0);
+    DVT_TRY(launch());
   }
   // ---- loss + d(pred), G gradient scattered in the same pass while G still trains ----
-  DVT_TRY(dvt_loss_launch(w.F, P + c->off_G, ridx, c->lattice, use_res ? w.Hres : nullptr, w.raw,
-                          w.dF, use_res ? w.dH : nullptr, phase2 ? nullptr : Gd + c->off_G, w.rows,
-                          B, C, (float)c->grad_scale, s));
-  if (log) DVT_TRY(dvt_loss_reduce(w.rows, b->losses + (size_t)step * 8, B, C, use_res, s));
-  // ---- backward: {field layer 2, h layer 3}, {field layer 1, h layer 2}, hash grid, {h layer 1}
   {
-    DvtLinearOp g4[4] = {dgrad_op(w.dF, c->off_w2, w.dh1, w.h1, C, H),
-                         wgrad_op(w.dF, w.h1, c->off_w2, c->off_b2, C, H),
-                         dgrad_op(w.dH, c->off_wh3, w.dr2, w.r2, C, R),
-                         wgrad_op(w.dH, w.r2, c->off_wh3, c->off_bh3, C, R)};
-    DVT_TRY(dvt_linear_group(g4, use_res ? 4 : 2, s));
-    DvtLinearOp g5[4] = {dgrad_op(w.dh1, c->off_w1, w.denc, nullptr, H, E),
-                         wgrad_op(w.dh1, w.enc, c->off_w1, c->off_b1, H, E),
-                         dgrad_op(w.dr2, c->off_wh2, w.dr1, w.r1, R, R),
-                         wgrad_op(w.dr2, w.r1, c->off_wh2, c->off_bh2, R, R)};
-    DVT_TRY(dvt_linear_group(g5, use_res ? 4 : 2, s));
+    float *Gp[KM], *dG[KM];
+    at(P, c->off_G, Gp);
+    at(Gd, c->off_G, dG);
+    if (phase2)
+      for (int f = 0; f < k; ++f) dG[f] = nullptr;
+    DVT_TRY(dvt_loss_launch_k(k, Fp, Gp, ridx, c->lattice, use_res ? Hres : nullptr, raw, dF, dH, dG,
+                              rows, B, C, (float)c->grad_scale, s));
   }
-  DVT_TRY(dvt_grid_bwd_idx(&c->grid, b->xy, ridx, w.denc, Gd + c->off_grid, b->touched, B, s));
+  for (int f = 0; f < k; ++f) {
+    const DvtFitBuffers* b = bs[f];
+    const bool log = b->losses != nullptr &&
+                     ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
+    if (log) DVT_TRY(dvt_loss_reduce(ws[f].rows, b->losses + (size_t)step * 8, B, C, use_res, s));
+  }
+  // ---- backward: {field layer 2, h layer 3}, {field layer 1, h layer 2}, hash grid, {h layer 1}
+  n_ops = 0;
+  for (int f = 0; f < k; ++f) {
+    const Work& w = ws[f];
+    ops[n_ops++] = dgrad_op(f, w.dF, c->off_w2, w.dh1, w.h1, C, H);
+    ops[n_ops++] = wgrad_op(f, w.dF, w.h1, c->off_w2, c->off_b2, C, H);
+    if (use_res) {
+      ops[n_ops++] = dgrad_op(f, w.dH, c->off_wh3, w.dr2, w.r2, C, R);
+      ops[n_ops++] = wgrad_op(f, w.dH, w.r2, c->off_wh3, c->off_bh3, C, R);
+    }
+  }
+  DVT_TRY(launch());
+  n_ops = 0;
+  for (int f = 0; f < k; ++f) {
+    const Work& w = ws[f];
+    ops[n_ops++] = dgrad_op(f, w.dh1, c->off_w1, w.denc, nullptr, H, E);
+    ops[n_ops++] = wgrad_op(f, w.dh1, w.enc, c->off_w1, c->off_b1, H, E);
+    if (use_res) {
+      ops[n_ops++] = dgrad_op(f, w.dr2, c->off_wh2, w.dr1, w.r1, R, R);
+      ops[n_ops++] = wgrad_op(f, w.dr2, w.r1, c->off_wh2, c->off_bh2, R, R);
+    }
+  }
+  DVT_TRY(launch());
+  {
+    float* dgrid[KM];
+    at(Gd, c->off_grid, dgrid);
+    DVT_TRY(dvt_grid_bwd_k(&c->grid, k, xy, ridx, denc, dgrid, touched, B, s));
+  }
   if (use_res) {
-    DvtLinearOp g6[1] = {wgrad_op(w.dr1, w.raw, c->off_wh1, c->off_bh1, R, C)};
-    DVT_TRY(dvt_linear_group(g6, 1, s));
+    n_ops = 0;
+    for (int f = 0; f < k; ++f)
+      ops[n_ops++] = wgrad_op(f, ws[f].dr1, ws[f].raw, c->off_wh1, c->off_bh1, R, C);
+    DVT_TRY(launch());
   }
   // ---- Adam (dense) + zero_grad ----
   DvtAdamArgs a{};
@@ -204,7 +269,7 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
   a.eps = c->eps;
   a.weight_decay = c->weight_decay;
   a.sparse_end = c->off_w1;
-  const double lr = b->h_lr[step];
+  const double lr = bs[0]->h_lr[step];
   auto seg = [&](int64_t beg, int64_t end, int t) {
     DvtAdamSeg sg{};
     sg.begin = beg;
@@ -221,7 +286,7 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
     seg(c->off_grid, c->off_G, step + 1);  // grid + field MLP (G frozen: grad None)
     if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
   }
-  return dvt_adam_step(&a, P, b->adam_m, b->adam_v, Gd, b->touched, s);
+  return dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s);
 }
 #undef DVT_TRY
 
@@ -229,34 +294,28 @@ int fit_step(const DvtFitConfig* c, const DvtFitBuffers* b, const Work& w, int s
 
 extern "C" int dvt_fit_run(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin,
                            int step_end, void* stream) {
-  int rc = check_bufs(c, b, step_begin, step_end);
-  if (rc) return rc;
-  Work w;
-  carve(c, b->workspace, &w);
-  for (int step = step_begin; step < step_end; ++step) {
-    rc = fit_step(c, b, w, step, (hipStream_t)stream);
-    if (rc) return rc;
-  }
-  return 0;
+  return dvt_fit_run_batched(c, 1, &b, step_begin, step_end, stream);
 }
 
-// k independent fits (k images) advanced in lock step, fit j on streams[j]: their
-// latency-bound small kernels overlap on the GPU (config 3 of BASELINE.json: many concurrent
-// neural fields per GPU).  All fits must share num_iters.
-extern "C" int dvt_fit_run_multi(int k, const DvtFitConfig* const* cfgs,
-                                 const DvtFitBuffers* const* bufs, void* const* streams,
-                                 int step_begin, int step_end) {
-  if (k <= 0 || k > 16 || !cfgs || !bufs || !streams) return DVT_E_BADARG;
-  Work w[16];
+// k independent fits (k images, ONE configuration and learning-rate schedule) advanced in lock
+// step by shared launches (BASELINE.json configs[2]: many concurrent neural fields per GPU).
+// Results are those of k separate dvt_fit_run calls: every fit keeps its own arena, Adam state,
+// index stream and workspace; only the grids are fused.
+extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bufs,
+                                   int step_begin, int step_end, void* stream) {
+  if (k <= 0 || k > DVT_FIT_BATCH_MAX || !bufs) return DVT_E_BADARG;
+  Work w[DVT_FIT_BATCH_MAX];
   for (int j = 0; j < k; ++j) {
-    int rc = check_bufs(cfgs[j], bufs[j], step_begin, step_end);
+    int rc = check_bufs(c, bufs[j], step_begin, step_end);
     if (rc) return rc;
-    carve(cfgs[j], bufs[j]->workspace, &w[j]);
+    for (int i = 0; i < j; ++i)
+      if (bufs[i]->params == bufs[j]->params || bufs[i]->workspace == bufs[j]->workspace)
+        return DVT_E_BADARG;  // fits must not share state
+    carve(c, bufs[j]->workspace, &w[j]);
   }
-  for (int step = step_begin; step < step_end; ++step)
-    for (int j = 0; j < k; ++j) {
-      int rc = fit_step(cfgs[j], bufs[j], w[j], step, (hipStream_t)streams[j]);
-      if (rc) return rc;
-    }
+  for (int step = step_begin; step < step_end; ++step) {
+    int rc = fit_step(c, k, bufs, w, step, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   return 0;
 }

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
 // (wgrad + dgrad of a layer, field branch + residual branch) are therefore packed into one
 // launch: a workgroup finds its problem from blockIdx.x, the operand layouts become a run-time
 // switch over the three instantiations of the same body.
-constexpr int MULTI_MAX = 4;
+constexpr int MULTI_MAX = 16;  // 4 problems of one fit x DVT_FIT_BATCH_MAX fits
 struct MultiArgs {
   int n;
   int blk0[MULTI_MAX + 1];  // first block of each problem

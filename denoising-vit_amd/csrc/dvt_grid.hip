@@ -20,7 +20,7 @@
 
 #include "dvt_common.h"
 
-extern "C" int dvt_abi_version(void) { return 1; }
+extern "C" int dvt_abi_version(void) { return DVT_ABI_VERSION; }
 
 extern "C" int dvt_struct_sizes(int64_t* out) {
   if (!out) return DVT_E_BADARG;
@@ -159,13 +159,22 @@ struct GridBwdPlan {
   int splits[DVT_MAX_LEVELS];           // sample slices per chunk of that level
 };
 
+struct GridBwdPtrs {  // per fit of a batched launch (blockIdx.y)
+  const float2* xy[DVT_FIT_BATCH_MAX];
+  const int32_t* ridx[DVT_FIT_BATCH_MAX];
+  const float* d_enc[DVT_FIT_BATCH_MAX];
+  float* d_params[DVT_FIT_BATCH_MAX];
+  uint32_t* touched[DVT_FIT_BATCH_MAX];
+};
+
 template <int LDS_CHUNK>
 __global__ __launch_bounds__(1024) void grid_bwd_kernel(DvtGridTable T, GridBwdPlan plan,
-                                                        const float2* __restrict__ xy,
-                                                        const int32_t* __restrict__ ridx,
-                                                        const float* __restrict__ d_enc,
-                                                        float* __restrict__ d_params,
-                                                        uint32_t* __restrict__ touched, int n) {
+                                                        GridBwdPtrs q, int n) {
+  const float2* __restrict__ xy = q.xy[blockIdx.y];
+  const int32_t* __restrict__ ridx = q.ridx[blockIdx.y];
+  const float* __restrict__ d_enc = q.d_enc[blockIdx.y];
+  float* __restrict__ d_params = q.d_params[blockIdx.y];
+  uint32_t* __restrict__ touched = q.touched[blockIdx.y];
   __shared__ float acc[LDS_CHUNK * 8];
   __shared__ uint32_t flags[LDS_CHUNK / 32 + 1];
   const int L = T.n_levels;
@@ -332,33 +341,58 @@ int dvt_grid_fwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ri
 int dvt_grid_bwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ridx,
                      const float* d_enc, float* d_params, uint32_t* touched, int n,
                      hipStream_t stream) {
-  if (!tbl || !xy || !d_enc || !d_params || n < 0 || tbl->n_features != 8) return DVT_E_BADARG;
+  return dvt_grid_bwd_k(tbl, 1, &xy, &ridx, &d_enc, &d_params, &touched, n, stream);
+}
+
+int dvt_grid_bwd_k(const DvtGridTable* tbl, int k, const float* const* xy, const int32_t* const* ridx,
+                   const float* const* d_enc, float* const* d_params, uint32_t* const* touched, int n,
+                   hipStream_t stream) {
+  if (!tbl || k < 1 || k > DVT_FIT_BATCH_MAX || n < 0 || tbl->n_features != 8) return DVT_E_BADARG;
+  GridBwdPtrs q{};
+  for (int f = 0; f < k; ++f) {
+    if (!xy[f] || !d_enc[f] || !d_params[f]) return DVT_E_BADARG;
+    q.xy[f] = (const float2*)xy[f];
+    q.ridx[f] = ridx[f];
+    q.d_enc[f] = d_enc[f];
+    q.d_params[f] = d_params[f];
+    q.touched[f] = touched[f];
+  }
   if (n == 0) return 0;
   GridBwdPlan plan;
   make_bwd_plan(*tbl, n, &plan);
   const long long threads = (long long)n * (tbl->n_levels - plan.first_direct_level) * 8;
   const int blocks = plan.n_lds_blocks + dvt_cdiv(threads, 1024);
   // algorithmic bytes: 32 B read + 4 corners x 32 B read-modify-write per (sample, level)
-  DvtProbeScope probe(DVT_PROBE_GRID, stream, (double)n * tbl->n_levels * (32 + 4 * 64));
+  DvtProbeScope probe(DVT_PROBE_GRID, stream, (double)k * n * tbl->n_levels * (32 + 4 * 64));
   if (g_grid_lds_chunk == LDS_CHUNK_SMALL)
-    hipLaunchKernelGGL(grid_bwd_kernel<LDS_CHUNK_SMALL>, dim3(blocks), dim3(1024), 0, stream, *tbl,
-                       plan, (const float2*)xy, ridx, d_enc, d_params, touched, n);
+    hipLaunchKernelGGL(grid_bwd_kernel<LDS_CHUNK_SMALL>, dim3(blocks, k), dim3(1024), 0, stream, *tbl,
+                       plan, q, n);
   else
-    hipLaunchKernelGGL(grid_bwd_kernel<LDS_CHUNK_BIG>, dim3(blocks), dim3(1024), 0, stream, *tbl,
-                       plan, (const float2*)xy, ridx, d_enc, d_params, touched, n);
+    hipLaunchKernelGGL(grid_bwd_kernel<LDS_CHUNK_BIG>, dim3(blocks, k), dim3(1024), 0, stream, *tbl,
+                       plan, q, n);
   DVT_CHECK_LAUNCH();
   return 0;
 }
 
 // Fused step prologue of the fit: raw-row gather (one wave per row) and hash-grid forward in ONE
 // launch (blocks [0, gather_blocks) gather, the rest encode) -- two fewer dependent launches.
-__global__ __launch_bounds__(256) void fit_prep_kernel(DvtGridTable T, const float2* __restrict__ xy,
-                                                       const int32_t* __restrict__ ridx,
-                                                       const float4* __restrict__ params,
-                                                       float4* __restrict__ enc,
-                                                       const float4* __restrict__ feat,
-                                                       float4* __restrict__ raw, int n, int cq,
+struct PrepPtrs {  // per fit of a batched launch (blockIdx.y)
+  const float2* xy[DVT_FIT_BATCH_MAX];
+  const int32_t* ridx[DVT_FIT_BATCH_MAX];
+  const float4* params[DVT_FIT_BATCH_MAX];
+  float4* enc[DVT_FIT_BATCH_MAX];
+  const float4* feat[DVT_FIT_BATCH_MAX];
+  float4* raw[DVT_FIT_BATCH_MAX];
+};
+
+__global__ __launch_bounds__(256) void fit_prep_kernel(DvtGridTable T, PrepPtrs q, int n, int cq,
                                                        int gather_blocks) {
+  const float2* __restrict__ xy = q.xy[blockIdx.y];
+  const int32_t* __restrict__ ridx = q.ridx[blockIdx.y];
+  const float4* __restrict__ params = q.params[blockIdx.y];
+  float4* __restrict__ enc = q.enc[blockIdx.y];
+  const float4* __restrict__ feat = q.feat[blockIdx.y];
+  float4* __restrict__ raw = q.raw[blockIdx.y];
   if ((int)blockIdx.x < gather_blocks) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -395,13 +429,28 @@ __global__ __launch_bounds__(256) void fit_prep_kernel(DvtGridTable T, const flo
 
 int dvt_fit_prep(const DvtGridTable* tbl, const float* xy, const int32_t* ridx, const float* params,
                  float* enc, const float* feat, float* raw, int n, int c, hipStream_t stream) {
-  if (!tbl || !xy || !ridx || !params || !enc || !feat || !raw || n <= 0 || (c & 3)) return DVT_E_BADARG;
+  return dvt_fit_prep_k(tbl, 1, &xy, &ridx, &params, &enc, &feat, &raw, n, c, stream);
+}
+
+int dvt_fit_prep_k(const DvtGridTable* tbl, int k, const float* const* xy, const int32_t* const* ridx,
+                   const float* const* params, float* const* enc, const float* const* feat,
+                   float* const* raw, int n, int c, hipStream_t stream) {
+  if (!tbl || k < 1 || k > DVT_FIT_BATCH_MAX || n <= 0 || (c & 3)) return DVT_E_BADARG;
+  PrepPtrs q{};
+  for (int f = 0; f < k; ++f) {
+    if (!xy[f] || !ridx[f] || !params[f] || !enc[f] || !feat[f] || !raw[f]) return DVT_E_BADARG;
+    q.xy[f] = (const float2*)xy[f];
+    q.ridx[f] = ridx[f];
+    q.params[f] = (const float4*)params[f];
+    q.enc[f] = (float4*)enc[f];
+    q.feat[f] = (const float4*)feat[f];
+    q.raw[f] = (float4*)raw[f];
+  }
   const int gather_blocks = dvt_cdiv(n, 4);
   const long long threads = (long long)n * tbl->n_levels;
-  DvtProbeScope probe(DVT_PROBE_GRID, stream, (double)threads * (4 * 32 + 32));
-  hipLaunchKernelGGL(fit_prep_kernel, dim3(gather_blocks + dvt_cdiv(threads, 256)), dim3(256), 0,
-                     stream, *tbl, (const float2*)xy, ridx, (const float4*)params, (float4*)enc,
-                     (const float4*)feat, (float4*)raw, n, c / 4, gather_blocks);
+  DvtProbeScope probe(DVT_PROBE_GRID, stream, (double)k * threads * (4 * 32 + 32));
+  hipLaunchKernelGGL(fit_prep_kernel, dim3(gather_blocks + dvt_cdiv(threads, 256), k), dim3(256), 0,
+                     stream, *tbl, q, n, c / 4, gather_blocks);
   DVT_CHECK_LAUNCH();
   return 0;
 }

@@ -114,12 +114,30 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
 // HAS_RES: the residual predictor output Hres participates (phase 2).
+struct LossPtrs {  // per fit of a batched launch (blockIdx.y)
+  const float4* F[DVT_FIT_BATCH_MAX];
+  const float4* G[DVT_FIT_BATCH_MAX];
+  const int32_t* g_idx[DVT_FIT_BATCH_MAX];
+  const float4* Hres[DVT_FIT_BATCH_MAX];
+  const float4* raw[DVT_FIT_BATCH_MAX];
+  float4* d_pred[DVT_FIT_BATCH_MAX];
+  float4* d_hres[DVT_FIT_BATCH_MAX];
+  float* d_G[DVT_FIT_BATCH_MAX];
+  float* row_sums[DVT_FIT_BATCH_MAX];
+};
+
 template <bool HAS_RES>
-__global__ __launch_bounds__(256) void loss_kernel(
-    const float4* __restrict__ F, const float4* __restrict__ G, const int32_t* __restrict__ g_idx,
-    int lattice, const float4* __restrict__ Hres, const float4* __restrict__ raw,
-    float4* __restrict__ d_pred, float4* __restrict__ d_hres, float* __restrict__ d_G,
-    float* __restrict__ row_sums, int n, int cq, float grad_scale) {
+__global__ __launch_bounds__(256) void loss_kernel(LossPtrs q, int lattice, int n, int cq,
+                                                   float grad_scale) {
+  const float4* __restrict__ F = q.F[blockIdx.y];
+  const float4* __restrict__ G = q.G[blockIdx.y];
+  const int32_t* __restrict__ g_idx = q.g_idx[blockIdx.y];
+  const float4* __restrict__ Hres = q.Hres[blockIdx.y];
+  const float4* __restrict__ raw = q.raw[blockIdx.y];
+  float4* __restrict__ d_pred = q.d_pred[blockIdx.y];
+  float4* __restrict__ d_hres = q.d_hres[blockIdx.y];
+  float* __restrict__ d_G = q.d_G[blockIdx.y];
+  float* __restrict__ row_sums = q.row_sums[blockIdx.y];
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -267,18 +285,37 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
 int dvt_loss_launch(const float* F, const float* G, const int32_t* g_idx, int lattice,
                     const float* Hres, const float* raw_rows, float* d_pred, float* d_hres,
                     float* d_G, float* row_sums, int n, int c, float grad_scale, hipStream_t s) {
-  if (!F || !G || !raw_rows || n < 0 || c <= 0 || (c & 3) || c > 64 * 4 * MAXQ) return DVT_E_BADARG;
+  return dvt_loss_launch_k(1, &F, &G, &g_idx, lattice, Hres ? &Hres : nullptr, &raw_rows, &d_pred,
+                           &d_hres, &d_G, &row_sums, n, c, grad_scale, s);
+}
+
+// Hres == nullptr: no residual term for any of the k fits (they share step and configuration)
+int dvt_loss_launch_k(int k, const float* const* F, const float* const* G, const int32_t* const* g_idx,
+                      int lattice, const float* const* Hres, const float* const* raw_rows,
+                      float* const* d_pred, float* const* d_hres, float* const* d_G,
+                      float* const* row_sums, int n, int c, float grad_scale, hipStream_t s) {
+  if (k < 1 || k > DVT_FIT_BATCH_MAX || n < 0 || c <= 0 || (c & 3) || c > 64 * 4 * MAXQ)
+    return DVT_E_BADARG;
+  LossPtrs q{};
+  for (int f = 0; f < k; ++f) {
+    if (!F[f] || !G[f] || !raw_rows[f] || (Hres && !Hres[f])) return DVT_E_BADARG;
+    q.F[f] = (const float4*)F[f];
+    q.G[f] = (const float4*)G[f];
+    q.g_idx[f] = g_idx[f];
+    q.Hres[f] = Hres ? (const float4*)Hres[f] : nullptr;
+    q.raw[f] = (const float4*)raw_rows[f];
+    q.d_pred[f] = (float4*)d_pred[f];
+    q.d_hres[f] = Hres ? (float4*)d_hres[f] : nullptr;
+    q.d_G[f] = d_G[f];
+    q.row_sums[f] = row_sums[f];
+  }
   if (n == 0) return 0;
   const int cq = c / 4;
-  dim3 grid(dvt_cdiv(n, 4)), block(256);
+  dim3 grid(dvt_cdiv(n, 4), k), block(256);
   if (Hres != nullptr)
-    hipLaunchKernelGGL(loss_kernel<true>, grid, block, 0, s, (const float4*)F, (const float4*)G,
-                       g_idx, lattice, (const float4*)Hres, (const float4*)raw_rows,
-                       (float4*)d_pred, (float4*)d_hres, d_G, row_sums, n, cq, grad_scale);
+    hipLaunchKernelGGL(loss_kernel<true>, grid, block, 0, s, q, lattice, n, cq, grad_scale);
   else
-    hipLaunchKernelGGL(loss_kernel<false>, grid, block, 0, s, (const float4*)F, (const float4*)G,
-                       g_idx, lattice, (const float4*)nullptr, (const float4*)raw_rows,
-                       (float4*)d_pred, (float4*)nullptr, d_G, row_sums, n, cq, grad_scale);
+    hipLaunchKernelGGL(loss_kernel<false>, grid, block, 0, s, q, lattice, n, cq, grad_scale);
   DVT_CHECK_LAUNCH();
   return 0;
 }

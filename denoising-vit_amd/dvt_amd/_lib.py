@@ -147,8 +147,7 @@ _SIGNATURES = {
     "dvt_fit_layout": (_I, [C.POINTER(FitConfig)]),
     "dvt_fit_workspace_floats": (C.c_int64, [C.POINTER(FitConfig)]),
     "dvt_fit_run": (_I, [C.POINTER(FitConfig), C.POINTER(FitBuffers), _I, _I, _P]),
-    "dvt_fit_run_multi": (_I, [_I, C.POINTER(C.POINTER(FitConfig)), C.POINTER(C.POINTER(FitBuffers)),
-                               C.POINTER(C.c_void_p), _I, _I]),
+    "dvt_fit_run_batched": (_I, [C.POINTER(FitConfig), _I, C.POINTER(C.POINTER(FitBuffers)), _I, _I, _P]),
     "dvt_field_infer": (_I, [C.POINTER(FitConfig), _P, _P, _P, _P, _I, _P]),
     "dvt_vit_gemm_residual": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dvt_render_views": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),

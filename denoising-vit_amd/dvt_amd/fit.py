@@ -259,17 +259,27 @@ class FitEngine:
                 if host[i, 0] != 0.0}
 
 
-def fit_many(engines, feats, xys, streams, log_every: int = 1000) -> None:
-    """Advance k independent fits in lock step, fit j on streams[j] (torch.cuda.Stream): the
-    small latency-bound kernels of different images overlap on the GPU (`dvt_fit_run_multi`).
-    Index streams are drawn in engine order from the reference's numpy RNG."""
+FIT_BATCH_MAX = 4  # DVT_FIT_BATCH_MAX
+
+
+def fit_many(engines, feats, xys, idxs=None, log_every: int = 1000, step_begin: int = 0,
+             step_end: int | None = None) -> None:
+    """Advance k independent fits (k images, identical settings) in lock step on the CURRENT
+    stream with shared launches (`dvt_fit_run_batched`): every kernel of a step covers all k
+    fits, so the fixed per-launch latency of the ~10 dependent launches per step is paid once
+    per k images.  Each engine keeps its own arena / Adam state / index stream; index streams
+    are drawn in engine order from the reference's numpy RNG when `idxs` is None."""
     k = len(engines)
-    bufs = []
-    for e, f, x, st in zip(engines, feats, xys, streams):
-        with torch.cuda.stream(st):
-            bufs.append(e.buffers(f, x, None, log_every))
-    cfg_arr = (C.POINTER(_lib.FitConfig) * k)(*[C.pointer(e.cfg) for e in engines])
+    if not 1 <= k <= FIT_BATCH_MAX:
+        raise _lib.DvtError(f"fit_many takes 1..{FIT_BATCH_MAX} engines")
+    ref = bytes(engines[0].cfg)
+    if any(bytes(e.cfg) != ref for e in engines[1:]):
+        raise _lib.DvtError("batched fits must share one configuration")
+    if len({id(e) for e in engines}) != k:
+        raise _lib.DvtError("batched fits need distinct engines")
+    idxs = idxs if idxs is not None else [None] * k
+    bufs = [e.buffers(f, x, i, log_every) for e, f, x, i in zip(engines, feats, xys, idxs)]
     buf_arr = (C.POINTER(_lib.FitBuffers) * k)(*[C.pointer(b) for b in bufs])
-    st_arr = (C.c_void_p * k)(*[st.cuda_stream for st in streams])
-    _lib.check(_lib.lib().dvt_fit_run_multi(k, cfg_arr, buf_arr, st_arr, 0, engines[0].s.num_iters),
-               "dvt_fit_run_multi")
+    end = engines[0].s.num_iters if step_end is None else step_end
+    _lib.check(_lib.lib().dvt_fit_run_batched(C.byref(engines[0].cfg), k, buf_arr, step_begin, end,
+                                              _lib.stream()), "dvt_fit_run_batched")

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import views as V
-from .fit import FitEngine, FitSettings
+from .fit import FIT_BATCH_MAX, FitEngine, FitSettings, fit_many
 from .models import MODEL_LIST, PretrainedViTWrapper
 from .utils import misc
 
@@ -58,6 +58,8 @@ def get_args(argv=None):
     # additions of this build
     p.add_argument("--vit_checkpoint", type=str, default=None, help="timm-layout state dict (.pth)")
     p.add_argument("--synthetic", action="store_true", help="N(0,1) views instead of image crops")
+    p.add_argument("--fit_batch", type=int, default=1,
+                   help="images fitted together by shared launches (dvt_fit_run_batched), 1..4")
     args = p.parse_args(argv)
     if isinstance(args.input_size, int):
         args.input_size = (args.input_size, args.input_size)
@@ -117,12 +119,13 @@ class Stage1:
     """Everything that is reused across images on one GPU: ViT weights, the view / feature /
     coordinate buffers (main_img_denoising.py:261-276) and the fit engine.
 
-    Images are pipelined over two HIP streams: the MFMA-bound extractor of image i+1 runs on
-    `s_vit` while the latency/HBM-bound fit of image i runs on the high-priority `s_fit`
-    (`depth` slots of buffers; depth=1 reproduces the reference's strictly serial flow)."""
+    Images are pipelined over two HIP streams in groups of `fit_batch`: the MFMA-bound extractor
+    of the next group runs on `s_vit` while the latency/HBM-bound fits of the current group run
+    -- batched into shared launches (`fit_many`) -- on the high-priority `s_fit` (`depth` groups
+    of buffers; depth=1, fit_batch=1 reproduces the reference's strictly serial flow)."""
 
     def __init__(self, args, device, vit: PretrainedViTWrapper | None = None, depth: int = 2,
-                 vit_cus_per_32: int = 32):
+                 vit_cus_per_32: int = 32, fit_batch: int = 1):
         self.args, self.device = args, torch.device(device)
         self.vit = vit or PretrainedViTWrapper(args.model, stride=args.stride_size,
                                                checkpoint_path=getattr(args, "vit_checkpoint", None),
@@ -134,17 +137,21 @@ class Stage1:
         self.feat_dim = v.n_output_dims
         n = args.num_views + 1
         dev = self.device
+        depth = max(1, depth)
+        self.fit_batch = kb = min(max(1, fit_batch), FIT_BATCH_MAX) if depth > 1 else 1
+        self.depth = depth
         self.slots = [_Slot(n, args.input_size, self.pos_h, self.pos_w, self.feat_dim, dev)
-                      for _ in range(max(1, depth))]
+                      for _ in range(depth * kb)]
         s = FitSettings(feat_dim=self.feat_dim, noise_map_height=self.pos_h,
                         noise_map_width=self.pos_w, n_levels=args.n_levels,
                         num_iters=args.num_iters, warmup_iters=args.warmup_iters,
                         freeze_shared_artifacts_after=args.freeze_shared_artifacts_after,
                         lr=args.lr, min_lr=args.min_lr, weight_decay=args.weight_decay,
                         pixel_bsz=args.pixel_bsz)
-        self.engine = FitEngine(s, n * self.pos_h * self.pos_w, dev)
+        self.engines = [FitEngine(s, n * self.pos_h * self.pos_w, dev) for _ in range(kb)]
+        self.engine = self.engines[0]
         self.gen = torch.Generator(device=dev).manual_seed(args.seed)
-        if len(self.slots) > 1:
+        if depth > 1:
             self.s_vit = (torch.cuda.Stream(device=dev) if vit_cus_per_32 >= 32
                           else _cu_masked_stream(dev, vit_cus_per_32))
             self.s_fit = torch.cuda.Stream(device=dev, priority=-1)
@@ -168,46 +175,69 @@ class Stage1:
         e.fit(slot.features.view(-1, C), slot.coords.view(-1, 2), None, log_every=log_every)
         return e.infer(slot.coords[-1]).unsqueeze(0)
 
+    def fit_group(self, group, log_every: int = 1000):
+        """The fits of up to `fit_batch` images advanced together (shared launches).  Models are
+        constructed image by image in order (torch RNG), index streams are drawn in the same
+        order (numpy RNG) -- the draws of the reference's sequential loop."""
+        engines = self.engines[:len(group)]
+        C = self.feat_dim
+        for e in engines:
+            e.reset(self.gen)
+        fit_many(engines, [sl.features.view(-1, C) for sl in group],
+                 [sl.coords.view(-1, 2) for sl in group], None, log_every=log_every)
+        return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
+
     # -- the pipeline --------------------------------------------------------------------------
     def run(self, jobs, on_result=None, log_every: int = 1000) -> int:
         """jobs: iterable of (tag, set_views) with set_views(slot) filling slot.views / slot.coords
         (called with `s_vit` current).  on_result(tag, raw_host, den_host) is called on the host
         once an image's outputs have landed in pinned memory.  Returns the number of images."""
-        pending = []  # slots whose fit has been enqueued, in order
+        kb, depth = self.fit_batch, self.depth
+        pending = []  # groups whose fit has been enqueued, in order
         done = 0
 
-        def retire(slot):
+        def retire(group):
             nonlocal done
-            slot.fitted.synchronize()
-            if on_result is not None:
-                on_result(slot.tag, slot.raw_host.numpy(), slot.den_host.numpy())
-            done += 1
+            group[-1].fitted.synchronize()  # recorded after the whole group's D2H copies
+            for slot in group:
+                if on_result is not None:
+                    on_result(slot.tag, slot.raw_host.numpy(), slot.den_host.numpy())
+                done += 1
 
-        def enqueue_fit(slot):
+        def enqueue_fit(group):
             with torch.cuda.stream(self.s_fit):
-                self.s_fit.wait_event(slot.extracted)
-                den = self.fit(slot, log_every)
-                slot.raw_host.copy_(slot.features[-1], non_blocking=True)
-                slot.den_host.copy_(den, non_blocking=True)
-                slot.fitted.record(self.s_fit)
-            pending.append(slot)
+                for slot in group:
+                    self.s_fit.wait_event(slot.extracted)
+                dens = self.fit_group(group, log_every)
+                for slot, den in zip(group, dens):
+                    slot.raw_host.copy_(slot.features[-1], non_blocking=True)
+                    slot.den_host.copy_(den, non_blocking=True)
+                group[-1].fitted.record(self.s_fit)
+            pending.append(group)
 
-        prev = None
-        for k, (tag, set_views) in enumerate(jobs):
-            slot = self.slots[k % len(self.slots)]
-            while slot in pending:  # the slot's previous image must have left the pipeline
+        prev, cur = None, []
+        for n, (tag, set_views) in enumerate(jobs):
+            g, j = divmod(n, kb)
+            slot = self.slots[(g % depth) * kb + j]
+            # the group that used this slot set before must have left the pipeline
+            while any(slot in grp for grp in pending):
                 retire(pending.pop(0))
             slot.tag = tag
             with torch.cuda.stream(self.s_vit):
                 set_views(slot)
                 self.extract(slot)
                 slot.extracted.record(self.s_vit)
-            # enqueue the extractor of image k BEFORE the (long, back-pressured) fit enqueue of k-1
-            if prev is not None:
-                enqueue_fit(prev)
-            prev = slot
+            cur.append(slot)
+            if len(cur) == kb:
+                # the extractors of group g are enqueued BEFORE the (long, back-pressured) fit
+                # enqueue of group g-1
+                if prev is not None:
+                    enqueue_fit(prev)
+                prev, cur = cur, []
         if prev is not None:
             enqueue_fit(prev)
+        if cur:
+            enqueue_fit(cur)
         while pending:
             retire(pending.pop(0))
         return done
@@ -242,7 +272,7 @@ def main(args, rank: int = 0, world: int = 1):
     names = work_list(args)
     lo, hi = misc.shard_range(0, len(names), rank, world)
     names = names[lo:hi]
-    st = Stage1(args, device)
+    st = Stage1(args, device, fit_batch=getattr(args, "fit_batch", 1))
     norm = st.vit.transformation.transforms[-1]
     start = time.time()
 

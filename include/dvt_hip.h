@@ -41,7 +41,9 @@ extern "C" {
 #define DVT_E_BADARG (-1) /* shape/alignment precondition violated */
 #define DVT_E_NOTIMPL (-2)
 
-/* ABI version; bumped on any struct change. */
+/* ABI version; bumped on any struct or entry-point change (2: dvt_fit_run_batched replaces
+ * dvt_fit_run_multi; dvt_render_views; dvt_vit_gemm_residual). */
+#define DVT_ABI_VERSION 2
 int dvt_abi_version(void);
 /* HOST: sizeof() of {DvtGridTable, DvtAdamSeg, DvtAdamArgs, DvtFitConfig, DvtFitBuffers} so that
  * a foreign-language binding (ctypes) can verify its struct mirrors. */
@@ -226,11 +228,15 @@ int64_t dvt_fit_workspace_floats(const DvtFitConfig* h_cfg);
 int dvt_fit_run(const DvtFitConfig* h_cfg, const DvtFitBuffers* h_bufs, int step_begin,
                 int step_end, void* stream);
 
-/* k independent fits advanced in lock step, fit j enqueued on h_streams[j] (hipStream_t as
- * void*): the latency-bound small kernels of different images overlap on the GPU
- * (BASELINE.json configs[2]: many concurrent neural fields per GPU).  k <= 16. */
-int dvt_fit_run_multi(int k, const DvtFitConfig* const* h_cfgs, const DvtFitBuffers* const* h_bufs,
-                      void* const* h_streams, int step_begin, int step_end);
+/* k independent fits (k images) of ONE configuration advanced in lock step by SHARED launches:
+ * every kernel of a step covers all k fits (BASELINE.json configs[2]: many concurrent neural
+ * fields per GPU).  A fit step is a chain of ~10 small dependent launches, each paying a fixed
+ * launch latency that does not grow with the grid.  Every fit keeps its own arena, Adam state,
+ * index stream and workspace (h_bufs[j]); results equal k separate dvt_fit_run calls up to the
+ * ordering of fp32 atomics.  1 <= k <= DVT_FIT_BATCH_MAX; h_lr is read from h_bufs[0]. */
+#define DVT_FIT_BATCH_MAX 4
+int dvt_fit_run_batched(const DvtFitConfig* h_cfg, int k, const DvtFitBuffers* const* h_bufs,
+                        int step_begin, int step_end, void* stream);
 
 /* out[n, C] = field(xy[n,2]) using arena params; workspace >= n*(L*F + hidden) floats. */
 int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float* xy, float* out,

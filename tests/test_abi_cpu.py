@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(built_lib, n), f"libdvt_hip.so lacks {n}"
     from dvt_amd import _lib
     assert set(_lib._SIGNATURES) == set(names), "ctypes signatures out of sync with include/*.h"
-    assert built_lib.dvt_abi_version() >= 1
+    assert built_lib.dvt_abi_version() == 2
 
 
 def test_struct_mirrors_match(built_lib):

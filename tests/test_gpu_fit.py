@@ -148,3 +148,42 @@ def test_full_size_properties(built_lib):
     assert float(d.mean()) < 1e-4 and float(d.max()) < 0.1
     out = eng.infer(xy[-1].to(DEV))
     assert out.shape == (37, 37, 768) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_batched_fits_equal_separate_fits(built_lib, k):
+    """dvt_fit_run_batched (k images advanced by shared launches, BASELINE configs[2]) against k
+    separate dvt_fit_run calls with the same initial parameters and index streams, across the
+    phase switch.  Different images per fit; agreement up to fp32 atomics order."""
+    from dvt_amd.fit import FitEngine, FitSettings, fit_many
+    V, H, W, C = 6, 37, 37, 768
+    s = FitSettings(num_iters=30, warmup_iters=3)
+    n_rows = V * H * W
+    data = [synthetic_image(V, H, W, C, seed=10 + j) for j in range(k)]
+    fs = [d[0].reshape(-1, C).to(DEV) for d in data]
+    cs = [d[1].reshape(-1, 2).to(DEV) for d in data]
+    np.random.seed(3)
+    idxs = [FitEngine.sample_indices(n_rows, s.num_iters, s.pixel_bsz) for _ in range(k)]
+    solo, batched = [], []
+    for j in range(k):
+        e = FitEngine(s, n_rows, DEV)
+        e.reset(torch.Generator(device=DEV).manual_seed(j))
+        e.fit(fs[j], cs[j], idxs[j], log_every=1)
+        solo.append(e)
+        b = FitEngine(s, n_rows, DEV)
+        b.reset(torch.Generator(device=DEV).manual_seed(j))
+        batched.append(b)
+    fit_many(batched, fs, cs, idxs, log_every=1)
+    torch.cuda.synchronize()
+    for j in range(k):
+        d = (solo[j].params - batched[j].params).abs()
+        assert float(d.mean()) < 1e-4 and float(d.max()) < 0.1, (j, float(d.mean()), float(d.max()))
+        a, b = solo[j].infer(data[j][1][-1].to(DEV)), batched[j].infer(data[j][1][-1].to(DEV))
+        assert per_patch_cos(a.cpu(), b.cpu()).min() > 0.9999
+        la, lb = solo[j].loss_log(), batched[j].loss_log()
+        assert len(lb) == s.num_iters
+        assert abs(la[29]["loss"] - lb[29]["loss"]) < 1e-3 * abs(la[29]["loss"])
+        assert float(batched[j].grads.abs().max()) == 0.0 and int(batched[j].touched.abs().max()) == 0
+    # fits of one batch must not share state
+    with pytest.raises(Exception):
+        fit_many([batched[0], batched[0]], fs[:2], cs[:2], idxs[:2])

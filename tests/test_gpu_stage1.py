@@ -18,25 +18,27 @@ def _make_image(path, h=300, w=400):
     Image.fromarray(img).save(path)
 
 
-def test_stage1_driver_end_to_end(built_lib, tmp_path, capsys):
+@pytest.mark.parametrize("fit_batch", [1, 2])
+def test_stage1_driver_end_to_end(built_lib, tmp_path, capsys, fit_batch):
+    """three images: with fit_batch=2 one full group (shared launches) and one partial group"""
     from dvt_amd import stage1
     data_root = tmp_path / "data"
     (data_root / "sub").mkdir(parents=True)
-    for name in ("sub/a.png", "b.png"):
+    for name in ("sub/a.png", "b.png", "c.png"):
         _make_image(str(data_root / name))
     lst = tmp_path / "list.txt"
-    lst.write_text("sub/a.png\nb.png extra-token\n")
+    lst.write_text("sub/a.png\nb.png extra-token\nc.png\n")
     argv = ["--img_path", str(lst), "--data_root", str(data_root), "--save_root", str(tmp_path / "out"),
             "--output_dir", str(tmp_path / "work"), "--num_views", "63", "--num_iters", "60",
-            "--warmup_iters", "6", "--pixel_bsz", "512", "--num_imgs", "10"]
+            "--warmup_iters", "6", "--pixel_bsz", "512", "--num_imgs", "10", "--fit_batch", str(fit_batch)]
     args = stage1.get_args(argv)
     assert args.input_size == (518, 518) and args.n_levels == 16 and args.model.startswith("vit_base")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")  # random ViT weights (no checkpoint offline)
         done = stage1.main(args)
-    assert done == 2
+    assert done == 3
     model = "vit_base_patch14_dinov2.lvd142m"
-    for rel in ("sub/a.npy", "b.npy"):
+    for rel in ("sub/a.npy", "b.npy", "c.npy"):
         raw = np.load(tmp_path / "out" / "raw_features" / model / rel)
         den = np.load(tmp_path / "out" / "denoised_features" / model / rel)
         assert raw.shape == (37, 37, 768) and raw.dtype == np.float32

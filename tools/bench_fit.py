@@ -17,7 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=1000)
 ap.add_argument("--views", type=int, default=769)
 ap.add_argument("--reps", type=int, default=2)
-ap.add_argument("--concurrent", type=int, default=2)
+ap.add_argument("--concurrent", type=int, default=4)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 C, HW = 768, 1369
@@ -42,30 +42,17 @@ def run_once(tag):
     return idx
 
 
-for lds_max in (40960, 0, 300, 1500, 5000, 400000):
-    L.dvt_tune_set(2, lds_max)
-    idx = run_once(f"grid lds_level_max={lds_max}")
-L.dvt_tune_set(2, 40960)
-for target in (1024, 16384):
-    L.dvt_tune_set(2, -target)
-    run_once(f"grid lds atomics/block target={target}")
-L.dvt_tune_set(2, -4096)
-for cfg in (0, 1, 2):
-    L.dvt_tune_set(0, cfg)
-    run_once(f"f32 gemm tile cfg={cfg}")
-L.dvt_tune_set(0, -1)
-eng.reset(g)
-_lib.prof_enable(["adam", "grid", "fit_gemm"])
-eng.fit(feat, xy, idx, log_every=1000)
-torch.cuda.synchronize()
-print("probed (inflated by event overhead): " + ", ".join(
-    f"{n} {_lib.prof_collect(n)['total_ms']/a.iters*1e3:.1f} us/step" for n in ("adam", "grid", "fit_gemm")), flush=True)
-_lib.prof_enable([])
-# host-side enqueue cost with the GPU idle-ish: tiny number of steps
-eng.reset(g)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-eng.fit(feat, xy, idx, log_every=0, step_begin=0, step_end=50)
-print(f"host enqueue of 50 steps (queue not full): {(time.perf_counter()-t0)/50*1e6:.1f} us/step", flush=True)
-torch.cuda.synchronize()
-print({i: v for i, v in eng.loss_log().items()})
+run_once("single fit")
+# k batched fits (shared launches, dvt_fit_run_batched)
+for k in (2, 3, 4)[: max(0, a.concurrent - 1)]:
+    engines = [eng] + [FitEngine(s, n_rows, dev) for _ in range(k - 1)]
+    for rep in range(a.reps):
+        for e in engines:
+            e.reset(g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fit_many(engines, [feat] * k, [xy] * k, None, log_every=1000)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+    print(f"{k} batched fits: {t/a.iters*1e6:.1f} us/step = {t/a.iters*1e6/k:.1f} us/step/image", flush=True)
+    del engines
