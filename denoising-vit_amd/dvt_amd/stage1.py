@@ -18,6 +18,8 @@ import argparse
 import glob
 import json
 import os
+import queue
+import threading
 import time
 
 import numpy as np
@@ -158,6 +160,7 @@ class Stage1:
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
         self.timings = []
+        self._idx_spare = []  # index streams drawn ahead for the next fit (numpy stream order kept)
 
     # -- single-image pieces (each enqueues on the CURRENT stream) -------------------------
     def extract(self, slot: _Slot) -> None:
@@ -169,11 +172,14 @@ class Stage1:
     def fit(self, slot: _Slot, log_every: int = 1000) -> torch.Tensor:
         """denoise_an_image (:28-149): fresh models, the loop, then F on the original image's
         lattice (quirk Q7).  Returns denoised_feats [1, H, W, C] (device)."""
+        return self.fit_group([slot], log_every)[0]
+
+    def _draw_indices(self, k: int):
+        """k index streams from the reference's numpy stream (main_img_denoising.py:73), in image
+        order.  Drawn one group AHEAD (while the GPU drains the tail of the previous fit): 2 M
+        draws cost ~20 ms of host time that would otherwise sit between two fits."""
         e = self.engine
-        e.reset(self.gen)
-        C = self.feat_dim
-        e.fit(slot.features.view(-1, C), slot.coords.view(-1, 2), None, log_every=log_every)
-        return e.infer(slot.coords[-1]).unsqueeze(0)
+        return [e.sample_indices(e.cfg.n_rows, e.s.num_iters, e.s.pixel_bsz) for _ in range(k)]
 
     def fit_group(self, group, log_every: int = 1000):
         """The fits of up to `fit_batch` images advanced together (shared launches).  Models are
@@ -181,66 +187,113 @@ class Stage1:
         order (numpy RNG) -- the draws of the reference's sequential loop."""
         engines = self.engines[:len(group)]
         C = self.feat_dim
+        t0 = time.perf_counter()
+        spare, self._idx_spare = self._idx_spare, []
+        idxs = spare[:len(group)] + self._draw_indices(max(0, len(group) - len(spare)))
+        t1 = time.perf_counter()
         for e in engines:
             e.reset(self.gen)
+        t2 = time.perf_counter()
         fit_many(engines, [sl.features.view(-1, C) for sl in group],
-                 [sl.coords.view(-1, 2) for sl in group], None, log_every=log_every)
-        return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
+                 [sl.coords.view(-1, 2) for sl in group], idxs, log_every=log_every)
+        t3 = time.perf_counter()
+        out = [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
+        if os.environ.get("DVT_DEBUG_TIMING"):
+            print(f"[host] draw {1e3*(t1-t0):.1f} reset {1e3*(t2-t1):.1f} fit_many {1e3*(t3-t2):.1f} "
+                  f"infer {1e3*(time.perf_counter()-t3):.1f} ms at {time.perf_counter():.3f}", flush=True)
+        return out
 
     # -- the pipeline --------------------------------------------------------------------------
     def run(self, jobs, on_result=None, log_every: int = 1000) -> int:
         """jobs: iterable of (tag, set_views) with set_views(slot) filling slot.views / slot.coords
-        (called with `s_vit` current).  on_result(tag, raw_host, den_host) is called on the host
-        once an image's outputs have landed in pinned memory.  Returns the number of images."""
-        kb, depth = self.fit_batch, self.depth
-        pending = []  # groups whose fit has been enqueued, in order
-        done = 0
+        (called with `s_vit` current).  on_result(tag, raw_host, den_host) is called (on the
+        retiring thread) once an image's outputs have landed in pinned memory.  Returns the number
+        of images.
 
-        def retire(group):
-            nonlocal done
-            group[-1].fitted.synchronize()  # recorded after the whole group's D2H copies
-            for slot in group:
-                if on_result is not None:
-                    on_result(slot.tag, slot.raw_host.numpy(), slot.den_host.numpy())
-                done += 1
+        Three host threads: the EXTRACTOR walks `jobs` and enqueues view synthesis + ViT on
+        `s_vit`; the calling thread enqueues the fits on `s_fit`; the RETIRER waits for finished
+        images, hands them to `on_result` (the .npy writer) and recycles their buffers.  With one
+        thread the ~10 k launches of a fit back-pressure the host for most of the fit's duration
+        and both streams idled 60-85 ms per image waiting for it."""
+        kb, dev = self.fit_batch, self.device
+        free, ready, fitted = queue.Queue(), queue.Queue(), queue.Queue()
+        for slot in self.slots:
+            free.put(slot)
+        errors = []
+        done = [0]
 
-        def enqueue_fit(group):
-            with torch.cuda.stream(self.s_fit):
-                for slot in group:
-                    self.s_fit.wait_event(slot.extracted)
-                dens = self.fit_group(group, log_every)
-                for slot, den in zip(group, dens):
-                    slot.raw_host.copy_(slot.features[-1], non_blocking=True)
-                    slot.den_host.copy_(den, non_blocking=True)
-                group[-1].fitted.record(self.s_fit)
-            pending.append(group)
+        def extractor():
+            try:
+                torch.cuda.set_device(dev)
+                for tag, set_views in jobs:
+                    slot = free.get()
+                    if slot is None:  # another thread failed
+                        return
+                    slot.tag = tag
+                    with torch.cuda.stream(self.s_vit):
+                        set_views(slot)
+                        self.extract(slot)
+                        slot.extracted.record(self.s_vit)
+                    ready.put(slot)
+            except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread
+                errors.append(e)
+            finally:
+                ready.put(None)
 
-        prev, cur = None, []
-        for n, (tag, set_views) in enumerate(jobs):
-            g, j = divmod(n, kb)
-            slot = self.slots[(g % depth) * kb + j]
-            # the group that used this slot set before must have left the pipeline
-            while any(slot in grp for grp in pending):
-                retire(pending.pop(0))
-            slot.tag = tag
-            with torch.cuda.stream(self.s_vit):
-                set_views(slot)
-                self.extract(slot)
-                slot.extracted.record(self.s_vit)
-            cur.append(slot)
-            if len(cur) == kb:
-                # the extractors of group g are enqueued BEFORE the (long, back-pressured) fit
-                # enqueue of group g-1
-                if prev is not None:
-                    enqueue_fit(prev)
-                prev, cur = cur, []
-        if prev is not None:
-            enqueue_fit(prev)
-        if cur:
-            enqueue_fit(cur)
-        while pending:
-            retire(pending.pop(0))
-        return done
+        def retirer():
+            try:
+                torch.cuda.set_device(dev)
+                while True:
+                    group = fitted.get()
+                    if group is None:
+                        return
+                    group[-1].fitted.synchronize()  # recorded after the whole group's D2H copies
+                    for slot in group:
+                        if on_result is not None:
+                            on_result(slot.tag, slot.raw_host.numpy(), slot.den_host.numpy())
+                        done[0] += 1
+                        free.put(slot)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                free.put(None)
+
+        threads = [threading.Thread(target=extractor, name="dvt-extractor", daemon=True),
+                   threading.Thread(target=retirer, name="dvt-retirer", daemon=True)]
+        for th in threads:
+            th.start()
+        try:
+            last = False
+            while not last and not errors:
+                group = []
+                while len(group) < kb:
+                    slot = ready.get()
+                    if slot is None:
+                        last = True
+                        break
+                    group.append(slot)
+                if not group:
+                    break
+                with torch.cuda.stream(self.s_fit):
+                    for slot in group:
+                        self.s_fit.wait_event(slot.extracted)
+                    dens = self.fit_group(group, log_every)
+                    for slot, den in zip(group, dens):
+                        slot.raw_host.copy_(slot.features[-1], non_blocking=True)
+                        slot.den_host.copy_(den, non_blocking=True)
+                    group[-1].fitted.record(self.s_fit)
+                fitted.put(group)
+                if not last:  # next group's index streams, while the GPU finishes this fit
+                    self._idx_spare = self._draw_indices(kb)
+        except BaseException:
+            free.put(None)  # unblock the extractor thread
+            raise
+        finally:
+            fitted.put(None)
+            for th in threads:
+                th.join()
+        if errors:
+            raise errors[0]
+        return done[0]
 
     def process(self, set_views, save_paths=None):
         """Strictly serial single image (reference flow) with the two timers of :341, :355."""
@@ -275,6 +328,11 @@ def main(args, rank: int = 0, world: int = 1):
     st = Stage1(args, device, fit_batch=getattr(args, "fit_batch", 1))
     norm = st.vit.transformation.transforms[-1]
     start = time.time()
+    # Crop parameters come from their own generator: in the reference they are drawn by the
+    # DataLoader worker processes (own seeds), not from the main process' numpy stream, which
+    # serves only the fit's index draws (main_img_denoising.py:73) -- and here the two are
+    # consumed by different host threads.
+    view_rng = np.random.RandomState(args.seed + 1000003 * (rank + 1))
 
     def jobs():
         for idx, filename in enumerate(names):
@@ -296,7 +354,7 @@ def main(args, rank: int = 0, world: int = 1):
                 else:
                     img = V.load_image(filename, args.input_size, norm.mean, norm.std, device)
                     boxes, coords = V.sample_view_boxes(args.num_views, args.input_size, st.pos_h,
-                                                        st.pos_w)
+                                                        st.pos_w, rng=view_rng)
                     V.render_views(img, boxes, slot.views)
                     slot.coords.copy_(coords.to(device), non_blocking=True)
 
