@@ -57,6 +57,9 @@ def parse():
                    help="images whose fits share launches (dvt_fit_run_batched); 1 = one fit at a time "
                         "(measured: 1.94 / 1.93 / 1.87 images/s at 1 / 2 / 4 -- the step is throughput-, "
                         "not launch-latency-bound)")
+    p.add_argument("--fit-dtype", default="bfloat16", choices=["bfloat16", "float32"],
+                   help="operand precision of the fit's MLP GEMMs (the reference's --dtype; bfloat16 = its "
+                        "autocast mode, which the ViT of this bench always runs in)")
     p.add_argument("--pixel-bsz", type=int, default=2048,
                    help="developer experiment only: anything but 2048 is not BASELINE's workload")
     p.add_argument("--pipeline-depth", type=int, default=2,
@@ -69,7 +72,7 @@ def stage1_args(a):
         model=a.model, input_size=(518, 518), stride_size=14, layer_depth_ratio=1.0,
         num_views=a.views, num_iters=a.num_iters, warmup_iters=a.warmup_iters, n_levels=16,
         freeze_shared_artifacts_after=0.5, lr=0.01, min_lr=0.001, weight_decay=1e-5,
-        extract_bsz=32, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None)
+        extract_bsz=32, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None, dtype=a.fit_dtype)
 
 
 def cpu_baseline(a):
@@ -194,7 +197,11 @@ def main():
                             "1k-step per-image fit (B=2048, L=16, F=8, 2^20 hash) on 1 MI355X per rank",
                 "model": a.model, "views": a.views + 1, "num_iters": a.num_iters,
                 "warmup_iters": a.warmup_iters, "pixel_bsz": a.pixel_bsz,
-                "arithmetic": "ViT: bf16 MFMA / fp32 accumulate; fit: fp32 (f32-input MFMA, fp32 Adam)",
+                "arithmetic": ("ViT: bf16 MFMA / fp32 accumulate; fit MLP GEMMs: " +
+                               ("bf16 operands / fp32 accumulate + outputs (reference --dtype bfloat16 autocast)"
+                                if a.fit_dtype == "bfloat16" else "fp32-operand MFMA") +
+                               "; hash grid, losses, Adam: fp32"),
+                "fit_dtype": a.fit_dtype,
                 "weights": "random init (no network for checkpoints)",
                 "t_extract_s_serial": t_ext / a.steps, "t_fit_s_serial": t_fit / a.steps,
                 "pipeline_depth": a.pipeline_depth, "fit_batch": a.fit_batch,

@@ -86,6 +86,7 @@ struct DvtLinearOp {
   float* dx;
   int m, n, k, relu;
 };
-int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s);
+// bf16_operands: round operands to bf16 while staging (autocast semantics), fp32 otherwise
+int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s, int bf16_operands = 0);
 int dvt_fit_prep(const DvtGridTable* tbl, const float* xy, const int32_t* ridx, const float* params,
                  float* enc, const float* feat, float* raw, int n, int c, hipStream_t stream);

@@ -192,7 +192,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
   };
   DvtLinearOp ops[4 * KM];
   int n_ops;
-  auto launch = [&]() { return dvt_linear_group(ops, n_ops, s); };
+  auto launch = [&]() { return dvt_linear_group(ops, n_ops, s, c->mlp_bf16); };
   n_ops = 0;
   for (int f = 0; f < k; ++f) {
     const Work& w = ws[f];

@@ -229,6 +229,167 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(MultiArgs m) {
 }
 
 // ==========================================================================================
+// bf16-operand variant of the grouped body (DvtFitConfig.mlp_bf16, the reference's
+// `--dtype bfloat16` autocast mode: nn.Linear runs on bf16 casts of fp32 master weights and
+// activations; main_img_denoising.py:78).  Operands stay fp32 in HBM and are rounded to bf16
+// (RNE, v_cvt_pk_bf16_f32) while they are staged into LDS; accumulation, bias, ReLU, masks and
+// every output stay fp32 -- i.e. at least the reference's precision (autocast additionally rounds
+// each layer output to bf16).  The fp32-operand body above is MFMA-rate bound: one
+// v_mfma_f32_32x32x2_f32 (64 cycles) per 2 k per wave, a K = 768 contraction is a dependent chain
+// of 24.6 k cycles, ~10 us, whatever the tile/BK/staging (measured).  v_mfma_f32_32x32x16_bf16
+// covers 16 k in 32 cycles: the same chain is 1.5 k cycles.
+// 64 x 64 tile, 2 x 2 waves, BK = 64 (32 / 128 selectable).  LDS rows are k-contiguous bf16, pitch BK + 8
+// (conflict-free ds_read_b128 of a lane's 8 k); row-contiguous sources (k slow) are transposed on
+// the way in: a thread loads (k, k+1) for 4 rows and writes four packed bf16x2 words.
+// ==========================================================================================
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  const hwbf16x2_t v = __builtin_convertvector((f32x2_t){a, b}, hwbf16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+template <bool KCONTIG, int HBK>
+struct TileH {
+  static constexpr int HP = HBK + 8;        // bf16 elements per LDS row
+  static constexpr int ITERS = HBK / 16;    // float4 per thread per operand tile (256 threads)
+  __device__ static __forceinline__ void load(const float* __restrict__ X, int ld, int r0, int Rmax,
+                                              int k0, int kend, int tid, float4 regs[ITERS]) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KCONTIG) {
+        const int f = tid + 256 * i, r = f / (HBK / 4), kq = f % (HBK / 4);
+        const int gr = r0 + r, gk = k0 + 4 * kq;
+        if (gr < Rmax && gk < kend) v = *reinterpret_cast<const float4*>(X + (size_t)gr * ld + gk);
+      } else {  // regs[2 * it + par] = rows 4*rq .. +3 at k = 2 * (kp + 16 * it) + par
+        const int kp = (tid >> 4) + 16 * (i >> 1), rq = tid & 15;
+        const int gk = k0 + 2 * kp + (i & 1), gr = r0 + 4 * rq;
+        if (gk < kend && gr < Rmax) v = *reinterpret_cast<const float4*>(X + (size_t)gk * ld + gr);
+      }
+      regs[i] = v;
+    }
+  }
+  __device__ static __forceinline__ void store(uint16_t* __restrict__ S, int tid, const float4 regs[ITERS]) {
+    if (KCONTIG) {
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        const int f = tid + 256 * i, r = f / (HBK / 4), kq = f % (HBK / 4);
+        uint2 w;
+        w.x = pack_bf16x2(regs[i].x, regs[i].y);
+        w.y = pack_bf16x2(regs[i].z, regs[i].w);
+        *reinterpret_cast<uint2*>(S + r * HP + 4 * kq) = w;
+      }
+    } else {
+      const int rq = tid & 15;
+      uint32_t* S32 = reinterpret_cast<uint32_t*>(S);
+#pragma unroll
+      for (int it = 0; it < ITERS / 2; ++it) {
+        const int kp = (tid >> 4) + 16 * it;
+        const float4 lo = regs[2 * it], hi = regs[2 * it + 1];
+        S32[((4 * rq + 0) * HP >> 1) + kp] = pack_bf16x2(lo.x, hi.x);
+        S32[((4 * rq + 1) * HP >> 1) + kp] = pack_bf16x2(lo.y, hi.y);
+        S32[((4 * rq + 2) * HP >> 1) + kp] = pack_bf16x2(lo.z, hi.z);
+        S32[((4 * rq + 3) * HP >> 1) + kp] = pack_bf16x2(lo.w, hi.w);
+      }
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC, int HBK>
+__device__ __forceinline__ void gemm_bf16op_body(const GemmArgs& p, int bx, int by, int bz,
+                                                 uint16_t* __restrict__ As, uint16_t* __restrict__ Bs) {
+  using TA = TileH<A_KC, HBK>;
+  using TB = TileH<B_KC, HBK>;
+  constexpr int HP = TA::HP, NR = TA::ITERS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = bx * 64, m0 = by * 64;
+  const int kbeg = bz * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  if (kbeg >= kend) return;
+
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float csum = 0.f;
+  const bool do_colsum = (!A_KC) && p.colsum != nullptr && bx == 0;
+
+  float4 ra[NR], rb[NR];
+  TA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
+  TB::load(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+  // fragment addresses: MFMA step s of a tile uses k = kh * (HBK / 2) + s * 8 + j (j = 0..7, kh = lane >> 5)
+  const int kh = lane >> 5;
+  const uint16_t* pa = As + (wm * 32 + (lane & 31)) * HP + kh * (HBK / 2);
+  const uint16_t* pb = Bs + (wn * 32 + (lane & 31)) * HP + kh * (HBK / 2);
+  for (int k0 = kbeg; k0 < kend; k0 += HBK) {
+    TA::store(As, tid, ra);
+    TB::store(Bs, tid, rb);
+    __syncthreads();
+    if (k0 + HBK < kend) {  // prefetch the next tile while the MFMAs run
+      TA::load(p.A, p.lda, m0, p.M, k0 + HBK, kend, tid, ra);
+      TB::load(p.B, p.ldb, n0, p.N, k0 + HBK, kend, tid, rb);
+    }
+    bf16x8_t fa[HBK / 16], fb[HBK / 16];
+#pragma unroll
+    for (int q = 0; q < HBK / 16; ++q) {
+      fa[q] = *reinterpret_cast<const bf16x8_t*>(pa + 8 * q);
+      fb[q] = *reinterpret_cast<const bf16x8_t*>(pb + 8 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < HBK / 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q], fb[q], acc, 0, 0, 0);
+    if (do_colsum && tid < 64) {  // bias gradient: column sums of the staged (bf16-rounded) dy tile
+      const uint32_t* row = reinterpret_cast<const uint32_t*>(As + tid * HP);
+#pragma unroll
+      for (int k = 0; k < HBK / 2; ++k) {
+        const uint32_t w = row[k];
+        csum += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+      }
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int gn = n0 + wn * 32 + (lane & 31);
+  const float bias = (p.bias != nullptr && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int gm = m0 + wm * 32 + row;
+    if (gm < p.M && gn < p.N) {
+      float v = acc[r] + bias;
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.mask != nullptr) v = p.mask[(size_t)gm * p.ldmask + gn] > 0.f ? v : 0.f;
+      float* c = p.C + (size_t)gm * p.ldc + gn;
+      if (p.atomic)
+        atomic_add_f32(c, v);
+      else
+        *c = v;
+    }
+  }
+  if (do_colsum && tid < 64 && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
+}
+
+template <int HBK>
+__global__ __launch_bounds__(256) void gemm_bf16op_multi_kernel(MultiArgs m) {
+  __shared__ __attribute__((aligned(16))) uint16_t As[64 * (HBK + 8)];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[64 * (HBK + 8)];
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < MULTI_MAX; ++j)
+    if (j < m.n && (int)blockIdx.x >= m.blk0[j]) i = j;
+  const int local = (int)blockIdx.x - m.blk0[i];
+  const int bx = local % m.gx[i], by = (local / m.gx[i]) % m.gy[i], bz = local / (m.gx[i] * m.gy[i]);
+  switch (m.layout[i]) {
+    case 0: gemm_bf16op_body<true, true, HBK>(m.g[i], bx, by, bz, As, Bs); break;
+    case 1: gemm_bf16op_body<true, false, HBK>(m.g[i], bx, by, bz, As, Bs); break;
+    default: gemm_bf16op_body<false, false, HBK>(m.g[i], bx, by, bz, As, Bs); break;
+  }
+}
+
+// ==========================================================================================
 // 3-stage LDS-DMA variant (used when K % 64 == 0 and row-contiguous operands are 64-aligned).
 // PMC evidence for the register-staged kernel above at the fit's shapes: L2 hit rate 43 % (the
 // operands were just written by other XCDs' kernels), waves 45-54 % in s_waitcnt, MFMA pipe
@@ -464,7 +625,7 @@ GemmArgs make_dgrad(const float* dy, const float* w, float* dx, const float* rel
 
 }  // namespace
 
-int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s) {
+int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s, int bf16_operands) {
   if (!ops || n_ops < 1 || n_ops > MULTI_MAX) return DVT_E_BADARG;
   MultiArgs m{};
   m.n = n_ops;
@@ -494,7 +655,14 @@ int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s) {
   }
   m.blk0[n_ops] = blocks;
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, flops);
-  if (g_f32_bk == 16)
+  if (bf16_operands) {  // BK of the bf16-operand kernel: twice the fp32 knob (same LDS footprint)
+    if (g_f32_bk == 64)
+      hipLaunchKernelGGL(gemm_bf16op_multi_kernel<128>, dim3(blocks), dim3(256), 0, s, m);
+    else if (g_f32_bk == 16)
+      hipLaunchKernelGGL(gemm_bf16op_multi_kernel<32>, dim3(blocks), dim3(256), 0, s, m);
+    else
+      hipLaunchKernelGGL(gemm_bf16op_multi_kernel<64>, dim3(blocks), dim3(256), 0, s, m);
+  } else if (g_f32_bk == 16)
     hipLaunchKernelGGL(gemm_f32_multi_kernel<16>, dim3(blocks), dim3(256), 0, s, m);
   else if (g_f32_bk == 32)
     hipLaunchKernelGGL(gemm_f32_multi_kernel<32>, dim3(blocks), dim3(256), 0, s, m);

@@ -84,7 +84,7 @@ class FitConfig(C.Structure):
         ("num_iters", C.c_int32),
         ("switch_step", C.c_int32),
         ("enable_residual", C.c_int32),
-        ("pad0_", C.c_int32),
+        ("mlp_bf16", C.c_int32),
         ("grad_scale", C.c_double),
         ("beta1", C.c_double),
         ("beta2", C.c_double),

@@ -44,6 +44,10 @@ class FitSettings:
     beta2: float = 0.99
     eps: float = 1e-15
     grid_seed: int = 1337
+    # "float32": fp32-operand MFMA in the MLP GEMMs.  "bfloat16": operands rounded to bf16 while
+    # staged, fp32 accumulation and outputs -- the reference's `--dtype bfloat16` autocast mode
+    # (main_img_denoising.py:78) with fp32 (instead of bf16) layer outputs.
+    mlp_dtype: str = "float32"
 
     @property
     def lattice(self) -> int:
@@ -84,6 +88,9 @@ class FitEngine:
         cfg.num_iters = settings.num_iters
         cfg.switch_step = int(settings.freeze_shared_artifacts_after * settings.num_iters)
         cfg.enable_residual = int(settings.enable_residual_predictor)
+        if settings.mlp_dtype not in ("float32", "bfloat16"):
+            raise _lib.DvtError(f"mlp_dtype must be float32 or bfloat16, not {settings.mlp_dtype!r}")
+        cfg.mlp_bf16 = int(settings.mlp_dtype == "bfloat16")
         cfg.grad_scale = settings.grad_scale
         cfg.beta1, cfg.beta2 = settings.beta1, settings.beta2
         cfg.eps, cfg.weight_decay = settings.eps, settings.weight_decay

@@ -149,7 +149,9 @@ class Stage1:
                         num_iters=args.num_iters, warmup_iters=args.warmup_iters,
                         freeze_shared_artifacts_after=args.freeze_shared_artifacts_after,
                         lr=args.lr, min_lr=args.min_lr, weight_decay=args.weight_decay,
-                        pixel_bsz=args.pixel_bsz)
+                        pixel_bsz=args.pixel_bsz,
+                        mlp_dtype="bfloat16" if str(getattr(args, "dtype", "float32")) in
+                        ("bfloat16", "bf16", "torch.bfloat16") else "float32")
         self.engines = [FitEngine(s, n * self.pos_h * self.pos_w, dev) for _ in range(kb)]
         self.engine = self.engines[0]
         self.gen = torch.Generator(device=dev).manual_seed(args.seed)

@@ -195,7 +195,8 @@ typedef struct DvtFitConfig {
   int32_t num_iters;
   int32_t switch_step;  /* int(freeze_shared_artifacts_after*num_iters); phase 2 iff step > switch_step */
   int32_t enable_residual; /* enable_residual_predictor */
-  int32_t pad0_;
+  int32_t mlp_bf16;        /* 1: the MLP GEMMs of the loop round their operands to bf16 (fp32 accumulate,
+                            * fp32 outputs) = the reference's `--dtype bfloat16` autocast mode; 0: fp32 */
   double grad_scale;    /* 1024: GradScaler quirk, main_img_denoising.py:55,:88 */
   double beta1, beta2, eps, weight_decay;
   DvtGridTable grid;

@@ -33,11 +33,13 @@ def lr_at(step, lr, min_lr, warmup_iters, num_iters):
 
 def fit_image(denoiser, neural_field, all_raw_features, all_pixel_coords, idx_stream, *,
               num_iters, warmup_iters, lr=0.01, min_lr=0.001, weight_decay=1e-5,
-              freeze_shared_artifacts_after=0.5, grad_scale=1024.0, log_every=0):
+              freeze_shared_artifacts_after=0.5, grad_scale=1024.0, log_every=0,
+              autocast_dtype=None):
     """Runs the loop in place on the given modules; returns {step: {loss scalars}}.
 
     all_raw_features [V, H, W, C], all_pixel_coords [V, H, W, 2]; idx_stream [num_iters, B]
-    int (row indices into the flattened [V*H*W] rows, :73)."""
+    int (row indices into the flattened [V*H*W] rows, :73).  autocast_dtype=torch.bfloat16 restates
+    the reference's `--dtype bfloat16` mode (:78 `with autocast(enabled=dtype != float32)`)."""
     H, W = all_raw_features.shape[1:3]
     optimizer = torch.optim.Adam(  # :48-54
         chain(denoiser.parameters(), neural_field.parameters()),
@@ -57,8 +59,10 @@ def fit_image(denoiser, neural_field, all_raw_features, all_pixel_coords, idx_st
         cur = lr_at(step, lr, min_lr, warmup_iters, num_iters)  # :77
         for g in optimizer.param_groups:
             g["lr"] = cur
-        out = denoiser(raw_vit_outputs=raw, global_pixel_coords=xy, neural_field=neural_field,
-                       shared_artifact_coords=sac, return_visualization=False)  # :79-85
+        with torch.autocast("cpu", dtype=autocast_dtype or torch.bfloat16,
+                            enabled=autocast_dtype is not None):  # :78
+            out = denoiser(raw_vit_outputs=raw, global_pixel_coords=xy, neural_field=neural_field,
+                           shared_artifact_coords=sac, return_visualization=False)  # :79-85
         optimizer.zero_grad()  # :87
         (out["loss"] * grad_scale).backward()  # :88 (scale, never unscaled)
         optimizer.step()  # :89

@@ -187,3 +187,54 @@ def test_batched_fits_equal_separate_fits(built_lib, k):
     # fits of one batch must not share state
     with pytest.raises(Exception):
         fit_many([batched[0], batched[0]], fs[:2], cs[:2], idxs[:2])
+
+
+def test_bf16_operand_fit_vs_oracles(built_lib):
+    """FitSettings(mlp_dtype="bfloat16") (= the reference's `--dtype bfloat16`: nn.Linear on bf16 casts,
+    main_img_denoising.py:78) against BOTH oracles on identical initial parameters and index stream:
+    the fp32 loop (north-star tolerance: per-patch cosine >= 0.99 of the saved tensor) and the loop under
+    torch.autocast(bfloat16) that the reference itself would run.  The HIP path keeps layer outputs in
+    fp32, so it must sit at least as close to the fp32 oracle as the autocast oracle does."""
+    from dvt_amd.fit import FitEngine, FitSettings
+    from dvt_amd.models import NeuralFeatureField, SingleImageDenoiser
+    V, H, W, C, B, iters = 9, 7, 7, 64, 256, 80
+    torch.manual_seed(1)
+    np.random.seed(1)
+    feats, xy = synthetic_image(V, H, W, C, seed=5)
+    kw = dict(feat_dim=C, n_levels=16, max_resolution=1024, log2_hashmap_size=12)
+    f32_f, f32_d = NeuralFeatureFieldOracle(**kw), SingleImageDenoiserOracle(H, W, C, 3)
+    ac_f, ac_d = NeuralFeatureFieldOracle(**kw), SingleImageDenoiserOracle(H, W, C, 3)
+    ac_f.load_state_dict(f32_f.state_dict())
+    ac_d.load_state_dict(f32_d.state_dict())
+    n_rows = V * H * W
+    idx = FitEngine.sample_indices(n_rows, iters, B)
+    f_h, d_h = NeuralFeatureField(**kw), SingleImageDenoiser(H, W, C, 3)
+    f_h.load_state_dict(f32_f.state_dict())
+    d_h.load_state_dict(f32_d.state_dict())
+    outs, logs = {}, {}
+    for mode in ("float32", "bfloat16"):
+        s = FitSettings(feat_dim=C, noise_map_height=H, noise_map_width=W, n_levels=16, log2_hashmap_size=12,
+                        num_iters=iters, warmup_iters=8, pixel_bsz=B, mlp_dtype=mode)
+        eng = FitEngine(s, n_rows, DEV)
+        assert int(eng.cfg.mlp_bf16) == (mode == "bfloat16")
+        eng.load_modules(d_h.to(DEV), f_h.to(DEV))
+        eng.fit(feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV), idx, log_every=1)
+        torch.cuda.synchronize()
+        outs[mode] = eng.infer(xy[-1].to(DEV)).cpu()
+        logs[mode] = eng.loss_log()
+    want32_log = ofit.fit_image(f32_d, f32_f, feats, xy, idx, num_iters=iters, warmup_iters=8, log_every=1)
+    ofit.fit_image(ac_d, ac_f, feats, xy, idx, num_iters=iters, warmup_iters=8, autocast_dtype=torch.bfloat16)
+    want32 = ofit.final_denoised_feats(f32_d, f32_f, feats, xy)[0]
+    want_ac = ofit.final_denoised_feats(ac_d, ac_f, feats, xy)[0]
+    cos_h = per_patch_cos(outs["bfloat16"], want32)
+    cos_ac = per_patch_cos(want_ac, want32)
+    cos_hh = per_patch_cos(outs["bfloat16"], outs["float32"])
+    print(f"bf16-operand fit vs fp32 oracle: cos mean {cos_h.mean():.6f} min {cos_h.min():.6f}; "
+          f"autocast oracle vs fp32 oracle: mean {cos_ac.mean():.6f} min {cos_ac.min():.6f}; "
+          f"HIP bf16 vs HIP fp32: min {cos_hh.min():.6f}")
+    assert cos_h.mean() >= 0.999 and cos_h.min() >= 0.99          # the north-star tolerance
+    assert cos_h.min() >= cos_ac.min() - 2e-3                      # no worse than the reference's own bf16 mode
+    assert not torch.equal(outs["bfloat16"], outs["float32"])      # the flag really switches kernels
+    for step in (0, 5, iters // 2 + 3, iters - 1):                 # losses track the fp32 loop
+        a, b = logs["bfloat16"][step]["loss"], want32_log[step]["loss"]
+        assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (step, a, b)
