@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(MultiArgs m) {
 // v_mfma_f32_32x32x2_f32 (64 cycles) per 2 k per wave, a K = 768 contraction is a dependent chain
 // of 24.6 k cycles, ~10 us, whatever the tile/BK/staging (measured).  v_mfma_f32_32x32x16_bf16
 // covers 16 k in 32 cycles: the same chain is 1.5 k cycles.
-// 64 x 64 tile, 2 x 2 waves, BK = 64 (32 / 128 selectable).  LDS rows are k-contiguous bf16, pitch BK + 8
+// 64 x 64 tile, 2 x 2 waves, BK = 32 (64 selectable).  LDS rows are k-contiguous bf16, pitch BK + 8
 // (conflict-free ds_read_b128 of a lane's 8 k); row-contiguous sources (k slow) are transposed on
 // the way in: a thread loads (k, k+1) for 4 rows and writes four packed bf16x2 words.
 // ==========================================================================================
@@ -249,6 +249,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   const hwbf16x2_t v = __builtin_convertvector((f32x2_t){a, b}, hwbf16x2_t);
   return __builtin_bit_cast(uint32_t, v);
 }
+
 
 template <bool KCONTIG, int HBK>
 struct TileH {
@@ -317,43 +318,57 @@ __device__ __forceinline__ void gemm_bf16op_body(const GemmArgs& p, int bx, int 
   float csum = 0.f;
   const bool do_colsum = (!A_KC) && p.colsum != nullptr && bx == 0;
 
-  float4 ra[NR], rb[NR];
-  TA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
-  TB::load(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+  // Cycle stamps of one workgroup (K = 384 .. 768): ~2000 cycles from a tile's global loads to its
+  // MFMAs, i.e. with one tile in flight every k-step costs a full memory latency (0.85 us x 6-12
+  // steps), and another ~2500 cycles of the epilogue went to the bias / mask loads.  Hence TWO
+  // tiles in flight (register sets r0 / r1) and the epilogue operands requested up front.
+  float4 ra0[NR], rb0[NR], ra1[NR], rb1[NR];
+  TA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra0);
+  TB::load(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb0);
+  TA::load(p.A, p.lda, m0, p.M, kbeg + HBK, kend, tid, ra1);  // past kend: zeros, no memory access
+  TB::load(p.B, p.ldb, n0, p.N, kbeg + HBK, kend, tid, rb1);
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int gn = n0 + wn * 32 + (lane & 31);
+  const float bias = (p.bias != nullptr && gn < p.N) ? p.bias[gn] : 0.f;
+  float mk[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    mk[r] = (p.mask != nullptr && gm < p.M && gn < p.N) ? p.mask[(size_t)gm * p.ldmask + gn] : 1.f;
+  }
   // fragment addresses: MFMA step s of a tile uses k = kh * (HBK / 2) + s * 8 + j (j = 0..7, kh = lane >> 5)
   const int kh = lane >> 5;
   const uint16_t* pa = As + (wm * 32 + (lane & 31)) * HP + kh * (HBK / 2);
   const uint16_t* pb = Bs + (wn * 32 + (lane & 31)) * HP + kh * (HBK / 2);
-  for (int k0 = kbeg; k0 < kend; k0 += HBK) {
-    TA::store(As, tid, ra);
-    TB::store(Bs, tid, rb);
-    __syncthreads();
-    if (k0 + HBK < kend) {  // prefetch the next tile while the MFMAs run
-      TA::load(p.A, p.lda, m0, p.M, k0 + HBK, kend, tid, ra);
-      TB::load(p.B, p.ldb, n0, p.N, k0 + HBK, kend, tid, rb);
-    }
-    bf16x8_t fa[HBK / 16], fb[HBK / 16];
-#pragma unroll
-    for (int q = 0; q < HBK / 16; ++q) {
-      fa[q] = *reinterpret_cast<const bf16x8_t*>(pa + 8 * q);
-      fb[q] = *reinterpret_cast<const bf16x8_t*>(pb + 8 * q);
-    }
-#pragma unroll
-    for (int q = 0; q < HBK / 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q], fb[q], acc, 0, 0, 0);
-    if (do_colsum && tid < 64) {  // bias gradient: column sums of the staged (bf16-rounded) dy tile
-      const uint32_t* row = reinterpret_cast<const uint32_t*>(As + tid * HP);
-#pragma unroll
-      for (int k = 0; k < HBK / 2; ++k) {
-        const uint32_t w = row[k];
-        csum += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
-      }
-    }
-    __syncthreads();
+#define H_STEP(RA, RB, KNEXT)                                                                  \
+  do {                                                                                         \
+    TA::store(As, tid, RA);                                                                    \
+    TB::store(Bs, tid, RB);                                                                    \
+    __syncthreads();                                                                           \
+    TA::load(p.A, p.lda, m0, p.M, (KNEXT), kend, tid, RA); /* two tiles ahead */               \
+    TB::load(p.B, p.ldb, n0, p.N, (KNEXT), kend, tid, RB);                                     \
+    bf16x8_t fa[HBK / 16], fb[HBK / 16];                                                       \
+    _Pragma("unroll") for (int q = 0; q < HBK / 16; ++q) {                                     \
+      fa[q] = *reinterpret_cast<const bf16x8_t*>(pa + 8 * q);                                  \
+      fb[q] = *reinterpret_cast<const bf16x8_t*>(pb + 8 * q);                                  \
+    }                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < HBK / 16; ++q)                                       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q], fb[q], acc, 0, 0, 0);             \
+    if (do_colsum && tid < 64) { /* bias gradient: column sums of the staged (bf16) dy tile */ \
+      const uint32_t* row = reinterpret_cast<const uint32_t*>(As + tid * HP);                  \
+      _Pragma("unroll") for (int k = 0; k < HBK / 2; ++k) {                                    \
+        const uint32_t w = row[k];                                                             \
+        csum += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);                   \
+      }                                                                                        \
+    }                                                                                          \
+    __syncthreads();                                                                           \
+  } while (0)
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * HBK) {
+    H_STEP(ra0, rb0, k0 + 2 * HBK);
+    if (k0 + HBK < kend) H_STEP(ra1, rb1, k0 + 3 * HBK);
   }
+#undef H_STEP
 
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const int gn = n0 + wn * 32 + (lane & 31);
-  const float bias = (p.bias != nullptr && gn < p.N) ? p.bias[gn] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -361,7 +376,7 @@ __device__ __forceinline__ void gemm_bf16op_body(const GemmArgs& p, int bx, int 
     if (gm < p.M && gn < p.N) {
       float v = acc[r] + bias;
       if (p.relu) v = fmaxf(v, 0.f);
-      if (p.mask != nullptr) v = p.mask[(size_t)gm * p.ldmask + gn] > 0.f ? v : 0.f;
+      v = mk[r] > 0.f ? v : 0.f;
       float* c = p.C + (size_t)gm * p.ldc + gn;
       if (p.atomic)
         atomic_add_f32(c, v);
@@ -655,13 +670,13 @@ int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s, int bf16_
   }
   m.blk0[n_ops] = blocks;
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, flops);
-  if (bf16_operands) {  // BK of the bf16-operand kernel: twice the fp32 knob (same LDS footprint)
+  if (bf16_operands) {
+    // BK = 32 (80 VGPRs, 10 KB of LDS): fits beside the extractor's workgroups; BK = 64 (146 VGPRs)
+    // is equally fast alone (214 vs 215 us/step) and slower in the pipeline (2.09 vs 2.12 images/s)
     if (g_f32_bk == 64)
-      hipLaunchKernelGGL(gemm_bf16op_multi_kernel<128>, dim3(blocks), dim3(256), 0, s, m);
-    else if (g_f32_bk == 16)
-      hipLaunchKernelGGL(gemm_bf16op_multi_kernel<32>, dim3(blocks), dim3(256), 0, s, m);
-    else
       hipLaunchKernelGGL(gemm_bf16op_multi_kernel<64>, dim3(blocks), dim3(256), 0, s, m);
+    else
+      hipLaunchKernelGGL(gemm_bf16op_multi_kernel<32>, dim3(blocks), dim3(256), 0, s, m);
   } else if (g_f32_bk == 16)
     hipLaunchKernelGGL(gemm_f32_multi_kernel<16>, dim3(blocks), dim3(256), 0, s, m);
   else if (g_f32_bk == 32)
