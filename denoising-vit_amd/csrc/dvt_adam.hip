@@ -51,6 +51,14 @@ __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, flo
 
 // Each wave handles 64 consecutive float4 (256 floats, one bitmap word) per iteration; all
 // active tensor groups (different step counts t) are covered by ONE launch.
+struct AdamGather {  // device view of DvtAdamRowGather
+  long long q_begin, q_end;  // float4 range of G
+  int c, lattice;
+  const int32_t* offs[DVT_FIT_BATCH_MAX];
+  const uint16_t* perm[DVT_FIT_BATCH_MAX];
+  const float4* rows[DVT_FIT_BATCH_MAX];
+};
+
 struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
   float4* P[DVT_FIT_BATCH_MAX];
   float4* M[DVT_FIT_BATCH_MAX];
@@ -59,7 +67,7 @@ struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
   uint32_t* touched[DVT_FIT_BATCH_MAX];
 };
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, AdamGather gr) {
   float4* __restrict__ P = q.P[blockIdx.y];
   float4* __restrict__ M = q.M[blockIdx.y];
   float4* __restrict__ V = q.V[blockIdx.y];
@@ -88,7 +96,26 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q) {
       has = (word >> (lane >> 1)) & 1u;
     }
     float4 p = P[q], m = M[q], v = V[q];
-    if (has) g = G[q];
+    const bool gathered = q0 >= gr.q_begin && q0 < gr.q_end;  // wave-uniform: chunk inside G
+    if (gathered) {
+      // dG[row] = sum of the d_pred rows of this step's samples on lattice row `row`
+      const int e = (int)(q - gr.q_begin) * 4, row = e / gr.c, col4 = (e - row * gr.c) >> 2;
+      const int32_t* offs = gr.offs[blockIdx.y];
+      const uint16_t* perm = gr.perm[blockIdx.y];
+      const float4* rows = gr.rows[blockIdx.y];
+      const int cq = gr.c >> 2;
+      const bool real = row < gr.lattice;  // alignment padding behind the last row has no gradient
+      for (int o = real ? offs[row] : 0, oe = real ? offs[row + 1] : 0; o < oe; ++o) {
+        const float4 d = rows[(size_t)perm[o] * cq + col4];
+        g.x += d.x;
+        g.y += d.y;
+        g.z += d.z;
+        g.w += d.w;
+      }
+      has = false;  // nothing to clear in the dense gradient buffer
+    } else if (has) {
+      g = G[q];
+    }
     adam1(p.x, m.x, v.x, g.x, a.wd, one_m_b1, a.beta2, one_m_b2, bc2s, a.eps, neg_step);
     adam1(p.y, m.y, v.y, g.y, a.wd, one_m_b1, a.beta2, one_m_b2, bc2s, a.eps, neg_step);
     adam1(p.z, m.z, v.z, g.z, a.wd, one_m_b1, a.beta2, one_m_b2, bc2s, a.eps, neg_step);
@@ -114,7 +141,8 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
 }
 
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
-                    float* const* g, uint32_t* const* touched, hipStream_t stream) {
+                    float* const* g, uint32_t* const* touched, hipStream_t stream,
+                    const DvtAdamRowGather* gather) {
   if (!h || k < 1 || k > DVT_FIT_BATCH_MAX || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
     return DVT_E_BADARG;
   if (h->sparse_end & 255) return DVT_E_BADARG;
@@ -126,6 +154,22 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
     q.V[f] = (float4*)v[f];
     q.G[f] = (float4*)g[f];
     q.touched[f] = touched[f];
+  }
+  AdamGather gr{};
+  gr.q_begin = gr.q_end = -1;
+  if (gather != nullptr && gather->rows[0] != nullptr) {
+    if ((gather->begin & 255) || (gather->end & 255) || gather->c <= 0 || (gather->c & 3))
+      return DVT_E_BADARG;
+    gr.q_begin = gather->begin / 4;
+    gr.q_end = gather->end / 4;
+    gr.c = gather->c;
+    gr.lattice = gather->lattice;
+    for (int f = 0; f < k; ++f) {
+      if (!gather->offs[f] || !gather->perm[f] || !gather->rows[f]) return DVT_E_BADARG;
+      gr.offs[f] = gather->offs[f];
+      gr.perm[f] = gather->perm[f];
+      gr.rows[f] = (const float4*)gather->rows[f];
+    }
   }
   AdamKArgs a{};
   a.zero_all = g_adam_zero_all;
@@ -164,7 +208,7 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
   if (blocks > 256 * 16) blocks = 256 * 16;
   {
     DvtProbeScope probe(DVT_PROBE_ADAM, stream, work * k);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
     DVT_CHECK_LAUNCH();
   }
   return 0;

@@ -49,8 +49,24 @@ int dvt_loss_launch_k(int k, const float* const* F, const float* const* G, const
                       int lattice, const float* const* Hres, const float* const* raw_rows,
                       float* const* d_pred, float* const* d_hres, float* const* d_G,
                       float* const* row_sums, int n, int c, float grad_scale, hipStream_t s);
+// Gradient of the shared-artifact map G gathered inside Adam instead of scattered with atomics by the
+// loss kernel: G row r of step t receives the d_pred rows of the samples listed in
+// perm[offs[r] .. offs[r + 1]) (built once per run from the resident index stream, lists sorted, so
+// the sums are deterministic).  rows == nullptr: read the dense gradient buffer as usual.
+struct DvtAdamRowGather {
+  int64_t begin, end;           // arena range [begin, end) of G (floats, 256-aligned)
+  int c, lattice;               // floats per G row, rows
+  const int32_t* offs[DVT_FIT_BATCH_MAX];   // [lattice + 1] of this step, per fit
+  const uint16_t* perm[DVT_FIT_BATCH_MAX];  // [batch] of this step, per fit
+  const float* rows[DVT_FIT_BATCH_MAX];     // d_pred [batch, c], per fit
+};
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
-                    float* const* g, uint32_t* const* touched, hipStream_t stream);
+                    float* const* g, uint32_t* const* touched, hipStream_t stream,
+                    const DvtAdamRowGather* gather = nullptr);
+// offs [steps, lattice + 1] / perm [steps, batch] for steps [0, steps) of idx [steps, batch]; lattice <= 8192,
+// batch <= 65535
+int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,
+                        uint16_t* perm, hipStream_t stream);
 
 // ---- profiling probes (dvt_prof.hip) ----
 extern unsigned g_dvt_prof_mask;

@@ -22,7 +22,11 @@ inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct Work {
   float *enc, *h1, *F, *raw, *dF, *dh1, *denc, *rows, *r1, *r2, *Hres, *dH, *dr2, *dr1;
+  int32_t* g_offs;   // [num_iters, lattice + 1] row lists of the G gradient (nullptr: atomics path)
+  uint16_t* g_perm;  // [num_iters, batch]
 };
+
+bool row_lists_ok(const DvtFitConfig* c) { return c->lattice <= 8192 && c->batch <= 65535; }
 
 int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
   const int64_t B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
@@ -48,6 +52,12 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
   t.dH = take(B * C);
   t.dr2 = take(B * R);
   t.dr1 = take(B * R);
+  t.g_offs = nullptr;
+  t.g_perm = nullptr;
+  if (row_lists_ok(c)) {
+    t.g_offs = reinterpret_cast<int32_t*>(take((int64_t)c->num_iters * (c->lattice + 1)));
+    t.g_perm = reinterpret_cast<uint16_t*>(take(((int64_t)c->num_iters * B + 1) / 2));
+  }
   if (w) *w = t;
   return o;
 }
@@ -217,7 +227,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     float *Gp[KM], *dG[KM];
     at(P, c->off_G, Gp);
     at(Gd, c->off_G, dG);
-    if (phase2)
+    if (phase2 || ws[0].g_offs != nullptr)  // G frozen, or its gradient is gathered inside Adam
       for (int f = 0; f < k; ++f) dG[f] = nullptr;
     DVT_TRY(dvt_loss_launch_k(k, Fp, Gp, ridx, c->lattice, use_res ? Hres : nullptr, raw, dF, dH, dG,
                               rows, B, C, (float)c->grad_scale, s));
@@ -286,7 +296,19 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     seg(c->off_grid, c->off_G, step + 1);  // grid + field MLP (G frozen: grad None)
     if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
   }
-  return dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s);
+  DvtAdamRowGather gather{};
+  if (!phase2 && ws[0].g_offs != nullptr) {
+    gather.begin = c->off_G;
+    gather.end = c->off_wh1;
+    gather.c = C;
+    gather.lattice = c->lattice;
+    for (int f = 0; f < k; ++f) {
+      gather.offs[f] = ws[f].g_offs + (size_t)step * (c->lattice + 1);
+      gather.perm[f] = ws[f].g_perm + (size_t)step * B;
+      gather.rows[f] = ws[f].dF;
+    }
+  }
+  return dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather);
 }
 #undef DVT_TRY
 
@@ -312,6 +334,13 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
       if (bufs[i]->params == bufs[j]->params || bufs[i]->workspace == bufs[j]->workspace)
         return DVT_E_BADARG;  // fits must not share state
     carve(c, bufs[j]->workspace, &w[j]);
+    if (w[j].g_offs != nullptr && step_begin < c->switch_step + 1) {  // lists of the phase-1 steps of this call
+      const int last = step_end < c->switch_step + 1 ? step_end : c->switch_step + 1;
+      rc = dvt_build_row_lists(bufs[j]->idx + (size_t)step_begin * c->batch, last - step_begin, c->batch,
+                               c->lattice, w[j].g_offs + (size_t)step_begin * (c->lattice + 1),
+                               w[j].g_perm + (size_t)step_begin * c->batch, (hipStream_t)stream);
+      if (rc) return rc;
+    }
   }
   for (int step = step_begin; step < step_end; ++step) {
     int rc = fit_step(c, k, bufs, w, step, (hipStream_t)stream);

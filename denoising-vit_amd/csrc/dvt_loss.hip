@@ -320,6 +320,71 @@ int dvt_loss_launch_k(int k, const float* const* F, const float* const* G, const
   return 0;
 }
 
+// Row lists of the G gradient (see DvtAdamRowGather): one workgroup per step does a counting sort of
+// the step's `batch` lattice rows in LDS; every list is then sorted by sample index.
+constexpr int ROWLIST_MAX_LATTICE = 8192;
+__global__ __launch_bounds__(256) void row_lists_kernel(const int32_t* __restrict__ idx, int batch,
+                                                        int lattice, int32_t* __restrict__ offs,
+                                                        uint16_t* __restrict__ perm) {
+  __shared__ int cnt[ROWLIST_MAX_LATTICE + 1];
+  __shared__ int wsum[4];
+  const int step = blockIdx.x, tid = threadIdx.x;
+  const int32_t* ix = idx + (size_t)step * batch;
+  int32_t* o = offs + (size_t)step * (lattice + 1);
+  uint16_t* pm = perm + (size_t)step * batch;
+  for (int i = tid; i <= lattice; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int b = tid; b < batch; b += 256) atomicAdd(&cnt[ix[b] % lattice], 1);
+  __syncthreads();
+  // exclusive scan over lattice + 1 counters: each thread owns a contiguous run
+  const int per = (lattice + 1 + 255) / 256, lo = tid * per, hi = min(lo + per, lattice + 1);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[i];
+  int incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if ((tid & 63) >= d) incl += t;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = incl - s;
+  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  for (int i = lo; i < hi; ++i) {
+    const int c = cnt[i];
+    o[i] = base;
+    cnt[i] = base;  // becomes the fill cursor
+    base += c;
+  }
+  __syncthreads();
+  for (int b = tid; b < batch; b += 256) pm[atomicAdd(&cnt[ix[b] % lattice], 1)] = (uint16_t)b;
+  __syncthreads();
+  // deterministic order inside a list (lists hold a handful of samples: insertion sort)
+  for (int r = tid; r < lattice; r += 256) {
+    const int a = o[r], e = cnt[r];
+    for (int i = a + 1; i < e; ++i) {
+      const uint16_t v = pm[i];
+      int j = i - 1;
+      while (j >= a && pm[j] > v) {
+        pm[j + 1] = pm[j];
+        --j;
+      }
+      pm[j + 1] = v;
+    }
+  }
+}
+
+int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,
+                        uint16_t* perm, hipStream_t stream) {
+  if (!idx || !offs || !perm || steps < 0 || batch <= 0 || batch > 65535 || lattice <= 0 ||
+      lattice > ROWLIST_MAX_LATTICE)
+    return DVT_E_BADARG;
+  if (steps == 0) return 0;
+  hipLaunchKernelGGL(row_lists_kernel, dim3(steps), dim3(256), 0, stream, idx, batch, lattice, offs, perm);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int dvt_loss_fwd_bwd(const float* F, const float* G, const int32_t* g_idx, int lattice,
                                 const float* Hres, const float* raw_rows, float* d_pred,
                                 float* d_hres, float* row_sums, int n, int c, float grad_scale,
