@@ -20,7 +20,7 @@ out = torch.empty(128, 37, 37, 768, device=dev)
 vit.features_nhwc(x, out=out)
 torch.cuda.synchronize()
 n_rows = 128 * 1369
-eng = FitEngine(FitSettings(num_iters=60, warmup_iters=6), n_rows, dev)
+eng = FitEngine(FitSettings(num_iters=60, warmup_iters=6, mlp_dtype="bfloat16"), n_rows, dev)
 eng.reset(torch.Generator(device=dev).manual_seed(0))
 np.random.seed(0)
 eng.fit(out.view(-1, 768), torch.rand(n_rows, 2, device=dev), None, log_every=0)
