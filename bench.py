@@ -219,7 +219,8 @@ def main():
                     kern[n] = {"bound": "hbm", "achieved": p["work"] / sec / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s"}
                 else:
-                    peak = MFMA_F32_PEAK_TF if n == "fit_gemm" else MFMA_BF16_PEAK_TF
+                    peak = (MFMA_F32_PEAK_TF if n == "fit_gemm" and a.fit_dtype == "float32"
+                            else MFMA_BF16_PEAK_TF)
                     kern[n] = {"bound": "mfma", "achieved": p["work"] / sec / 1e12, "peak": peak,
                                "unit": "TFLOP/s"}
                 kern[n].update(frac=kern[n]["achieved"] / kern[n]["peak"],
