@@ -1036,8 +1036,9 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ vt,
                                                         bf16_t* __restrict__ out, int heads,
                                                         int s_pad, int n_valid) {
-  __shared__ __attribute__((aligned(16))) char Ks[KV_TILE * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * VT_LD];
+  // two K / V^T tile buffers: tile kt+1 is written while tile kt is being multiplied, one barrier per tile
+  __shared__ __attribute__((aligned(16))) char Ksb[2][KV_TILE * 128];
+  __shared__ __attribute__((aligned(16))) char Vsb[2][64 * VT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lc = lane & 15;
   // 1-D grid; XCD x gets a contiguous run of (image, head, query-block) triples so that the
@@ -1085,24 +1086,30 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
   const int sr0 = tid >> 3, sc = tid & 7;
   const bf16_t* kp0 = kbase + (size_t)sr0 * ldq + sc * 8;
   const bf16_t* vp0 = vbase + (size_t)sr0 * s_pad + sc * 8;
-  char* kd0 = Ks + sr0 * 128 + ((sc ^ (sr0 & 7)) << 4);
-  char* vd0 = Vs + sr0 * VT_LD + sc * 16;
+  const int kdo = sr0 * 128 + ((sc ^ (sr0 & 7)) << 4);
+  const int vdo = sr0 * VT_LD + sc * 16;
   uint4 kr0, vr0;
 #define ATT_LOAD(kt)                                                                   \
   do {                                                                                 \
     kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq);         \
     vr0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * KV_TILE);                       \
   } while (0)
-#define ATT_STORE()                           \
-  do {                                        \
-    *reinterpret_cast<uint4*>(kd0) = kr0;     \
-    *reinterpret_cast<uint4*>(vd0) = vr0;     \
+#define ATT_STORE(b)                                      \
+  do {                                                    \
+    *reinterpret_cast<uint4*>(Ksb[b] + kdo) = kr0;        \
+    *reinterpret_cast<uint4*>(Vsb[b] + vdo) = vr0;        \
   } while (0)
   ATT_LOAD(0);
-  ATT_STORE();
+  ATT_STORE(0);
+  if (ntiles > 1) ATT_LOAD(1);
   __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
-    if (kt + 1 < ntiles) ATT_LOAD(kt + 1);
+    const char* Ks = Ksb[kt & 1];
+    const char* Vs = Vsb[kt & 1];
+    if (kt + 1 < ntiles) {
+      ATT_STORE((kt + 1) & 1);  // loaded during the previous tile; that buffer's readers passed the last barrier
+      if (kt + 2 < ntiles) ATT_LOAD(kt + 2);
+    }
     // ---- S^T[key][q] = K . Q^T : acc s[mt][r] <-> key = 16*mt + 4*g + r, q = lc
     f32x4 s[4];
 #pragma unroll
@@ -1172,11 +1179,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
       o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0.v, pf0.v, o[mt], 0, 0, 0);
       o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1.v, pf1.v, o[mt], 0, 0, 0);
     }
-    __syncthreads();
-    if (kt + 1 < ntiles) {
-      ATT_STORE();
-      __syncthreads();
-    }
+    __syncthreads();  // tile kt+1 is complete in LDS, everyone is done reading tile kt
   }
 #undef ATT_LOAD
 #undef ATT_STORE
