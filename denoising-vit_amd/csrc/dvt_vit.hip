@@ -1024,6 +1024,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  return __builtin_fmaxf(__builtin_fmaxf(a, b), c);  // v_max3_f32
+}
+
 // ======================================================================================
 // Attention (head_dim 64): one workgroup = 128 queries of one (image, head); 8 waves x 16 queries
 // ======================================================================================
@@ -1131,25 +1135,39 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
         for (int r = 0; r < 4; ++r)
           if (kbase_idx + mt * 16 + 4 * g + r >= n_valid) s[mt][r] = -1e30f;
     }
-    float tmax = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
-                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-    tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])),
-                             fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
+    // 16 values per lane: v_max3_f32 tree (8 instructions)
+    float tmax = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[0][2]);
+    tmax = max3f(tmax, s[0][3], s[1][0]);
+    tmax = max3f(tmax, s[1][1], s[1][2]);
+    tmax = max3f(tmax, s[1][3], s[2][0]);
+    tmax = max3f(tmax, s[2][1], s[2][2]);
+    tmax = max3f(tmax, s[2][3], s[3][0]);
+    tmax = max3f(tmax, s[3][1], s[3][2]);
+    tmax = fmaxf(tmax, s[3][3]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
     // v_exp_f32 directly: arguments are <= 0, results in [0, 1]; a flushed denormal is an exact 0
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
     const float mb = m_new * LOG2E;
-    float psum = 0.f;
+    // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two logits per instruction
+    const f32x2 l2e2 = {LOG2E, LOG2E}, nmb2 = {-mb, -mb};
+    f32x2 ps2 = {0.f, 0.f};
     float pv[4][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pv[mt][r] = __builtin_amdgcn_exp2f(fmaf(s[mt][r], LOG2E, -mb));
-        psum += pv[mt][r];
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const f32x2 sv = {s[mt][2 * h2], s[mt][2 * h2 + 1]};
+        const f32x2 t = __builtin_elementwise_fma(sv, l2e2, nmb2);
+        f32x2 e;
+        e.x = __builtin_amdgcn_exp2f(t.x);
+        e.y = __builtin_amdgcn_exp2f(t.y);
+        ps2 += e;
+        pv[mt][2 * h2] = e.x;
+        pv[mt][2 * h2 + 1] = e.y;
       }
+    const float psum = ps2.x + ps2.y;
     // B operand of O^T = V^T.P^T: k slot j = 4*(mt&1) + r of k-step ks = mt>>1
     union { bf16x8 v; uint32_t u[4]; } pf0, pf1;
     pf0.u[0] = pack2(pv[0][0], pv[0][1]); pf0.u[1] = pack2(pv[0][2], pv[0][3]);
