@@ -163,6 +163,7 @@ class Stage1:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
         self.timings = []
         self._idx_spare = []  # index streams drawn ahead for the next fit (numpy stream order kept)
+        self._idx_queue = None  # look-ahead queue while `run` is active
 
     # -- single-image pieces (each enqueues on the CURRENT stream) -------------------------
     def extract(self, slot: _Slot) -> None:
@@ -177,11 +178,22 @@ class Stage1:
         return self.fit_group([slot], log_every)[0]
 
     def _draw_indices(self, k: int):
-        """k index streams from the reference's numpy stream (main_img_denoising.py:73), in image
-        order.  Drawn one group AHEAD (while the GPU drains the tail of the previous fit): 2 M
-        draws cost ~20 ms of host time that would otherwise sit between two fits."""
+        """k index streams from the reference's numpy stream (main_img_denoising.py:73), in image order
+        (2 M draws = ~20 ms of host time each)."""
         e = self.engine
         return [e.sample_indices(e.cfg.n_rows, e.s.num_iters, e.s.pixel_bsz) for _ in range(k)]
+
+    def _next_indices(self, k: int):
+        """Index streams of the next k images: from the look-ahead thread of `run` when it is active
+        (drawn while the fit thread is blocked inside the previous image's launch loop), else drawn
+        here.  Either way the numpy stream is consumed strictly in image order."""
+        out = []
+        while len(out) < k and self._idx_spare:
+            out.append(self._idx_spare.pop(0))
+        while len(out) < k:
+            q = self._idx_queue
+            out.append(q.get() if q is not None else self._draw_indices(1)[0])
+        return out
 
     def fit_group(self, group, log_every: int = 1000):
         """The fits of up to `fit_batch` images advanced together (shared launches).  Models are
@@ -189,21 +201,12 @@ class Stage1:
         order (numpy RNG) -- the draws of the reference's sequential loop."""
         engines = self.engines[:len(group)]
         C = self.feat_dim
-        t0 = time.perf_counter()
-        spare, self._idx_spare = self._idx_spare, []
-        idxs = spare[:len(group)] + self._draw_indices(max(0, len(group) - len(spare)))
-        t1 = time.perf_counter()
+        idxs = self._next_indices(len(group))
         for e in engines:
             e.reset(self.gen)
-        t2 = time.perf_counter()
         fit_many(engines, [sl.features.view(-1, C) for sl in group],
                  [sl.coords.view(-1, 2) for sl in group], idxs, log_every=log_every)
-        t3 = time.perf_counter()
-        out = [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
-        if os.environ.get("DVT_DEBUG_TIMING"):
-            print(f"[host] draw {1e3*(t1-t0):.1f} reset {1e3*(t2-t1):.1f} fit_many {1e3*(t3-t2):.1f} "
-                  f"infer {1e3*(time.perf_counter()-t3):.1f} ms at {time.perf_counter():.3f}", flush=True)
-        return out
+        return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
 
     # -- the pipeline --------------------------------------------------------------------------
     def run(self, jobs, on_result=None, log_every: int = 1000) -> int:
@@ -212,11 +215,12 @@ class Stage1:
         retiring thread) once an image's outputs have landed in pinned memory.  Returns the number
         of images.
 
-        Three host threads: the EXTRACTOR walks `jobs` and enqueues view synthesis + ViT on
-        `s_vit`; the calling thread enqueues the fits on `s_fit`; the RETIRER waits for finished
-        images, hands them to `on_result` (the .npy writer) and recycles their buffers.  With one
-        thread the ~10 k launches of a fit back-pressure the host for most of the fit's duration
-        and both streams idled 60-85 ms per image waiting for it."""
+        Host threads: the EXTRACTOR walks `jobs` and enqueues view synthesis + ViT on `s_vit`; the
+        calling thread enqueues the fits on `s_fit`; the RETIRER waits for finished images, hands
+        them to `on_result` (the .npy writer) and recycles their buffers; the INDEX thread draws
+        the next images' index streams.  With one thread the ~10 k launches of a fit back-pressure
+        the host for most of the fit's duration (the HIP queue holds ~650 launches) and both
+        streams idled 25-85 ms per image waiting for it."""
         kb, dev = self.fit_batch, self.device
         free, ready, fitted = queue.Queue(), queue.Queue(), queue.Queue()
         for slot in self.slots:
@@ -259,8 +263,30 @@ class Stage1:
                 errors.append(e)
                 free.put(None)
 
+        idx_q = queue.Queue(maxsize=2 * kb)
+        stop_idx = threading.Event()
+        undelivered = []
+
+        def indexer():  # the only consumer of the global numpy stream while the pipeline runs
+            try:
+                while not stop_idx.is_set():
+                    item = self._draw_indices(1)[0]
+                    while not stop_idx.is_set():
+                        try:
+                            idx_q.put(item, timeout=0.05)
+                            item = None
+                            break
+                        except queue.Full:
+                            pass
+                    if item is not None:  # stopped with one stream drawn but not handed over
+                        undelivered.append(item)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        self._idx_queue = idx_q
         threads = [threading.Thread(target=extractor, name="dvt-extractor", daemon=True),
-                   threading.Thread(target=retirer, name="dvt-retirer", daemon=True)]
+                   threading.Thread(target=retirer, name="dvt-retirer", daemon=True),
+                   threading.Thread(target=indexer, name="dvt-indices", daemon=True)]
         for th in threads:
             th.start()
         try:
@@ -284,15 +310,21 @@ class Stage1:
                         slot.den_host.copy_(den, non_blocking=True)
                     group[-1].fitted.record(self.s_fit)
                 fitted.put(group)
-                if not last:  # next group's index streams, while the GPU finishes this fit
-                    self._idx_spare = self._draw_indices(kb)
         except BaseException:
             free.put(None)  # unblock the extractor thread
             raise
         finally:
             fitted.put(None)
+            stop_idx.set()
             for th in threads:
                 th.join()
+            self._idx_queue = None
+            while True:  # streams drawn ahead but not used: first in line for the next run / fit
+                try:
+                    self._idx_spare.append(idx_q.get_nowait())
+                except queue.Empty:
+                    break
+            self._idx_spare.extend(undelivered)  # drawn last
         if errors:
             raise errors[0]
         return done[0]
