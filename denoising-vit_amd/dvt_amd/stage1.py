@@ -129,6 +129,8 @@ class Stage1:
     def __init__(self, args, device, vit: PretrainedViTWrapper | None = None, depth: int = 2,
                  vit_cus_per_32: int = 32, fit_batch: int = 1):
         self.args, self.device = args, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:  # worker threads call set_device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.vit = vit or PretrainedViTWrapper(args.model, stride=args.stride_size,
                                                checkpoint_path=getattr(args, "vit_checkpoint", None),
                                                img_size=args.input_size)

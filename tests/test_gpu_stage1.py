@@ -114,3 +114,64 @@ def test_fit_large_feature_dim(built_lib):
     assert len(log) == 30 and log[29]["patch_l2_loss"] < log[0]["patch_l2_loss"]
     assert float(eng.grads.abs().max()) == 0.0
     assert eng.infer(xy[-1].cuda()).shape == (37, 37, 1024)
+
+
+def test_pipeline_consumes_the_numpy_stream_in_image_order(built_lib, monkeypatch):
+    """The pipelined driver draws index streams on a look-ahead thread; every image must still get the
+    draws the reference's sequential loop would give it (np.random.randint after fix_random_seeds,
+    main_img_denoising.py:73), across two consecutive run() calls, and the pipelined results must equal
+    the strictly serial flow (depth 1) up to fp32 atomics order."""
+    from types import SimpleNamespace
+    from dvt_amd import fit as fit_mod
+    from dvt_amd import stage1
+    from dvt_amd import views as V
+    from dvt_amd.utils import misc
+    args = SimpleNamespace(model="vit_base_patch14_dinov2.lvd142m", input_size=(518, 518), stride_size=14,
+                           layer_depth_ratio=1.0, num_views=7, num_iters=24, warmup_iters=2, n_levels=16,
+                           freeze_shared_artifacts_after=0.5, lr=0.01, min_lr=0.001, weight_decay=1e-5,
+                           extract_bsz=32, pixel_bsz=256, seed=0, vit_checkpoint=None, dtype="float32")
+    n_img = 5
+
+    def run(depth):
+        misc.fix_random_seeds(0)
+        seen = []
+        real = fit_mod.FitEngine.buffers
+
+        def spy(self, feat, xy, idx=None, log_every=1000):
+            seen.append(None if idx is None else np.array(idx, copy=True))
+            return real(self, feat, xy, idx, log_every)
+
+        monkeypatch.setattr(fit_mod.FitEngine, "buffers", spy)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            st = stage1.Stage1(args, torch.device("cuda"), depth=depth)
+        outs = []
+
+        def jobs(lo, hi):
+            for k in range(lo, hi):
+                def set_views(slot, k=k):
+                    v, c = V.synthetic_views(args.num_views, args.input_size, st.pos_h, st.pos_w,
+                                             torch.device("cuda"), seed=k)
+                    slot.views.copy_(v)
+                    slot.coords.copy_(c)
+                yield k, set_views
+
+        def on_result(tag, raw, den):
+            outs.append((tag, den.copy()))
+
+        assert st.run(jobs(0, 3), on_result) == 3
+        assert st.run(jobs(3, n_img), on_result) == n_img - 3
+        monkeypatch.setattr(fit_mod.FitEngine, "buffers", real)
+        return seen, dict(outs)
+
+    seen, pipe = run(depth=2)
+    misc.fix_random_seeds(0)
+    n_rows = (args.num_views + 1) * 37 * 37
+    for k in range(n_img):
+        want = np.random.randint(0, n_rows, (args.num_iters, args.pixel_bsz)).astype(np.int32)
+        assert seen[k] is not None and np.array_equal(seen[k], want), k
+    _, serial = run(depth=1)
+    for k in range(n_img):
+        a, b = torch.from_numpy(pipe[k]).reshape(-1, 768), torch.from_numpy(serial[k]).reshape(-1, 768)
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
+        assert cos.mean() > 0.9999 and cos.min() > 0.999, (k, float(cos.mean()), float(cos.min()))
