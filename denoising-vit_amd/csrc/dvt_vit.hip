@@ -75,8 +75,9 @@ struct GemmBArgs {
   float* x;           // EPI_RESID / EPI_EMBED: residual stream [M, N]
   const float* gamma; // EPI_RESID: LayerScale [N]
   const float* pos;   // EPI_EMBED: pos_embed [n_tokens, N]
-  const float* cls;   // EPI_EMBED: cls token [N]
+  const float* cls;   // EPI_EMBED: prefix tokens [n_prefix, N] (cls, then register tokens)
   int dim, heads, s_pad, n_tokens;
+  int n_prefix, pos_has_cls;  // EPI_EMBED: prefix rows; pos_embed row 0 belongs to cls (else patches only)
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int dbg;
@@ -179,10 +180,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4
         for (int r = 0; r < 4; ++r) {
           const int t = mrow + r, s = t % p.s_pad;
           float o;
-          if (s == 0)
-            o = p.cls[n] + p.pos[n];
+          if (s < p.n_prefix)
+            o = p.cls[(size_t)s * p.N + n] + ((p.pos_has_cls && s == 0) ? p.pos[n] : 0.f);
           else if (s < p.n_tokens)
-            o = v[r] + p.pos[(size_t)s * p.N + n];
+            o = v[r] + p.pos[(size_t)(s - p.n_prefix + p.pos_has_cls) * p.N + n];
           else
             o = 0.f;
           p.x[(size_t)t * p.N + n] = o;
@@ -317,12 +318,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
       } else {
         const int sidx = t % p.s_pad;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sidx == 0) {
-          const float4 c = *reinterpret_cast<const float4*>(p.cls + nb + c4);
-          const float4 q = *reinterpret_cast<const float4*>(p.pos + nb + c4);
-          o = make_float4(c.x + q.x, c.y + q.y, c.z + q.z, c.w + q.w);
+        if (sidx < p.n_prefix) {  // cls / register tokens (timm: cls gets pos_embed[0] unless no_embed_class)
+          o = *reinterpret_cast<const float4*>(p.cls + (size_t)sidx * p.N + nb + c4);
+          if (p.pos_has_cls && sidx == 0) {
+            const float4 q = *reinterpret_cast<const float4*>(p.pos + nb + c4);
+            o = make_float4(o.x + q.x, o.y + q.y, o.z + q.z, o.w + q.w);
+          }
         } else if (sidx < p.n_tokens) {
-          const float4 q = *reinterpret_cast<const float4*>(p.pos + (size_t)sidx * p.N + nb + c4);
+          const float4 q = *reinterpret_cast<const float4*>(
+              p.pos + (size_t)(sidx - p.n_prefix + p.pos_has_cls) * p.N + nb + c4);
           o = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
         }
         *px = o;
@@ -945,11 +949,11 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
   const int b = t / c.s_pad, s = t - b * c.s_pad;
   bf16_t* dst = col + (size_t)t * c.k_patch;
   const int pp = c.patch * c.patch;
-  if (s == 0 || s >= c.n_tokens) {
+  if (s < c.n_prefix || s >= c.n_tokens) {
     for (int k = threadIdx.x; k < c.k_patch; k += 256) dst[k] = 0;
     return;
   }
-  const int py = (s - 1) / c.grid_w, px = (s - 1) - py * c.grid_w;
+  const int py = (s - c.n_prefix) / c.grid_w, px = (s - c.n_prefix) - py * c.grid_w;
   const float* src = img + (size_t)b * 3 * c.img_h * c.img_w;
   for (int k = threadIdx.x; k < c.k_patch; k += 256) {
     float v = 0.f;
@@ -971,14 +975,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         bf16_t* __restrict__ y_bf16,
                                                         float* __restrict__ y_f32, int rows,
                                                         int dim, float eps, int s_pad,
-                                                        int n_tokens) {
+                                                        int n_tokens, int n_prefix) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   size_t in_row = row;
-  if (FINAL) {  // output row = b*(n_tokens-1) + (s-1), input row = b*s_pad + s, s = 1..n_tokens-1
-    const int per = n_tokens - 1;
-    const int bb = row / per, s = row - bb * per + 1;
+  if (FINAL) {  // output row = b*(n_tokens-n_prefix) + (s-n_prefix), input row = b*s_pad + s
+    const int per = n_tokens - n_prefix;
+    const int bb = row / per, s = row - bb * per + n_prefix;
     in_row = (size_t)bb * s_pad + s;
   }
   const float4* xr = reinterpret_cast<const float4*>(x + in_row * dim);
@@ -1246,7 +1250,8 @@ int check_vit_cfg(const DvtVitConfig* c) {
   if (!c || c->dim <= 0 || c->dim % 128 || c->dim > 1024 || c->heads * 64 != c->dim) return DVT_E_BADARG;
   if (c->depth < 1 || c->depth > DVT_VIT_MAX_DEPTH || c->mlp_dim % 128) return DVT_E_BADARG;
   if (c->s_pad % 128 || c->s_pad < c->n_tokens || c->k_patch % 64) return DVT_E_BADARG;
-  if (c->n_tokens != 1 + c->grid_h * c->grid_w) return DVT_E_BADARG;
+  if (c->n_prefix < 1 || c->n_prefix > 9 || (c->pos_has_cls != 0 && c->pos_has_cls != 1)) return DVT_E_BADARG;
+  if (c->n_tokens != c->n_prefix + c->grid_h * c->grid_w) return DVT_E_BADARG;
   return 0;
 }
 
@@ -1275,7 +1280,12 @@ extern "C" int dvt_vit_struct_sizes(int64_t* out) {
 
 extern "C" int dvt_vit_config(int dim, int depth, int patch, int stride, int img_h, int img_w,
                               DvtVitConfig* c) {
-  if (!c || dim <= 0 || dim % 64 || patch <= 0 || stride <= 0 || img_h < patch || img_w < patch)
+  return dvt_vit_config_reg(dim, depth, patch, stride, img_h, img_w, 0, c);
+}
+
+extern "C" int dvt_vit_config_reg(int dim, int depth, int patch, int stride, int img_h, int img_w,
+                                  int n_reg_tokens, DvtVitConfig* c) {
+  if (!c || n_reg_tokens < 0 || n_reg_tokens > 8 || dim <= 0 || dim % 64 || patch <= 0 || stride <= 0 || img_h < patch || img_w < patch)
     return DVT_E_BADARG;
   c->dim = dim;
   c->depth = depth;
@@ -1287,12 +1297,12 @@ extern "C" int dvt_vit_config(int dim, int depth, int patch, int stride, int img
   c->img_w = img_w;
   c->grid_h = (img_h - patch) / stride + 1;  // vit_wrapper.py:84-88 dynamic_feat_size
   c->grid_w = (img_w - patch) / stride + 1;
-  c->n_tokens = 1 + c->grid_h * c->grid_w;
+  c->n_prefix = 1 + n_reg_tokens;
+  c->pos_has_cls = n_reg_tokens == 0;  // timm: the reg4 DINOv2 models use no_embed_class=True
+  c->n_tokens = c->n_prefix + c->grid_h * c->grid_w;
   c->s_pad = (c->n_tokens + 127) / 128 * 128;
   c->k_patch = (3 * patch * patch + 63) / 64 * 64;
-  c->pad_ = 0;
   c->ln_eps = 1e-6f;
-  c->pad2_ = 0.f;
   return check_vit_cfg(c);
 }
 
@@ -1325,7 +1335,7 @@ extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b,
   if (!x || !w || !b || !y || rows < 0 || dim <= 0 || dim % 4 || dim > 1024) return DVT_E_BADARG;
   if (rows == 0) return 0;
   hipLaunchKernelGGL(layernorm_kernel<false>, dim3(dvt_cdiv(rows, 4)), dim3(256), 0,
-                     (hipStream_t)stream, x, w, b, (bf16_t*)y, (float*)nullptr, rows, dim, eps, 0, 0);
+                     (hipStream_t)stream, x, w, b, (bf16_t*)y, (float*)nullptr, rows, dim, eps, 0, 0, 0);
   DVT_CHECK_LAUNCH();
   return 0;
 }
@@ -1369,6 +1379,7 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
     a.A = k.col; a.W = (const bf16_t*)w->patch_w; a.M = T; a.N = D; a.K = c->k_patch;
     a.bias = w->patch_b; a.x = k.x; a.pos = w->pos_embed; a.cls = w->cls_token;
     a.s_pad = c->s_pad; a.n_tokens = c->n_tokens; a.dim = D; a.heads = c->heads;
+    a.n_prefix = c->n_prefix; a.pos_has_cls = c->pos_has_cls;
     DVT_TRY(launch_gemm<EPI_EMBED>(a, s));
   }
   for (int l = 0; l < n_blocks; ++l) {
@@ -1404,10 +1415,10 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
   }
 #undef DVT_TRY
   // final LayerNorm, drop cls/pad rows, NHWC fp32 straight into the feature store
-  const int out_rows = batch * (c->n_tokens - 1);
+  const int out_rows = batch * (c->n_tokens - c->n_prefix);
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3(dvt_cdiv(out_rows, 4)), dim3(256), 0, s, k.x,
                      w->norm_w, w->norm_b, (bf16_t*)nullptr, feat, out_rows, D, c->ln_eps, c->s_pad,
-                     c->n_tokens);
+                     c->n_tokens, c->n_prefix);
   DVT_CHECK_LAUNCH();
   return 0;
 }

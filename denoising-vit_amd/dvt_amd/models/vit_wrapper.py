@@ -12,7 +12,9 @@ Differences forced by the environment (documented in DESIGN.md):
   * only the two DINOv2 backbones of BASELINE.json are built; the other 18 ids of the
     reference's MODEL_LIST raise NotImplementedError (out of scope).
   * the stride override (vit_wrapper.py:78-91) is honoured by the im2col kernel, but a
-    grid other than the checkpoint's 37x37 needs pos-embed resampling, which is not built.
+    grid other than the checkpoint's 37x37 is served by resampling pos_embed on the host (timm's
+    resample_abs_pos_embed restated); the *_reg4_* models carry 4 register tokens (prefix tokens
+    are stripped from the returned map like timm's `return_prefix_tokens=False`).
 """
 from __future__ import annotations
 
@@ -123,19 +125,15 @@ class PretrainedViTWrapper(nn.Module):
         size = img_size or self.spec.img_size
         self.img_size = (size, size) if isinstance(size, int) else tuple(size)
         self._state_dict, self.transformation = self.create_model(model_identifier, checkpoint_path)
-        gh = (self.img_size[0] - self.patch_size) // stride + 1
-        gw = (self.img_size[1] - self.patch_size) // stride + 1
-        if 1 + gh * gw != self._state_dict["pos_embed"].shape[1]:
-            raise NotImplementedError(
-                f"stride {stride} at {self.img_size} gives a {gh}x{gw} grid; the checkpoint's "
-                "pos_embed is not resampled in this build (SURVEY.md N4)")
+        # a grid other than the checkpoint's (stride override vit_wrapper.py:78-91, other input
+        # sizes) is handled by resampling pos_embed once on the host (dvt_amd.vit.resample_pos_embed)
         self.model = _ModelView(self._state_dict["pos_embed"].clone(), self.spec.depth,
                                 self.patch_size, stride)
         self._hip = None
 
     def create_model(self, model_identifier: str, checkpoint_path: str | None = None):
         path = checkpoint_path or os.environ.get("DVT_VIT_CHECKPOINT")
-        n_tokens = 1 + (self.spec.img_size // self.spec.patch) ** 2
+        n_tokens = (0 if self.spec.n_reg else 1) + (self.spec.img_size // self.spec.patch) ** 2
         if path:
             sd = torch.load(path, map_location="cpu")
             sd = sd.get("state_dict", sd.get("model", sd))
@@ -143,7 +141,7 @@ class PretrainedViTWrapper(nn.Module):
             warnings.warn(f"{model_identifier}: no checkpoint available offline -> RANDOM weights "
                           "(seed 0); set DVT_VIT_CHECKPOINT to a timm-layout state dict")
             sd = _vit.random_state_dict(self.spec.dim, self.spec.depth, self.spec.patch, n_tokens,
-                                        seed=0, ls_gamma=self.spec.ls_init)
+                                        seed=0, ls_gamma=self.spec.ls_init, n_reg=self.spec.n_reg)
         # timm data config of the DINOv2 models: ImageNet mean/std
         return sd, Compose([Normalize(IMAGENET_MEAN, IMAGENET_STD)])
 

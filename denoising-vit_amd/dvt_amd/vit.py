@@ -22,8 +22,8 @@ DVT_VIT_MAX_DEPTH = 48
 class VitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim", "depth", "heads", "mlp_dim", "patch", "stride", "img_h", "img_w", "grid_h",
-        "grid_w", "n_tokens", "s_pad", "k_patch", "pad_")] + [("ln_eps", C.c_float),
-                                                              ("pad2_", C.c_float)]
+        "grid_w", "n_tokens", "s_pad", "k_patch", "n_prefix")] + [("ln_eps", C.c_float),
+                                                                  ("pos_has_cls", C.c_int32)]
 
 
 class VitBlockWeights(C.Structure):
@@ -40,6 +40,7 @@ class VitWeights(C.Structure):
 _P, _I = C.c_void_p, C.c_int
 _lib.register_signatures({
     "dvt_vit_config": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(VitConfig)]),
+    "dvt_vit_config_reg": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(VitConfig)]),
     "dvt_vit_workspace_bytes": (C.c_int64, [C.POINTER(VitConfig), _I]),
     "dvt_vit_struct_sizes": (_I, [C.POINTER(C.c_int64)]),
     "dvt_vit_forward": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
@@ -56,19 +57,47 @@ class VitSpec:
     patch: int = 14
     img_size: int = 518
     ls_init: float = 1e-5  # DINOv2 LayerScale init
+    n_reg: int = 0         # register tokens (the *_reg4_* checkpoints; timm: no_embed_class=True)
 
 
-# the two backbones of BASELINE.json (of the 20 ids in the reference's MODEL_LIST)
+# the DINOv2 ViT-S/B/L backbones of the reference's MODEL_LIST with and without register tokens
+# (vit_wrapper.py:21-30; BASELINE.json names B and L).  ViT-g uses a SwiGLU MLP: not built.
 SPECS = {
+    "vit_small_patch14_dinov2.lvd142m": VitSpec(384, 12),
     "vit_base_patch14_dinov2.lvd142m": VitSpec(768, 12),
     "vit_large_patch14_dinov2.lvd142m": VitSpec(1024, 24),
+    "vit_small_patch14_reg4_dinov2.lvd142m": VitSpec(384, 12, n_reg=4),
+    "vit_base_patch14_reg4_dinov2.lvd142m": VitSpec(768, 12, n_reg=4),
+    "vit_large_patch14_reg4_dinov2.lvd142m": VitSpec(1024, 24, n_reg=4),
 }
 
 
-def vit_config(dim: int, depth: int, patch: int, stride: int, img_h: int, img_w: int) -> VitConfig:
+def resample_pos_embed(pos_embed: torch.Tensor, new_grid: tuple[int, int], n_prefix_pos: int) -> torch.Tensor:
+    """pos_embed [1, n_prefix_pos + g0*g0, dim] -> [1, n_prefix_pos + gh*gw, dim] for another token
+    grid (other `--stride_size` / `--input_size`, vit_wrapper.py:78-91 + timm dynamic_img_size).
+    Restates timm 1.0.7 `resample_abs_pos_embed` (layers/pos_embed.py; third party, absent here):
+    the patch part is reshaped to its square grid, resized with bicubic + antialias interpolation
+    (align_corners=False) in fp32 and flattened again; prefix positions are carried over."""
+    import torch.nn.functional as F
+    n_old = pos_embed.shape[1] - n_prefix_pos
+    g0 = int(math.sqrt(n_old))
+    if g0 * g0 != n_old:
+        raise _lib.DvtError(f"pos_embed with {n_old} patch positions is not a square grid")
+    if (g0, g0) == tuple(new_grid):
+        return pos_embed
+    prefix, patch = pos_embed[:, :n_prefix_pos], pos_embed[:, n_prefix_pos:]
+    dim = pos_embed.shape[-1]
+    patch = patch.float().reshape(1, g0, g0, dim).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, size=tuple(new_grid), mode="bicubic", antialias=True, align_corners=False)
+    patch = patch.permute(0, 2, 3, 1).reshape(1, -1, dim).to(pos_embed.dtype)
+    return torch.cat([prefix, patch], dim=1)
+
+
+def vit_config(dim: int, depth: int, patch: int, stride: int, img_h: int, img_w: int,
+               n_reg: int = 0) -> VitConfig:
     cfg = VitConfig()
-    _lib.check(_lib.lib().dvt_vit_config(dim, depth, patch, stride, img_h, img_w, C.byref(cfg)),
-               "dvt_vit_config")
+    _lib.check(_lib.lib().dvt_vit_config_reg(dim, depth, patch, stride, img_h, img_w, n_reg, C.byref(cfg)),
+               "dvt_vit_config_reg")
     sizes = (C.c_int64 * 3)()
     _lib.lib().dvt_vit_struct_sizes(sizes)
     if list(sizes) != [C.sizeof(VitConfig), C.sizeof(VitBlockWeights), C.sizeof(VitWeights)]:
@@ -77,7 +106,8 @@ def vit_config(dim: int, depth: int, patch: int, stride: int, img_h: int, img_w:
 
 
 def random_state_dict(dim: int, depth: int, patch: int, n_tokens: int, seed: int = 0,
-                      ls_gamma: float | None = 1e-5, well_conditioned: bool = False) -> dict:
+                      ls_gamma: float | None = 1e-5, well_conditioned: bool = False,
+                      n_reg: int = 0) -> dict:
     """Random-init weights in the timm layout (trunc_normal(0.02)-like matrices).  With
     `well_conditioned` biases / LayerScale / norm affine are random O(1) so that parity tests
     exercise every term (LayerScale 1e-5 would hide block errors)."""
@@ -91,6 +121,8 @@ def random_state_dict(dim: int, depth: int, patch: int, n_tokens: int, seed: int
         "norm.weight": 1 + rn(dim, std=0.2) if well_conditioned else torch.ones(dim),
         "norm.bias": rn(dim, std=0.2) if well_conditioned else torch.zeros(dim),
     }
+    if n_reg:  # timm layout of the reg4 models: reg_token [1, n_reg, dim]; pos_embed has NO cls row
+        sd["reg_token"] = rn(1, n_reg, dim, std=0.5 if well_conditioned else 1e-6)
     ws = 1.0 / math.sqrt(dim) if well_conditioned else 0.02
     for i in range(depth):
         p = f"blocks.{i}."
@@ -122,13 +154,14 @@ class HipViT:
         sd = {k: v.detach() for k, v in state_dict.items()}
         dim = sd["pos_embed"].shape[-1]
         depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
-        self.cfg = vit_config(dim, depth, patch, stride, img_size[0], img_size[1])
+        n_reg = int(sd["reg_token"].shape[1]) if "reg_token" in sd else 0
+        self.cfg = vit_config(dim, depth, patch, stride, img_size[0], img_size[1], n_reg)
         cfg = self.cfg
-        if sd["pos_embed"].shape[1] != cfg.n_tokens:
-            raise _lib.DvtError(
-                f"pos_embed has {sd['pos_embed'].shape[1]} tokens, the {cfg.grid_h}x{cfg.grid_w} "
-                "grid needs {cfg.n_tokens}: pos-embed resampling (other strides/sizes) is out of "
-                "scope of this build (SURVEY.md N4)")
+        # other strides / input sizes: the checkpoint's position grid is resampled once, on the host
+        sd["pos_embed"] = resample_pos_embed(sd["pos_embed"], (cfg.grid_h, cfg.grid_w), int(cfg.pos_has_cls))
+        if sd["pos_embed"].shape[1] != cfg.pos_has_cls + cfg.grid_h * cfg.grid_w:
+            raise _lib.DvtError(f"pos_embed has {sd['pos_embed'].shape[1]} rows for a "
+                                f"{cfg.grid_h}x{cfg.grid_w} grid")
         dev = self.device
         self._keep = []
 
@@ -147,7 +180,10 @@ class HipViT:
         pw_pad = torch.zeros(dim, cfg.k_patch)
         pw_pad[:, : pw.shape[1]] = pw
         w.patch_w, w.patch_b = bf16(pw_pad), f32(sd["patch_embed.proj.bias"])
-        w.cls_token, w.pos_embed = f32(sd["cls_token"].reshape(-1)), f32(sd["pos_embed"].reshape(-1, dim))
+        prefix = sd["cls_token"].reshape(1, dim)
+        if n_reg:
+            prefix = torch.cat([prefix.float(), sd["reg_token"].reshape(n_reg, dim).float()], 0)
+        w.cls_token, w.pos_embed = f32(prefix), f32(sd["pos_embed"].reshape(-1, dim))
         w.norm_w, w.norm_b = f32(sd["norm.weight"]), f32(sd["norm.bias"])
         for i in range(depth):
             p, b = f"blocks.{i}.", w.blocks[i]

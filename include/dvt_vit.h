@@ -36,12 +36,13 @@ typedef struct DvtVitConfig {
   int32_t stride;    /* conv stride (14; the reference's --stride_size) */
   int32_t img_h, img_w; /* 518 x 518 */
   int32_t grid_h, grid_w; /* (img - patch) / stride + 1 = 37 */
-  int32_t n_tokens;  /* 1 + grid_h * grid_w = 1370 (one prefix/cls token) */
+  int32_t n_tokens;  /* n_prefix + grid_h * grid_w = 1370 */
   int32_t s_pad;     /* tokens per image padded to a multiple of 128 (1408) */
   int32_t k_patch;   /* 3 * patch * patch padded to a multiple of 64 (588 -> 640) */
-  int32_t pad_;
+  int32_t n_prefix;  /* prefix tokens: 1 (cls) + register tokens (4 for the *_reg4_* models) */
   float ln_eps;      /* 1e-6 */
-  float pad2_;
+  int32_t pos_has_cls; /* 1: pos_embed[0] belongs to cls, patches follow (DINOv2); 0: pos_embed covers
+                        * the patch tokens only (timm no_embed_class=True, the reg4 models) */
 } DvtVitConfig;
 
 /* All matrices bf16 row-major [out, in] (nn.Linear layout), vectors fp32. */
@@ -59,8 +60,8 @@ typedef struct DvtVitBlockWeights {
 typedef struct DvtVitWeights {
   const void* patch_w;    /* bf16 [dim, k_patch], k = c*patch*patch + ky*patch + kx, zero padded */
   const float* patch_b;   /* [dim] */
-  const float* cls_token; /* [dim] */
-  const float* pos_embed; /* [n_tokens, dim] (already resampled to grid_h x grid_w) */
+  const float* cls_token; /* [n_prefix, dim]: cls token, then the register tokens */
+  const float* pos_embed; /* [pos_has_cls + grid_h * grid_w, dim] (already resampled to grid_h x grid_w) */
   const float* norm_w; const float* norm_b; /* final LayerNorm */
   DvtVitBlockWeights blocks[DVT_VIT_MAX_DEPTH];
 } DvtVitWeights;
@@ -68,6 +69,9 @@ typedef struct DvtVitWeights {
 /* HOST: derive grid/n_tokens/s_pad/k_patch/heads/mlp_dim from (dim, depth, patch, stride, img). */
 int dvt_vit_config(int dim, int depth, int patch, int stride, int img_h, int img_w,
                    DvtVitConfig* h_out);
+/* Same with register tokens (vit_wrapper.py:27-30, the *_reg4_dinov2 models: n_reg_tokens = 4). */
+int dvt_vit_config_reg(int dim, int depth, int patch, int stride, int img_h, int img_w,
+                       int n_reg_tokens, DvtVitConfig* h_out);
 /* HOST: bytes of scratch needed for a forward of `batch` images. */
 int64_t dvt_vit_workspace_bytes(const DvtVitConfig* h_cfg, int batch);
 int dvt_vit_struct_sizes(int64_t* h_out3); /* {DvtVitConfig, DvtVitBlockWeights, DvtVitWeights} */

@@ -15,6 +15,8 @@ Weights: timm state-dict layout.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -28,7 +30,15 @@ def forward_features(sd: dict, img: torch.Tensor, patch: int, stride: int,
     x = F.conv2d(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=stride)
     B, _, gh, gw = x.shape
     x = x.permute(0, 2, 3, 1).reshape(B, gh * gw, dim)
-    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1) + sd["pos_embed"]
+    n_reg = sd["reg_token"].shape[1] if "reg_token" in sd else 0
+    # timm VisionTransformer._pos_embed with dynamic_img_size: the checkpoint's position grid is
+    # resampled to (gh, gw); DINOv2: cls is concatenated first and pos_embed covers cls + patches;
+    # the reg4 models (no_embed_class=True): pos_embed covers the patches only, then [cls, reg, patches]
+    pos = resample_abs_pos_embed(sd["pos_embed"], (gh, gw), num_prefix_tokens=0 if n_reg else 1)
+    if n_reg:
+        x = torch.cat([sd["cls_token"].expand(B, -1, -1), sd["reg_token"].expand(B, -1, -1), x + pos], dim=1)
+    else:
+        x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1) + pos
     for i in range(n_blocks):
         p = f"blocks.{i}."
         h = F.layer_norm(x, (dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
@@ -44,24 +54,47 @@ def forward_features(sd: dict, img: torch.Tensor, patch: int, stride: int,
                      sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
         x = x + sd.get(p + "ls2.gamma", 1.0) * h
     x = F.layer_norm(x, (dim,), sd["norm.weight"], sd["norm.bias"], eps)
-    return x[:, 1:].reshape(B, gh, gw, dim)
+    return x[:, 1 + n_reg:].reshape(B, gh, gw, dim)  # prefix tokens stripped (return_prefix_tokens=False)
+
+
+def resample_abs_pos_embed(posemb: torch.Tensor, new_size, num_prefix_tokens: int = 1) -> torch.Tensor:
+    """timm 1.0.7 layers/pos_embed.py `resample_abs_pos_embed` (third party, absent: restated from its
+    published source): square source grid, bicubic + antialias interpolation in fp32."""
+    n_new = new_size[0] * new_size[1] + num_prefix_tokens
+    if n_new == posemb.shape[1] and new_size[0] == new_size[1]:
+        return posemb
+    hw = int(math.sqrt(posemb.shape[1] - num_prefix_tokens))
+    prefix, grid = posemb[:, :num_prefix_tokens], posemb[:, num_prefix_tokens:]
+    dim = posemb.shape[-1]
+    grid = grid.float().reshape(1, hw, hw, dim).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=tuple(new_size), mode="bicubic", antialias=True)
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim).to(posemb.dtype)
+    return torch.cat([prefix, grid], dim=1)
 
 
 def to_hf_dinov2(sd: dict, img_size: int, patch: int):
-    """Build a transformers.Dinov2Model carrying the same weights (second opinion)."""
-    from transformers import Dinov2Config, Dinov2Model
-
+    """Build a transformers.Dinov2Model (Dinov2WithRegistersModel when the state dict carries
+    `reg_token`) with the same weights (second opinion).  The HF register model keeps a cls row in
+    its position table (added to cls), timm's reg4 checkpoints do not: that row is set to zero."""
     dim = sd["pos_embed"].shape[-1]
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
-    cfg = Dinov2Config(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=dim // 64,
-                       mlp_ratio=4, image_size=img_size, patch_size=patch, layer_norm_eps=1e-6,
-                       hidden_act="gelu", qkv_bias=True, layerscale_value=1.0,
-                       attn_implementation="eager")
-    m = Dinov2Model(cfg).eval()
+    n_reg = sd["reg_token"].shape[1] if "reg_token" in sd else 0
+    kw = dict(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=dim // 64,
+              mlp_ratio=4, image_size=img_size, patch_size=patch, layer_norm_eps=1e-6,
+              hidden_act="gelu", qkv_bias=True, layerscale_value=1.0, attn_implementation="eager")
     hf = {}
+    if n_reg:
+        from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+        m = Dinov2WithRegistersModel(Dinov2WithRegistersConfig(num_register_tokens=n_reg, **kw)).eval()
+        hf["embeddings.register_tokens"] = sd["reg_token"]
+        pos = torch.cat([torch.zeros(1, 1, dim), sd["pos_embed"]], dim=1)
+    else:
+        from transformers import Dinov2Config, Dinov2Model
+        m = Dinov2Model(Dinov2Config(**kw)).eval()
+        pos = sd["pos_embed"]
     hf["embeddings.cls_token"] = sd["cls_token"]
     hf["embeddings.mask_token"] = torch.zeros(1, dim)
-    hf["embeddings.position_embeddings"] = sd["pos_embed"]
+    hf["embeddings.position_embeddings"] = pos
     hf["embeddings.patch_embeddings.projection.weight"] = sd["patch_embed.proj.weight"]
     hf["embeddings.patch_embeddings.projection.bias"] = sd["patch_embed.proj.bias"]
     for i in range(depth):

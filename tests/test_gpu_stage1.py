@@ -175,3 +175,26 @@ def test_pipeline_consumes_the_numpy_stream_in_image_order(built_lib, monkeypatc
         a, b = torch.from_numpy(pipe[k]).reshape(-1, 768), torch.from_numpy(serial[k]).reshape(-1, 768)
         cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
         assert cos.mean() > 0.9999 and cos.min() > 0.999, (k, float(cos.mean()), float(cos.min()))
+
+
+def test_stage1_driver_stride7_register_backbone(built_lib, tmp_path):
+    """SURVEY N4 end to end: the reference demo's `--stride_size 7` (73 x 73 lattice, 5 329 + 5 tokens per
+    view, pos_embed resampled from 37 x 37) with a register-token backbone through the whole driver."""
+    from dvt_amd import stage1
+    data_root = tmp_path / "data"
+    data_root.mkdir()
+    _make_image(str(data_root / "a.png"))
+    lst = tmp_path / "list.txt"
+    lst.write_text("a.png\n")
+    model = "vit_small_patch14_reg4_dinov2.lvd142m"
+    argv = ["--img_path", str(lst), "--data_root", str(data_root), "--save_root", str(tmp_path / "out"),
+            "--output_dir", str(tmp_path / "work"), "--model", model, "--stride_size", "7", "--num_views", "7",
+            "--num_iters", "40", "--warmup_iters", "4", "--pixel_bsz", "512", "--num_imgs", "1"]
+    args = stage1.get_args(argv)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert stage1.main(args) == 1
+    raw = np.load(tmp_path / "out" / "raw_features" / model / "a.npy")
+    den = np.load(tmp_path / "out" / "denoised_features" / model / "a.npy")
+    assert raw.shape == (73, 73, 384) and den.shape == (1, 73, 73, 384)
+    assert np.isfinite(raw).all() and np.isfinite(den).all() and np.abs(den).max() > 0

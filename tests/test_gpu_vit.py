@@ -99,6 +99,29 @@ def test_gemm_bias_variants(L, variant):
         assert rel(y.float(), want) < 6e-3, (variant, n, k)
 
 
+@pytest.mark.parametrize("dim,depth,img,stride,n_reg", [(128, 2, 56, 7, 0), (128, 2, 56, 14, 4),
+                                                        (256, 2, 98, 7, 4), (384, 1, 70, 14, 0)])
+def test_vit_strides_and_register_tokens_vs_oracle(L, dim, depth, img, stride, n_reg):
+    """the stride override (vit_wrapper.py:78-91; overlapping patches + pos_embed resampled
+    from the checkpoint's grid) and the *_reg4_* models (4 register tokens between cls and the patches,
+    pos_embed on the patches only, prefix tokens stripped from the returned map); ViT-S width."""
+    from dvt_amd.vit import HipViT, random_state_dict
+    g0 = img // 14                       # the checkpoint's grid (stride = patch)
+    g = (img - 14) // stride + 1         # the grid actually produced
+    sd = random_state_dict(dim, depth, 14, (0 if n_reg else 1) + g0 * g0, seed=dim + stride,
+                           well_conditioned=True, n_reg=n_reg)
+    x = torch.randn(3, 3, img, img, generator=torch.Generator().manual_seed(2))
+    want = ovit.forward_features(sd, x, 14, stride)
+    vit = HipViT(sd, 14, stride, (img, img), DEV)
+    assert (vit.cfg.grid_h, vit.cfg.n_prefix, vit.cfg.pos_has_cls) == (g, 1 + n_reg, int(n_reg == 0))
+    got = vit.forward_features(x.to(DEV)).cpu()
+    assert got.shape == want.shape == (3, g, g, dim)
+    cos = F.cosine_similarity(got.reshape(-1, dim), want.reshape(-1, dim), dim=-1)
+    err = float((got - want).norm() / want.norm())
+    print(f"ViT dim={dim} stride={stride} reg={n_reg}: cos mean {cos.mean():.6f} min {cos.min():.6f} rel-L2 {err:.4f}")
+    assert cos.min() > 0.999 and err < 2e-2
+
+
 def test_gemm_rejects_unaligned(L):
     assert L.dvt_vit_gemm_bias(1, 1, None, 1, 100, 128, 64, None) == -1
     assert L.dvt_vit_gemm_bias(1, 1, None, 1, 128, 128, 32, None) == -1
