@@ -73,7 +73,7 @@ def stage1_args(a):
         model=a.model, input_size=(518, 518), stride_size=14, layer_depth_ratio=1.0,
         num_views=a.views, num_iters=a.num_iters, warmup_iters=a.warmup_iters, n_levels=16,
         freeze_shared_artifacts_after=0.5, lr=0.01, min_lr=0.001, weight_decay=1e-5,
-        extract_bsz=32, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None, dtype=a.fit_dtype)
+        extract_bsz=128, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None, dtype=a.fit_dtype)
 
 
 def cpu_baseline(a):
@@ -139,7 +139,7 @@ def main():
     sa = stage1_args(a)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")  # random-init weights: there is no network for checkpoints
-        vit = PretrainedViTWrapper(a.model, stride=14)
+        vit = PretrainedViTWrapper(a.model, stride=14, allow_random_init=True)
     st = Stage1(sa, device, vit=vit, depth=a.pipeline_depth, vit_cus_per_32=a.vit_cus_per_32,
                 fit_batch=a.fit_batch)
     for k, slot in enumerate(st.slots):  # inputs resident in HBM before the timed region

@@ -54,12 +54,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2(f, 0.f) 
 // GEMM  C[M,N] = A[M,K] . W[N,K]^T   (both operands K-contiguous bf16)
 // ======================================================================================
 constexpr int GBM = 128, GBN = 128, GBK = 64;
-int g_vit_dbg_pad = 0;
 // GEMM schedule (dvt_tune_set(1, v)); when M or N is not a multiple of 256 the 256x256 variants
 // fall back to 3.  4 (default): 256x256 8-phase half-tile ring; 0: 256x256 two-stage;
 // 1: always 128x128 two-stage; 2: 256x128 lock-step three-stage; 3: 256x128 ping-pong.
-// 5 / 6 are timing experiments of variant 4 that compute WRONG results (5: every tile reads the
-// operands of tile (0, 0) = all loads L2-hot; 6: no operand loads at all).
+// Every selectable schedule computes the same result (tests/test_gpu_vit.py runs them all).
 int g_vit_gemm_variant = 4;
 constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
 
@@ -80,7 +78,6 @@ struct GemmBArgs {
   int n_prefix, pos_has_cls;  // EPI_EMBED: prefix rows; pos_embed row 0 belongs to cls (else patches only)
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
-  int dbg;
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
 };
 
@@ -790,18 +787,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int s_ = it * 512 + tid, r = s_ >> 3, c = (s_ & 7) ^ (r & 7);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int m0s = p.dbg == 1 ? 0 : m0, n0s = p.dbg == 1 ? 0 : n0;
-      srcA[h][it] = p.A + (size_t)(m0s + (r >> 6) * 128 + h * 64 + (r & 63)) * p.lda + c * 8;
-      srcB[h][it] = p.W + (size_t)(n0s + (r >> 5) * 64 + h * 32 + (r & 31)) * p.ldw + c * 8;
+      srcA[h][it] = p.A + (size_t)(m0 + (r >> 6) * 128 + h * 64 + (r & 63)) * p.lda + c * 8;
+      srcB[h][it] = p.W + (size_t)(n0 + (r >> 5) * 64 + h * 32 + (r & 31)) * p.ldw + c * 8;
     }
   }
   constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
   char* const ldsw = smem + wave * 1024;
 #define P8_STAGE(SRC, kt, off)                                   \
-  do { if (p.dbg != 2) {                                         \
+  do {                                                           \
     glds16(SRC[0] + (size_t)(kt) * GBK, ldsw + (off));           \
     glds16(SRC[1] + (size_t)(kt) * GBK, ldsw + (off) + 8192);    \
-  } } while (0)
+  } while (0)
   // fragment read offsets inside a half-tile: row*128 + ((ks*4 + cg) ^ (row & 7))*16
   const int cg = lane >> 4;
   const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
@@ -908,8 +904,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   }
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
   if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK &&
-      (g_vit_gemm_variant == 0 || g_vit_gemm_variant >= 4)) {
-    a.dbg = g_vit_gemm_variant >= 4 ? g_vit_gemm_variant - 4 : 0;
+      (g_vit_gemm_variant == 0 || g_vit_gemm_variant == 4)) {
     const int nt = a.N / 256;
     // N tiles per group: W slices of a group stay L2-resident, but never fewer than 3 tiles share
     // an A panel (K = 3072: one tile per group re-read A three times from HBM, 1.03 -> 1.23 PF/s)
@@ -918,7 +913,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     g = g > nt ? nt : g;
     while (g > 1 && nt % g) --g;
     a.group = g;
-    if (g_vit_gemm_variant >= 4)
+    if (g_vit_gemm_variant == 4)
       hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     else
       hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
@@ -1262,10 +1257,7 @@ int dvt_vit_tune(int v) {
     g_vit_group_bytes = v * 1024;
     return 0;
   }
-  if (v < 0) {  // experiment: leading-dimension pad (elements) of dvt_vit_gemm_bias operands
-    g_vit_dbg_pad = -v - 1;
-    return 0;
-  }
+  if (v < 0 || v > 4) return DVT_E_BADARG;
   g_vit_gemm_variant = v;
   return 0;
 }
@@ -1317,7 +1309,7 @@ extern "C" int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, v
   GemmBArgs a{};
   a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
   a.bias = b; a.out = (bf16_t*)y;
-  a.lda = a.ldw = k + g_vit_dbg_pad;
+  a.lda = a.ldw = k;
   return launch_gemm<EPI_BIAS>(a, (hipStream_t)stream);
 }
 

@@ -199,6 +199,12 @@ class FitEngine:
                                 f"n_rows={cfg.n_rows}, C={s.feat_dim}")
         if not feat.is_contiguous() or not xy.is_contiguous():
             raise _lib.DvtError("feat/xy must be contiguous")
+        # The reference asserts 0 <= coords <= 1 with a host sync on EVERY step
+        # (neural_feature_field.py:47); here the whole coordinate table of the image is checked
+        # once, asynchronously: the flag is read by check_inputs() after the fit (the retiring thread
+        # of the driver, loss_log()), never inside the launch loop.
+        lo, hi = torch.aminmax(xy)
+        self._range_bad = (lo < 0) | (hi > 1) | torch.isnan(lo + hi)
         if idx is None:
             idx = self.sample_indices(cfg.n_rows, s.num_iters, s.pixel_bsz)
         if isinstance(idx, np.ndarray):
@@ -239,6 +245,13 @@ class FitEngine:
         _lib.check(_lib.lib().dvt_fit_run(C.byref(self.cfg), C.byref(b), step_begin, end,
                                           _lib.stream()), "dvt_fit_run")
 
+    def check_inputs(self) -> None:
+        """Raise if the coordinates handed to the last fit left [0, 1] (synchronises on the flag)."""
+        flag = getattr(self, "_range_bad", None)
+        if flag is not None and bool(flag.item()):
+            raise _lib.DvtError("coordinates should be in [0, 1] (neural_feature_field.py:47): the fit of this "
+                                "image consumed out-of-range coordinates, its result is invalid")
+
     def infer(self, xy: torch.Tensor) -> torch.Tensor:
         """F(xy): the denoised features saved by the reference (quirk Q7) -- the field evaluated
         on a coordinate lattice, main_img_denoising.py:121-130 / offline_denoiser.py:151."""
@@ -259,6 +272,7 @@ class FitEngine:
 
     def loss_log(self) -> dict[int, dict[str, float]]:
         """Loss scalars of the logged steps (one D2H copy, after the loop)."""
+        self.check_inputs()
         host = self.losses.cpu().numpy()
         keys = ("loss", "patch_l2_loss", "cosine_similarity_loss", "residual_loss",
                 "residual_sparsity_loss")

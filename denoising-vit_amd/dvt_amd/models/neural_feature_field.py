@@ -171,10 +171,12 @@ class NeuralFeatureField(nn.Module):
         )
 
     def forward(self, coords: Tensor) -> Tensor:
-        # The reference asserts the [0,1] range with a device->host sync every call (:47); the
-        # range is a property of the data pipeline, so it is checked without forcing a sync
-        # unless debugging is requested.
-        if __debug__ and not coords.is_cuda:
-            _lib.require_cuda(coords)
+        # Same contract as the reference (:47), including its device->host sync: this is the
+        # reference-style module API.  (Without the check, out-of-range coordinates would wrap
+        # silently through the grid's stride / modulo arithmetic.)  The fused loop validates the
+        # whole coordinate table once per image instead (FitEngine.buffers / check_inputs).
+        _lib.require_cuda(coords)
+        lo, hi = torch.aminmax(coords.detach())
+        assert hi <= 1 and lo >= 0, "coordinates should be in [0, 1]"
         feats = self.neural_field(coords.reshape(-1, 2))
         return self.mlp(feats.view(list(coords.shape[:-1]) + [-1]))

@@ -90,42 +90,35 @@ class _LossFn(torch.autograd.Function):
 
 
 class SingleImageDenoiser(nn.Module):
-    def __init__(
-        self,
-        noise_map_height: int = 37,
-        noise_map_width: int = 37,
-        feat_dim: int = 768,
-        layer_index: int = 11,
-        enable_residual_predictor: bool = True,
-        disable_pe: bool = False,
-    ):
+    """Per-image decomposition raw = F(coords) + G[lattice] (+ h(raw)).
+
+    Parameters owned here: `shared_artifacts` = G, one C-vector per lattice position, stored in
+    the reference's [1, C, H, W] layout (state-dict compatible), and `residual_predictor` = h, the
+    C -> C/4 -> C/4 -> C MLP that only trains in the second half of the schedule.  F is the
+    caller's NeuralFeatureField.  Names, defaults and result keys follow
+    dvt/models/offline_denoiser.py:11-171 because the driver, the visualisation code and
+    checkpoints address them by name; the arithmetic behind them is this repo's HIP kernels.
+    """
+
+    def __init__(self, noise_map_height: int = 37, noise_map_width: int = 37, feat_dim: int = 768,
+                 layer_index: int = 11, enable_residual_predictor: bool = True, disable_pe: bool = False):
         super().__init__()
-        self.noise_map_h = noise_map_height
-        self.noise_map_w = noise_map_width
-        self.feat_dim = feat_dim
-        self.layer_idx = layer_index
-        # g: the input-independent artifact term shared by all views (reference :27-36)
-        if disable_pe:
-            self.shared_artifacts = nn.Parameter(
-                torch.zeros(1, feat_dim, noise_map_height, noise_map_width), requires_grad=False)
-        else:
-            self.shared_artifacts = nn.Parameter(
-                torch.randn(1, feat_dim, noise_map_height, noise_map_width) * 0.02,
-                requires_grad=True)
+        self.noise_map_h, self.noise_map_w = noise_map_height, noise_map_width
+        self.feat_dim, self.layer_idx = feat_dim, layer_index
+        shape = (1, feat_dim, noise_map_height, noise_map_width)
+        # disable_pe: a frozen all-zero map (ablation switch of the reference, :27-31); otherwise
+        # N(0, 0.02^2) and trainable until stop_shared_artifacts_grad() (:33-36)
+        self.shared_artifacts = nn.Parameter(torch.zeros(shape) if disable_pe else torch.randn(shape) * 0.02,
+                                             requires_grad=not disable_pe)
         self.enable_residual_predictor = enable_residual_predictor
-        if self.enable_residual_predictor:
-            # h: residual term co-dependent on the image and the location (reference :38-46)
-            self.residual_predictor = nn.Sequential(
-                HipLinear(feat_dim, feat_dim // 4),
-                nn.ReLU(),
-                HipLinear(feat_dim // 4, feat_dim // 4),
-                nn.ReLU(),
-                HipLinear(feat_dim // 4, feat_dim),
-            )
+        if enable_residual_predictor:
+            q = feat_dim // 4
+            self.residual_predictor = nn.Sequential(HipLinear(feat_dim, q), nn.ReLU(), HipLinear(q, q),
+                                                    nn.ReLU(), HipLinear(q, feat_dim))
         self.residual_predictor_start = False
 
+    # -- schedule toggles used by the driver at the phase switch (main_img_denoising.py:70-72)
     def start_residual_predictor(self):
-        """Enables the training of the residual predictor."""
         self.residual_predictor_start = True
 
     @property
@@ -133,57 +126,47 @@ class SingleImageDenoiser(nn.Module):
         return self.enable_residual_predictor and self.residual_predictor_start
 
     def stop_shared_artifacts_grad(self):
-        """Stops gradient updates for the shared artifacts."""
         self.shared_artifacts.requires_grad = False
 
-    def forward(
-        self,
-        raw_vit_outputs: Tensor,
-        global_pixel_coords: Tensor,
-        neural_field: NeuralFeatureField = None,
-        shared_artifact_coords: Tensor = None,
-        return_visualization: bool = False,
-    ) -> Dict[str, Tensor]:
-        if len(raw_vit_outputs.shape) != 2:
-            original_shape = raw_vit_outputs.shape
+    def forward(self, raw_vit_outputs: Tensor, global_pixel_coords: Tensor,
+                neural_field: NeuralFeatureField = None, shared_artifact_coords: Tensor = None,
+                return_visualization: bool = False) -> Dict[str, Tensor]:
+        flat = raw_vit_outputs.dim() == 2
+        if flat:  # training call: sampled rows, G looked up at the rows' lattice coordinates
+            assert shared_artifact_coords is not None, "shared_artifact_coords must be provided."
+            lead = None
+            g_rows = _BilinearRowsFn.apply(self.shared_artifacts, shared_artifact_coords)
+        else:  # whole maps [..., H, W, C]: every lattice row of G once, in order
+            lead = tuple(raw_vit_outputs.shape[:-1])
             raw_vit_outputs = raw_vit_outputs.reshape(-1, self.feat_dim)
             global_pixel_coords = global_pixel_coords.reshape(-1, 2)
-            shared_patterns = self.shared_artifacts.permute(0, 2, 3, 1).reshape(-1, self.feat_dim)
-        else:
-            assert shared_artifact_coords is not None, "shared_artifact_coords must be provided."
-            original_shape = None
-            shared_patterns = _BilinearRowsFn.apply(self.shared_artifacts, shared_artifact_coords)
-        denoised_feats = neural_field(global_pixel_coords)
-        pred_residual = (self.residual_predictor(raw_vit_outputs)
-                         if self.use_residual_predictor else None)
+            g_rows = self.shared_artifacts.permute(0, 2, 3, 1).reshape(-1, self.feat_dim)
+        f_rows = neural_field(global_pixel_coords)
+        h_rows = self.residual_predictor(raw_vit_outputs) if self.use_residual_predictor else None
 
-        losses = _LossFn.apply(denoised_feats, shared_patterns, pred_residual, raw_vit_outputs)
-        results = {
-            "patch_l2_loss": losses[1].detach(),
-            "loss": losses[0],
-            "cosine_similarity_loss": losses[2].detach(),
-        }
-        if self.use_residual_predictor:
+        losses = _LossFn.apply(f_rows, g_rows, h_rows, raw_vit_outputs)
+        results = {"patch_l2_loss": losses[1].detach(), "loss": losses[0],
+                   "cosine_similarity_loss": losses[2].detach()}
+        if h_rows is not None:
             results["residual_loss"] = losses[3].detach()
             results["residual_sparsity_loss"] = losses[4].detach()
+        if not return_visualization:
+            return results
 
-        if return_visualization:
-            assert original_shape is not None, "original_shape must be provided."
-            shp = tuple(original_shape[:-1]) + (-1,)
-            if self.use_residual_predictor:
-                pred = denoised_feats + shared_patterns + pred_residual.detach()
-            else:
-                pred = shared_patterns + denoised_feats
-            results["raw_vit_outputs"] = raw_vit_outputs.detach().reshape(shp)
-            results["pred_features"] = pred.detach().reshape(shp)
-            results["denoised_feats"] = denoised_feats.detach().reshape(shp)
-            results["shared_patterns"] = shared_patterns.detach().reshape(shp)
-            if self.use_residual_predictor:
-                results["pred_residual"] = pred_residual.detach().reshape(shp)
-                results["shared_patterns_and_residual"] = (
-                    shared_patterns + pred_residual).detach().reshape(shp)
-                denoised_features = raw_vit_outputs - shared_patterns - pred_residual
-            else:
-                denoised_features = raw_vit_outputs - shared_patterns
-            results["denoised_features"] = denoised_features.detach().reshape(shp)
+        assert lead is not None, "return_visualization needs map-shaped inputs"
+
+        def as_map(t):
+            return t.detach().reshape(*lead, -1)
+
+        results["raw_vit_outputs"] = as_map(raw_vit_outputs)
+        results["denoised_feats"] = as_map(f_rows)      # what stage 1 saves (quirk Q7)
+        results["shared_patterns"] = as_map(g_rows)
+        if h_rows is None:
+            results["pred_features"] = as_map(g_rows + f_rows)
+            results["denoised_features"] = as_map(raw_vit_outputs - g_rows)
+        else:
+            results["pred_features"] = as_map(f_rows + g_rows + h_rows.detach())
+            results["pred_residual"] = as_map(h_rows)
+            results["shared_patterns_and_residual"] = as_map(g_rows + h_rows)
+            results["denoised_features"] = as_map(raw_vit_outputs - g_rows - h_rows)
         return results

@@ -7,10 +7,12 @@ model behind it is replaced by the hand-written HIP forward (csrc/dvt_vit.hip).
 Differences forced by the environment (documented in DESIGN.md):
   * no network / no timm: `pretrained=True` cannot download.  Weights come from
     `checkpoint_path=` (a timm-layout state dict saved with torch.save) or the environment
-    variable DVT_VIT_CHECKPOINT; otherwise they are randomly initialised (seed 0) and a
-    warning is printed -- fine for synthetic benchmarks, meaningless for real features.
-  * only the two DINOv2 backbones of BASELINE.json are built; the other 18 ids of the
-    reference's MODEL_LIST raise NotImplementedError (out of scope).
+    variable DVT_VIT_CHECKPOINT.  Without either the constructor RAISES, like the reference
+    does when the pretrained weights cannot be loaded -- features of a random ViT written to
+    disk would be skipped forever by the existence-based resume.  Random init (seed 0) is
+    available only on request (`allow_random_init=True`: synthetic benchmarks and tests).
+  * only the DINOv2 S/B/L backbones (with / without registers) are built; the other ids of
+    the reference's MODEL_LIST raise NotImplementedError (out of scope).
   * the stride override (vit_wrapper.py:78-91) is honoured by the im2col kernel, but a
     grid other than the checkpoint's 37x37 is served by resampling pos_embed on the host (timm's
     resample_abs_pos_embed restated); the *_reg4_* models carry 4 register tokens (prefix tokens
@@ -41,16 +43,14 @@ MODEL_LIST = [
     # MAE
     "vit_base_patch16_224.mae", "vit_large_patch16_224.mae", "vit_huge_patch14_224.mae",
     # CLIP
-    "vit_base_patch16_clip_384.laion2b_ft_in12k_in1k",
+    "vit_base_patch16_clip_384.laion2b_ft_in12k_in1k", "vit_base_patch16_clip_224.openai",
     # EVA
     "eva02_base_patch16_clip_224.merged2b",
     # DEiT-III
     "deit3_base_patch16_224.fb_in1k",
     # Auto-auged supervised ViT:
     "vit_base_patch16_384.augreg_in21k_ft_in1k",
-    # SAM
-    "samvit_base_patch16.sa1b",
-]
+]  # entry for entry the reference's list (dvt/models/vit_wrapper.py:15-56; its SAM / I-JEPA ids are commented out)
 
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
@@ -109,6 +109,7 @@ class PretrainedViTWrapper(nn.Module):
         dynamic_img_pad: bool = False,
         checkpoint_path: str | None = None,
         img_size: int | Tuple[int, int] | None = None,
+        allow_random_init: bool = False,
         **kwargs,
     ):
         super().__init__()
@@ -124,6 +125,7 @@ class PretrainedViTWrapper(nn.Module):
         self.spec = _vit.SPECS[model_identifier]
         size = img_size or self.spec.img_size
         self.img_size = (size, size) if isinstance(size, int) else tuple(size)
+        self.allow_random_init = bool(allow_random_init)
         self._state_dict, self.transformation = self.create_model(model_identifier, checkpoint_path)
         # a grid other than the checkpoint's (stride override vit_wrapper.py:78-91, other input
         # sizes) is handled by resampling pos_embed once on the host (dvt_amd.vit.resample_pos_embed)
@@ -137,9 +139,14 @@ class PretrainedViTWrapper(nn.Module):
         if path:
             sd = torch.load(path, map_location="cpu")
             sd = sd.get("state_dict", sd.get("model", sd))
+        elif not self.allow_random_init:
+            raise RuntimeError(
+                f"{model_identifier}: no pretrained checkpoint (timm cannot download here). Pass "
+                "checkpoint_path= / --vit_checkpoint or set DVT_VIT_CHECKPOINT to a timm-layout state "
+                "dict; random weights need an explicit allow_random_init=True / --synthetic.")
         else:
-            warnings.warn(f"{model_identifier}: no checkpoint available offline -> RANDOM weights "
-                          "(seed 0); set DVT_VIT_CHECKPOINT to a timm-layout state dict")
+            warnings.warn(f"{model_identifier}: RANDOM ViT weights (seed 0) on request -- synthetic "
+                          "benchmarks and tests only")
             sd = _vit.random_state_dict(self.spec.dim, self.spec.depth, self.spec.patch, n_tokens,
                                         seed=0, ls_gamma=self.spec.ls_init, n_reg=self.spec.n_reg)
         # timm data config of the DINOv2 models: ImageNet mean/std
@@ -164,11 +171,12 @@ class PretrainedViTWrapper(nn.Module):
         return self._hip
 
     def features_nhwc(self, x: torch.Tensor, layer_index: int | None = None,
-                      out: torch.Tensor | None = None) -> torch.Tensor:
+                      out: torch.Tensor | None = None, max_batch: int = 128) -> torch.Tensor:
         """Fast path used by the stage-1 driver: NHWC fp32 patch-token map, optionally written
         straight into a slice of the feature store (no NCHW round trip)."""
         idx = self.last_layer_index if layer_index is None else layer_index
-        return self._engine(x.device).forward_features(x.float(), n_blocks=idx + 1, out=out)
+        return self._engine(x.device).forward_features(x.float(), n_blocks=idx + 1, out=out,
+                                                       max_batch=max_batch)
 
     def get_intermediate_layers(
         self,

@@ -51,7 +51,10 @@ def get_args(argv=None):
     p.add_argument("--lr", type=float, default=0.01)
     p.add_argument("--min_lr", type=float, default=0.001)
     p.add_argument("--weight_decay", type=float, default=1e-5)
-    p.add_argument("--extract_bsz", type=int, default=32)
+    p.add_argument("--extract_bsz", type=int, default=128,
+                   help="views per extractor launch.  The reference's 32 is its DataLoader batch; here the "
+                        "views are already on the device and 128 keeps every GEMM at M = 128 * 1408 rows. "
+                        "Results do not depend on it (tested).")
     p.add_argument("--pixel_bsz", type=int, default=2048)
     p.add_argument("--output_dir", type=str, default="./work_dirs/demo")
     p.add_argument("--num_vis_samples", type=int, default=5)
@@ -60,6 +63,9 @@ def get_args(argv=None):
     # additions of this build
     p.add_argument("--vit_checkpoint", type=str, default=None, help="timm-layout state dict (.pth)")
     p.add_argument("--synthetic", action="store_true", help="N(0,1) views instead of image crops")
+    p.add_argument("--allow_random_vit", action="store_true",
+                   help="run without a checkpoint on RANDOM ViT weights (tests / plumbing runs only; implied by "
+                        "--synthetic).  Without it a missing checkpoint is an error, as in the reference.")
     p.add_argument("--fit_batch", type=int, default=1,
                    help="images fitted together by shared launches (dvt_fit_run_batched), 1..4")
     args = p.parse_args(argv)
@@ -131,9 +137,10 @@ class Stage1:
         self.args, self.device = args, torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:  # worker threads call set_device
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.vit = vit or PretrainedViTWrapper(args.model, stride=args.stride_size,
-                                               checkpoint_path=getattr(args, "vit_checkpoint", None),
-                                               img_size=args.input_size)
+        self.vit = vit or PretrainedViTWrapper(
+            args.model, stride=args.stride_size, checkpoint_path=getattr(args, "vit_checkpoint", None),
+            img_size=args.input_size,
+            allow_random_init=bool(getattr(args, "synthetic", False) or getattr(args, "allow_random_vit", False)))
         v = self.vit
         self.layer_index = int(args.layer_depth_ratio * v.last_layer_index)
         self.pos_h = (args.input_size[0] - v.patch_size) // args.stride_size + 1
@@ -163,6 +170,11 @@ class Stage1:
             self.s_fit = torch.cuda.Stream(device=dev, priority=-1)
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
+        self.extract_bsz = max(1, int(getattr(args, "extract_bsz", 128) or 128))
+        # Everything above was allocated / zero-filled on the CURRENT stream; the first writers are the
+        # side streams.  One device-wide sync here orders them for good (a zero-fill must never land
+        # after set_views / reset).
+        torch.cuda.synchronize(dev)
         self.timings = []
         self._idx_spare = []  # index streams drawn ahead for the next fit (numpy stream order kept)
         self._idx_queue = None  # look-ahead queue while `run` is active
@@ -172,7 +184,8 @@ class Stage1:
         """Feature extraction of all views into the feature store (:315-339), NHWC, no
         NCHW round trip; batches of 128 views keep every GEMM at M = 128*1408 rows."""
         with torch.no_grad():
-            self.vit.features_nhwc(slot.views, self.layer_index, out=slot.features)
+            self.vit.features_nhwc(slot.views, self.layer_index, out=slot.features,
+                                   max_batch=self.extract_bsz)
 
     def fit(self, slot: _Slot, log_every: int = 1000) -> torch.Tensor:
         """denoise_an_image (:28-149): fresh models, the loop, then F on the original image's
@@ -224,6 +237,10 @@ class Stage1:
         the host for most of the fit's duration (the HIP queue holds ~650 launches) and both
         streams idled 25-85 ms per image waiting for it."""
         kb, dev = self.fit_batch, self.device
+        cur = torch.cuda.current_stream(dev)
+        for side in (self.s_vit, self.s_fit):  # work queued by the caller (e.g. resident inputs) comes first
+            if side != cur:
+                side.wait_stream(cur)
         free, ready, fitted = queue.Queue(), queue.Queue(), queue.Queue()
         for slot in self.slots:
             free.put(slot)
@@ -256,6 +273,8 @@ class Stage1:
                     if group is None:
                         return
                     group[-1].fitted.synchronize()  # recorded after the whole group's D2H copies
+                    for eng in self.engines[:len(group)]:
+                        eng.check_inputs()  # the asynchronous coordinate-range flag (free: already synced)
                     for slot in group:
                         if on_result is not None:
                             on_result(slot.tag, slot.raw_host.numpy(), slot.den_host.numpy())

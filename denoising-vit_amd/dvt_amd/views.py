@@ -21,7 +21,6 @@ import math
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 
 def get_params(height: int, width: int, scale=(0.1, 0.5), ratio=(3.0 / 4.0, 4.0 / 3.0),
@@ -108,24 +107,37 @@ def render_views(image: torch.Tensor, boxes: np.ndarray, out: torch.Tensor) -> N
                                            min(V_, len(b)), OH, OW, _lib.stream()), "dvt_render_views")
 
 
+def base_resize_u8(img_u8: np.ndarray, size) -> np.ndarray:
+    """The reference's base transform up to ToTensor (main_img_denoising.py:279-284:
+    `ToPILImage() -> Resize(input_size)`): torchvision's Resize on a PIL image is PIL's own
+    `resize((w, h), BILINEAR)` on uint8 (support-scaled when shrinking, rounded back to uint8).
+    The later `F.resize(..., BICUBIC, antialias=True)` of single_image_dataset.py:33-38 asks for
+    the size the image already has and returns it unchanged.  One image per ~1000 fit steps: this
+    stays on the host, with PIL itself, so the pixels are the reference's bit for bit."""
+    from PIL import Image
+    pil = Image.fromarray(np.ascontiguousarray(img_u8, dtype=np.uint8))
+    if pil.size != (size[1], size[0]):
+        pil = pil.resize((size[1], size[0]), Image.BILINEAR)
+    return np.asarray(pil, dtype=np.uint8)
+
+
+def normalize_u8(img_u8: np.ndarray, mean, std, device) -> torch.Tensor:
+    """ToTensor (uint8 HWC -> fp32 CHW / 255) + Normalize; [3, H, W] fp32 on `device`."""
+    x = torch.from_numpy(np.array(img_u8, dtype=np.uint8, copy=True)).to(device).permute(2, 0, 1).float().div(255.0)
+    m = torch.tensor(mean, device=device, dtype=torch.float32).view(3, 1, 1)
+    s = torch.tensor(std, device=device, dtype=torch.float32).view(3, 1, 1)
+    return ((x - m) / s).contiguous()
+
+
 def load_image(path: str, size, mean, std, device) -> torch.Tensor:
-    """single_image_dataset.py:29-38: PIL decode -> resize to `size` (bicubic, antialias) ->
-    [0,1] -> normalise.  Returns [3, H, W] fp32 on `device`."""
+    """single_image_dataset.py:29-38 + the base transform of main_img_denoising.py:279-286:
+    PIL decode -> PIL bilinear resize to `size` (uint8) -> [0,1] -> normalise.
+    Returns [3, H, W] fp32 on `device`."""
     from PIL import Image
 
     Image.MAX_IMAGE_PIXELS = None
     img = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
-    x = (torch.from_numpy(img).to(device).permute(2, 0, 1).float() / 255.0).contiguous()
-    h, w = x.shape[1:]
-    if h / size[0] <= 3.5 and w / size[1] <= 3.5:
-        base = torch.empty((1, 3, size[0], size[1]), device=device)
-        render_views(x, np.array([[0, 0, h, w, 0]]), base)  # base resize on the HIP resampler
-        x = base[0]
-    else:  # very large photos: beyond the kernel's 16-tap window
-        x = F.interpolate(x[None], size=tuple(size), mode="bicubic", antialias=True, align_corners=False)[0]
-    m = torch.tensor(mean, device=device).view(3, 1, 1)
-    s = torch.tensor(std, device=device).view(3, 1, 1)
-    return (x - m) / s
+    return normalize_u8(base_resize_u8(img, size), mean, std, device)
 
 
 def synthetic_views(num_views: int, size, h_patches: int, w_patches: int, device, seed: int = 0):

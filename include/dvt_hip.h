@@ -253,10 +253,14 @@ int dvt_field_infer(const DvtFitConfig* h_cfg, const float* params, const float*
 int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float* out, int V, int OH,
                      int OW, void* stream);
 
-/* Tuning knob (developer use): key 0 = fp32 GEMM tile configuration override
+/* Schedule selection (developer use).  Every selectable value computes the SAME results (each one
+ * is parity-tested); the knobs only trade speed.  The state is process-global: set it before any
+ * work is enqueued, never concurrently with launches (the compute entry points themselves are
+ * re-entrant on distinct streams).
+ * key 0 = fp32 GEMM tile configuration override
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
- * key 1 = ViT bf16 GEMM variant (0: 256x128 ping-pong when M % 256 == 0, 1: always 128x128 2-stage,
- *         2: 256x128 lock-step 3-stage;
+ * key 1 = ViT bf16 GEMM schedule (4, default: 256x256 8-phase ring; 0: 256x256 two-stage; 1: always
+ *         128x128 two-stage; 2: 256x128 lock-step three-stage; 3: 256x128 ping-pong;
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per

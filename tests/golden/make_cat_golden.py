@@ -1,0 +1,88 @@
+"""BASELINE.json configs[0] as a committed fixture: the CPU oracle chain run ONCE, in the build
+container, on the reference's own demo input (/root/reference/demo/cat.jpg,
+sample_scripts/stage1_demo.sh:25-42) -- "plumbing only": DINOv2 ViT-B/14 geometry with
+random-init weights (no checkpoint can be fetched here), pure-PyTorch neural field, CPU.
+
+    python tests/golden/make_cat_golden.py          (~2 min on 8 cores)
+
+Chain (reference main_img_denoising.py:301-352): PIL decode -> base transform (PIL bilinear
+resize to 518x518, /255, normalise; :279-286) -> V random resized crops + the original
+(dvt/dataset/transform.py:39-76) -> fp32 ViT features of every view (vit_wrapper.py:122-143)
+-> denoise_an_image (:28-149; T Adam steps, B = 2048, L = 16 / 2^20 hash) -> the saved tensor
+`denoised_feats` = F on the original image's lattice (:121-130).
+
+The reference cannot travel to the GPU box, so everything the HIP driver needs to repeat the
+run is stored: the base-resized uint8 image, the view boxes and the seeds.  ViT weights and the
+initial field / denoiser parameters are regenerated from seeds (torch CPU generators are
+deterministic for one torch build); checksums guard that assumption.
+Output: tests/golden/cat_demo.npz (denoised_feats as fp16: the comparison is a per-patch cosine).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "denoising-vit_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+CAT = "/root/reference/demo/cat.jpg"
+OUT = os.path.join(ROOT, "tests", "golden", "cat_demo.npz")
+MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # timm data config of the DINOv2 models
+V, T, WARM, B, SIZE, HP = 8, 60, 6, 2048, (518, 518), 37
+
+
+def vit_weights():
+    from dvt_amd.vit import random_state_dict
+    return random_state_dict(768, 12, 14, 1370, seed=0, well_conditioned=True)
+
+
+def fresh_modules(seed=0):
+    from oracle.models import NeuralFeatureFieldOracle, SingleImageDenoiserOracle
+    torch.manual_seed(seed)
+    d = SingleImageDenoiserOracle(HP, HP, 768, 11)   # main_img_denoising.py:39-44
+    f = NeuralFeatureFieldOracle(feat_dim=768, n_levels=16)  # :46
+    return d, f
+
+
+def checksum(tensors) -> float:
+    return float(sum(float(t.detach().double().abs().sum()) for t in tensors))
+
+
+def main():
+    from PIL import Image
+    from oracle import fit as ofit
+    from oracle import views as oviews
+    from oracle import vit as ovit
+
+    torch.set_num_threads(os.cpu_count() or 8)
+    img = np.asarray(Image.open(CAT).convert("RGB"), dtype=np.uint8)
+    u8, x = oviews.base_transform(img, SIZE, MEAN, STD)
+    boxes, views, coords = oviews.make_views(x, V, SIZE, HP, HP, np.random.RandomState(0))
+    sd = vit_weights()
+    t0 = time.time()
+    with torch.no_grad():
+        feats = torch.cat([ovit.forward_features(sd, views[i:i + 1], 14, 14) for i in range(V + 1)])
+    print(f"oracle ViT: {V + 1} views in {time.time() - t0:.1f} s", flush=True)
+    d, f = fresh_modules(0)
+    init_sum = checksum(list(d.parameters()) + list(f.parameters()))
+    idx = np.random.RandomState(0).randint(0, (V + 1) * HP * HP, (T, B))
+    t0 = time.time()
+    logs = ofit.fit_image(d, f, feats, coords, idx, num_iters=T, warmup_iters=WARM, log_every=1)
+    print(f"oracle fit: {T} steps in {time.time() - t0:.1f} s", flush=True)
+    den = ofit.final_denoised_feats(d, f, feats, coords)[0]  # [37, 37, 768]
+    keys = ("loss", "patch_l2_loss", "cosine_similarity_loss", "residual_loss", "residual_sparsity_loss")
+    loss_tab = np.array([[logs[s].get(k, 0.0) for k in keys] for s in range(T)], np.float64)
+    np.savez_compressed(
+        OUT, image_u8=u8, boxes=boxes, denoised_f16=den.numpy().astype(np.float16),
+        raw_orig_f16_sub=feats[-1, :, :, ::8].numpy().astype(np.float16), losses=loss_tab,
+        vit_checksum=np.float64(checksum(sd.values())), init_checksum=np.float64(init_sum),
+        meta=np.array([V, T, WARM, B], np.int64))
+    print(f"wrote {OUT} ({os.path.getsize(OUT) / 1e6:.2f} MB); loss {loss_tab[0, 0]:.4f} -> {loss_tab[-1, 0]:.4f}")
+
+
+if __name__ == "__main__":
+    main()

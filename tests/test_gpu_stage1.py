@@ -30,7 +30,8 @@ def test_stage1_driver_end_to_end(built_lib, tmp_path, capsys, fit_batch):
     lst.write_text("sub/a.png\nb.png extra-token\nc.png\n")
     argv = ["--img_path", str(lst), "--data_root", str(data_root), "--save_root", str(tmp_path / "out"),
             "--output_dir", str(tmp_path / "work"), "--num_views", "63", "--num_iters", "60",
-            "--warmup_iters", "6", "--pixel_bsz", "512", "--num_imgs", "10", "--fit_batch", str(fit_batch)]
+            "--warmup_iters", "6", "--pixel_bsz", "512", "--num_imgs", "10", "--fit_batch", str(fit_batch),
+            "--allow_random_vit"]
     args = stage1.get_args(argv)
     assert args.input_size == (518, 518) and args.n_levels == 16 and args.model.startswith("vit_base")
     with warnings.catch_warnings():
@@ -129,7 +130,8 @@ def test_pipeline_consumes_the_numpy_stream_in_image_order(built_lib, monkeypatc
     args = SimpleNamespace(model="vit_base_patch14_dinov2.lvd142m", input_size=(518, 518), stride_size=14,
                            layer_depth_ratio=1.0, num_views=7, num_iters=24, warmup_iters=2, n_levels=16,
                            freeze_shared_artifacts_after=0.5, lr=0.01, min_lr=0.001, weight_decay=1e-5,
-                           extract_bsz=32, pixel_bsz=256, seed=0, vit_checkpoint=None, dtype="float32")
+                           extract_bsz=32, pixel_bsz=256, seed=0, vit_checkpoint=None, dtype="float32",
+                           allow_random_vit=True)
     n_img = 5
 
     def run(depth):
@@ -189,7 +191,7 @@ def test_stage1_driver_stride7_register_backbone(built_lib, tmp_path):
     model = "vit_small_patch14_reg4_dinov2.lvd142m"
     argv = ["--img_path", str(lst), "--data_root", str(data_root), "--save_root", str(tmp_path / "out"),
             "--output_dir", str(tmp_path / "work"), "--model", model, "--stride_size", "7", "--num_views", "7",
-            "--num_iters", "40", "--warmup_iters", "4", "--pixel_bsz", "512", "--num_imgs", "1"]
+            "--num_iters", "40", "--warmup_iters", "4", "--pixel_bsz", "512", "--num_imgs", "1", "--allow_random_vit"]
     args = stage1.get_args(argv)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -185,7 +185,8 @@ def test_wrapper_api_full_depth(L):
     assert len(MODEL_LIST) == 20
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14).to(DEV).eval()
+        vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14,
+                                   allow_random_init=True).to(DEV).eval()
     assert (vit.n_output_dims, vit.num_blocks, vit.last_layer_index, vit.patch_size) == (768, 12, 11, 14)
     norm = vit.transformation.transforms[-1]
     assert len(norm.mean) == 3 and len(norm.std) == 3

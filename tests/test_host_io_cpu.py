@@ -1,0 +1,103 @@
+"""CPU: host-side I/O contracts of the stage-1 path.
+
+  * the base resize is the reference's (PIL bilinear on uint8, main_img_denoising.py:279-284), not a
+    float bicubic one;
+  * the product's view boxes / coordinates equal the oracle restatement of transform.py:39-76;
+  * the .npy pair stage 1 writes (main_img_denoising.py:131-146) round-trips through the stage-2
+    reader (dvt/dataset/paired_list_dataset.py:27-43) -- SURVEY.md 8c known-answer material;
+  * the stage-1 CLI refuses to run on random ViT weights unless told so.
+"""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stage2_reader
+from oracle import views as oviews
+
+
+def _photo(h, w, seed=0):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([xx * 255.0 / w, yy * 255.0 / h, ((xx // 9 + yy // 7) % 2) * 180.0], -1)
+    return np.clip(base + rng.randn(h, w, 3) * 20, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("h,w", [(375, 500), (1200, 900), (518, 518), (200, 640)])
+def test_base_resize_is_pil_bilinear_on_uint8(h, w):
+    from PIL import Image
+    from dvt_amd import views as V
+    img = _photo(h, w)
+    got = V.base_resize_u8(img, (518, 518))
+    want = np.asarray(Image.fromarray(img).resize((518, 518), Image.BILINEAR))
+    assert got.dtype == np.uint8 and got.shape == (518, 518, 3) and np.array_equal(got, want)
+    u8, x = oviews.base_transform(img, (518, 518), (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    assert np.array_equal(u8, got)
+    y = V.normalize_u8(got, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225), "cpu")
+    assert torch.equal(x, y)
+    if (h, w) != (518, 518):  # and it is NOT what a float bicubic+antialias resize gives
+        bic = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].float(), size=(518, 518),
+                                              mode="bicubic", antialias=True)[0].permute(1, 2, 0)
+        assert float((bic - torch.from_numpy(got).float()).abs().max()) > 2.0
+
+
+def test_view_boxes_and_coords_equal_the_oracle():
+    from dvt_amd import views as V
+    boxes, coords = V.sample_view_boxes(40, (518, 518), 37, 37, np.random.RandomState(3))
+    img = torch.zeros(3, 518, 518)
+    oboxes, _, ocoords = oviews.make_views(img, 40, (518, 518), 37, 37, np.random.RandomState(3))
+    assert np.array_equal(boxes, oboxes) and torch.equal(coords, ocoords)
+    assert boxes[-1].tolist() == [0, 0, 518, 518, 0]
+    assert float(coords.min()) >= 0.0 and float(coords.max()) <= 1.0
+
+
+def test_stage1_outputs_roundtrip_through_the_stage2_reader(tmp_path):
+    from dvt_amd.utils import misc
+    model = "vit_base_patch14_dinov2.lvd142m"
+    args = Namespace(save_root=str(tmp_path / "feats"), model=model, data_root=str(tmp_path / "VOC"))
+    lines = ["VOC2007/JPEGImages/000005.jpg", "VOC2012/JPEGImages/2008_000008.jpg extra", "VOC2012/x/missing.png"]
+    rng = np.random.RandomState(0)
+    written = {}
+    for line in lines[:2]:
+        rel = line.split(" ")[0]
+        fn = os.path.join(args.data_root, rel)
+        raw, den = rng.randn(37, 37, 768).astype(np.float32), rng.randn(1, 37, 37, 768).astype(np.float32)
+        raw_p, den_p = misc.output_paths(args.save_root, model, args.data_root, fn)
+        misc.atomic_save_npy(raw_p, raw)   # [H, W, C]    main_img_denoising.py:144
+        misc.atomic_save_npy(den_p, den)   # [1, H, W, C] main_img_denoising.py:145
+        assert misc.check_if_file_exists(args, fn)
+        written[rel] = (raw, den)
+    feat_root = f"{args.save_root}/denoised_features/{model}"  # what main_denoiser.py is pointed at
+    for line in lines[:2]:
+        pair = stage2_reader.read_pair(feat_root, line)
+        raw, den = written[line.split(" ")[0]]
+        assert pair["original_feats"].shape == pair["denoised_feats"].shape == (37, 37, 768)
+        assert np.array_equal(pair["original_feats"], raw) and np.array_equal(pair["denoised_feats"], den[0])
+        assert pair["denoised_feats"].dtype == np.float32
+    assert stage2_reader.read_pair(feat_root, lines[2]) is None
+    assert not [p for p in (tmp_path / "feats").rglob("*") if ".tmp." in p.name]  # atomic writes left nothing
+
+
+def test_wrapper_requires_weights_unless_random_init_is_allowed():
+    from dvt_amd.models import PretrainedViTWrapper
+    os.environ.pop("DVT_VIT_CHECKPOINT", None)
+    with pytest.raises(RuntimeError, match="checkpoint"):
+        PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14)
+    with pytest.warns(UserWarning, match="RANDOM"):
+        w = PretrainedViTWrapper("vit_small_patch14_dinov2.lvd142m", stride=14, allow_random_init=True)
+    assert w.n_output_dims == 384 and w.num_blocks == 12
+
+
+def test_wrapper_loads_a_timm_layout_checkpoint(tmp_path):
+    from dvt_amd.models import MODEL_LIST, PretrainedViTWrapper
+    from dvt_amd.vit import random_state_dict
+    sd = random_state_dict(384, 12, 14, 1370, seed=5)
+    path = tmp_path / "vits14.pth"
+    torch.save(sd, path)
+    w = PretrainedViTWrapper("vit_small_patch14_dinov2.lvd142m", stride=14, checkpoint_path=str(path))
+    assert torch.equal(w._state_dict["pos_embed"], sd["pos_embed"])
+    # the reference's list, entry for entry (dvt/models/vit_wrapper.py:15-56)
+    assert len(MODEL_LIST) == 20 and "vit_base_patch16_clip_224.openai" in MODEL_LIST
+    assert not any(m.startswith("samvit") for m in MODEL_LIST)

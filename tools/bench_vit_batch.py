@@ -14,7 +14,7 @@ from dvt_amd.models import PretrainedViTWrapper  # noqa: E402
 dev = torch.device("cuda:0")
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14)
+    vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14, allow_random_init=True)
 x = torch.randn(769, 3, 518, 518, device=dev)
 out = torch.empty(769, 37, 37, 768, device=dev)
 eng = vit._engine(dev)
