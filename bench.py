@@ -1,12 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- stage-1 images denoised / second on N MI355X (BASELINE.json metric).
 
-One "step" = one image of BASELINE.json configs[1]: DINOv2 ViT-B/14 features of 768
-synthetic 518x518 views + the original (769 forwards, HIP bf16-MFMA extractor), a fresh
-neural field + 1000 fused Adam steps (B=2048, L=16, F=8, fp32), the final F(lattice)
-inference and the D2H copy of the two output arrays.  Inputs (views, coordinates) are
-resident in HBM before the timed region.  N>1: one rank per GPU, images are independent
-units -> weak scaling, no collective in the loop (barrier + max-over-ranks timing only).
+One "step" = one image of BASELINE.json configs[1]: DINOv2 ViT-B/14 features of 768 synthetic
+518x518 views + the original (769 forwards, HIP bf16-MFMA extractor), a fresh neural field + 1000
+fused Adam steps (B=2048, L=16, F=8), the final F(lattice) inference and the D2H copy of the two
+output arrays.  Inputs (views, coordinates) are resident in HBM before the timed region.
+N>1: one rank per GPU, images are independent units -> weak scaling, no collective in the loop
+(barrier + max-over-ranks timing + ONE gather of per-rank counters, dvt_amd/dist.py).
+
+`value` is the reference's `--dtype bfloat16` mode end to end (bf16 ViT, bf16-operand fit MLP);
+`value_fp32_fit` repeats the timed region with fp32-operand fit GEMMs (the reference's default
+precision for the fit; the extractor of this line stays bf16).  `parity` is measured in the same
+process: the HIP chain against the CPU oracle chain on the sample the CPU baseline is timed on.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -29,10 +34,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 # HBM bytes per launch from PMC counters, collected in separate rocprofv3 --pmc passes
-# (profiles/r01d_pmc/{fetch,write}.txt; tools/gpu_pmc.sh on a 128-view batch + 60 fit steps):
+# (profiles/r0*_pmc/{fetch,write}.txt; tools/gpu_pmc.sh on a 128-view batch + 60 fit steps):
 # (FETCH_SIZE x 2 [gfx950 wide-load correction, MI355X_MICROARCH.md HBM section] + WRITE_SIZE)
 # x 1024 B / launches.  Calibration: layernorm reads 830.6 MB/launch = its algorithmic 830 MB.
-# vit_gemm = launch-weighted mean of the qkv (1961 MB), proj / fc2 (2080 MB) and fc1 (2364 MB) GEMMs.
+# vit_gemm = launch-weighted mean of the qkv, proj / fc2 and fc1 GEMMs.
 PMC_TRAFFIC_BYTES_PER_LAUNCH = {"vit_gemm": 2121.0e6, "vit_attn": 1108.3e6, "adam": 517.3e6,
                                 "fit_gemm": 48.4e6, "grid": None}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
@@ -49,18 +54,17 @@ def parse():
     p.add_argument("--num-iters", type=int, default=1000)
     p.add_argument("--warmup-iters", type=int, default=100)
     p.add_argument("--views", type=int, default=768)
-    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (baseline + parity)")
     p.add_argument("--no-probes", action="store_true")
+    p.add_argument("--no-fp32-fit", action="store_true", help="skip the second timed region (fp32-operand fit)")
     p.add_argument("--vit-cus-per-32", type=int, default=32,
                    help="CUs (of every 32) the extractor stream may use; <32 keeps some free for the fit")
     p.add_argument("--tune", type=str, default="", help="developer knobs: key=value,... for dvt_tune_set")
     p.add_argument("--fit-batch", type=int, default=1,
-                   help="images whose fits share launches (dvt_fit_run_batched); 1 = one fit at a time "
-                        "(measured: 1.94 / 1.93 / 1.87 images/s at 1 / 2 / 4 -- the step is throughput-, "
-                        "not launch-latency-bound)")
+                   help="images whose fits share launches (dvt_fit_run_batched); 1 = one fit at a time")
     p.add_argument("--fit-dtype", default="bfloat16", choices=["bfloat16", "float32"],
-                   help="operand precision of the fit's MLP GEMMs (the reference's --dtype; bfloat16 = its "
-                        "autocast mode, which the ViT of this bench always runs in)")
+                   help="operand precision of the fit's MLP GEMMs for `value` (the reference's --dtype; bfloat16 = "
+                        "its autocast mode, which the ViT of this bench always runs in)")
     p.add_argument("--pixel-bsz", type=int, default=2048,
                    help="developer experiment only: anything but 2048 is not BASELINE's workload")
     p.add_argument("--pipeline-depth", type=int, default=2,
@@ -76,54 +80,103 @@ def stage1_args(a):
         extract_bsz=128, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None, dtype=a.fit_dtype)
 
 
-def cpu_baseline(a):
-    """The oracle (CPU restatement of the reference path: fp32 ViT + pure-PyTorch hash-grid
-    field + torch.optim.Adam) timed on this box's host cores on a bounded sample and
-    extrapolated linearly (the reference itself has no CPU path: tiny-cuda-nn is CUDA-only)."""
-    from dvt_amd.vit import SPECS, random_state_dict
+def _best_threads(fn):
+    """The GPU box exposes many host threads; small torch ops get SLOWER with all of them.  Time one
+    call of `fn` at a few thread counts and keep the fastest (the count is reported as `cores`)."""
+    total = os.cpu_count() or 8
+    best, best_t = None, float("inf")
+    for n in sorted({min(total, c) for c in (8, 16, 32, 64, total)}):
+        torch.set_num_threads(n)
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        t = time.perf_counter() - t0
+        if t < best_t:
+            best, best_t = n, t
+    torch.set_num_threads(best)
+    return best
+
+
+def cpu_baseline_and_parity(a, vit, device):
+    """The oracle (CPU restatement of the reference path: fp32 ViT + pure-PyTorch hash-grid field +
+    torch.optim.Adam; the reference itself has no CPU path: tiny-cuda-nn is CUDA-only) timed on this
+    box's host cores on a bounded sample of the SAME workload -- 8 synthetic views + the original
+    through the 12-block ViT-B/14 and 20 Adam steps at the full fit configuration --
+    and extrapolated linearly.  The very same oracle outputs then serve as the checker of the HIP
+    chain on that sample (`parity`): identical weights, views, initial parameters and index stream."""
+    from dvt_amd import views as Vw
+    from dvt_amd.fit import FitEngine, FitSettings
+    from dvt_amd.models import NeuralFeatureField, SingleImageDenoiser
     from oracle import fit as ofit
     from oracle import vit as ovit
     from oracle.models import NeuralFeatureFieldOracle, SingleImageDenoiserOracle
 
-    cores = torch.get_num_threads()
-    spec = SPECS[a.model]
-    sd = random_state_dict(spec.dim, spec.depth, 14, 1370, seed=0)
-    img = torch.randn(1, 3, 518, 518)
+    sd = vit._state_dict
+    C = vit.n_output_dims
+    V, T, WARM, B, H = 8, 20, 2, a.pixel_bsz, 37
+    views, coords = Vw.synthetic_views(V, (518, 518), H, H, device, seed=4242)
+    views_c, coords_c = views.cpu(), coords.cpu()
     with torch.no_grad():
-        ovit.forward_features(sd, img, 14, 14, n_blocks=1)  # warm
+        cores = _best_threads(lambda: ovit.forward_features(sd, views_c[:1], 14, 14, n_blocks=2))
         t0 = time.perf_counter()
-        n_views = 3
-        for _ in range(n_views):
-            ovit.forward_features(sd, img, 14, 14)
-        t_view = (time.perf_counter() - t0) / n_views
-    C, H, W, V = spec.dim, 37, 37, 8
-    torch.manual_seed(0)
-    feats, xy = torch.randn(V, H, W, C), torch.rand(V, H, W, 2)
-    f_o = NeuralFeatureFieldOracle(feat_dim=C, n_levels=16)
-    d_o = SingleImageDenoiserOracle(H, W, C, spec.depth - 1)
-    T = 6  # 3 steps of each phase (switch at int(0.5*T) = 3)
-    idx = np.random.RandomState(0).randint(0, V * H * W, (T, 2048))
+        feats_o = torch.cat([ovit.forward_features(sd, views_c[i:i + 1], 14, 14) for i in range(V + 1)])
+        t_view = (time.perf_counter() - t0) / (V + 1)
+    n_rows = (V + 1) * H * H
+    idx = np.random.RandomState(0).randint(0, n_rows, (T, B)).astype(np.int32)
+
+    def fresh():
+        torch.manual_seed(0)
+        return SingleImageDenoiserOracle(H, H, C, 11), NeuralFeatureFieldOracle(feat_dim=C, n_levels=16)
+
+    d_w, f_w = fresh()
+    ofit.fit_image(d_w, f_w, feats_o, coords_c, idx[:2], num_iters=2, warmup_iters=1)  # warm (allocations)
+    del d_w, f_w
+    d_o, f_o = fresh()
+    init_d = {k: v.clone() for k, v in d_o.state_dict().items()}
+    init_f = {k: v.clone() for k, v in f_o.state_dict().items()}
     t0 = time.perf_counter()
-    ofit.fit_image(d_o, f_o, feats, xy, idx, num_iters=T, warmup_iters=1)
+    ofit.fit_image(d_o, f_o, feats_o, coords_c, idx, num_iters=T, warmup_iters=WARM)
     t_step = (time.perf_counter() - t0) / T
+    want = ofit.final_denoised_feats(d_o, f_o, feats_o, coords_c)[0]
     sec_per_image = t_view * (a.views + 1) + t_step * a.num_iters
-    return {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n_views} fp32 ViT views ({t_view:.2f} s each) + {T} fit steps "
-                      f"({t_step:.2f} s each), extrapolated linearly to {a.views + 1} views + "
+    base = {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{V + 1} fp32 ViT-B/14 views ({t_view:.2f} s each) + {T} fit steps at B={B}, L=16, 2^20 "
+                      f"({t_step:.3f} s each) on {cores} host threads, extrapolated linearly to {a.views + 1} views + "
                       f"{a.num_iters} steps ({sec_per_image:.0f} s/image)"}
+    # ---- the HIP chain on the same sample
+    cos = torch.nn.functional.cosine_similarity
+    with torch.no_grad():
+        feats_h = vit.features_nhwc(views, 11)
+    raw_cos = cos(feats_h.reshape(-1, C).cpu().double(), feats_o.reshape(-1, C).double(), dim=-1)
+    par = {"sample": f"{V + 1} synthetic views, {T} Adam steps, identical weights / init / index stream; "
+                     "HIP chain (bf16 ViT -> fit) vs CPU oracle chain (fp32 ViT -> fp32 fit)",
+           "metric": "per-patch cosine of the saved tensor denoised_feats [37,37,768] (north-star bar >= 0.99)",
+           "raw_features_cos_mean": float(raw_cos.mean()), "raw_features_cos_min": float(raw_cos.min())}
+    f_h, d_h = NeuralFeatureField(feat_dim=C, n_levels=16), SingleImageDenoiser(H, H, C, 11)
+    f_h.load_state_dict(init_f)
+    d_h.load_state_dict(init_d)
+    f_h, d_h = f_h.to(device), d_h.to(device)
+    for mode in ("bfloat16", "float32"):
+        s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=WARM, pixel_bsz=B, mlp_dtype=mode)
+        eng = FitEngine(s, n_rows, device)
+        eng.load_modules(d_h, f_h)
+        eng.fit(feats_h.reshape(-1, C), coords.reshape(-1, 2), idx, log_every=0)
+        got = eng.infer(coords[-1]).cpu()
+        c = cos(got.reshape(-1, C).double(), want.reshape(-1, C).double(), dim=-1)
+        par[f"denoised_feats_cos_mean_{mode}_fit"] = float(c.mean())
+        par[f"denoised_feats_cos_min_{mode}_fit"] = float(c.min())
+        del eng
+    return base, par
 
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    from dvt_amd import dist as D
+    rank, world, local = D.env_ranks()
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+    D.init(device, world)
 
     from dvt_amd import _lib
     from dvt_amd import views as V
@@ -153,11 +206,10 @@ def main():
         for k in range(n):
             yield k, (lambda slot: None)  # views already resident
 
-    def barrier():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
+    def set_fit_dtype(mode):
+        for e in st.engines:
+            e.s.mlp_dtype = mode
+            e.cfg.mlp_bf16 = int(mode == "bfloat16")
 
     st.run(jobs(a.warmup))
     probes = [] if a.no_probes else ["adam", "vit_gemm", "vit_attn", "fit_gemm", "grid"]
@@ -172,19 +224,21 @@ def main():
     # distort the metric
     probes = [n for n in probes if n in ("adam", "vit_gemm", "vit_attn")]
     _lib.prof_enable(probes)
-    barrier()
-    t0 = time.perf_counter()
-    n_done = st.run(jobs(a.steps))
-    barrier()
-    elapsed = time.perf_counter() - t0
+    n_done, elapsed, per_rank = D.timed(lambda: st.run(jobs(a.steps)), device)
     assert n_done == a.steps
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     prof = {n: _lib.prof_collect(n) for n in probes}
     _lib.prof_enable([])
-    t_ext, t_fit = split["t_extract"] * a.steps, split["t_fit"] * a.steps
+    other = "float32" if a.fit_dtype == "bfloat16" else "bfloat16"
+    second = None
+    if not a.no_fp32_fit:  # the other fit precision, same timed bracket, fewer images
+        k2 = max(2, a.steps // 3)
+        set_fit_dtype(other)
+        st.run(jobs(1))
+        n2, el2, _ = D.timed(lambda: st.run(jobs(k2)), device)
+        st.process(lambda slot: None)
+        second = {"images_per_s": world * n2 / el2, "images_timed_per_rank": n2,
+                  "t_fit_s_serial": st.timings[-1]["t_fit"]}
+        set_fit_dtype(a.fit_dtype)
 
     if rank == 0:
         out = {
@@ -198,17 +252,22 @@ def main():
                             "1k-step per-image fit (B=2048, L=16, F=8, 2^20 hash) on 1 MI355X per rank",
                 "model": a.model, "views": a.views + 1, "num_iters": a.num_iters,
                 "warmup_iters": a.warmup_iters, "pixel_bsz": a.pixel_bsz,
-                "arithmetic": ("ViT: bf16 MFMA / fp32 accumulate; fit MLP GEMMs: " +
-                               ("bf16 operands / fp32 accumulate + outputs (reference --dtype bfloat16 autocast)"
-                                if a.fit_dtype == "bfloat16" else "fp32-operand MFMA") +
-                               "; hash grid, losses, Adam: fp32"),
+                "precision_mode": "reference --dtype bfloat16 (autocast) end to end: ViT bf16 MFMA / fp32 accumulate; "
+                                  f"fit MLP GEMMs {a.fit_dtype} operands / fp32 accumulate + outputs; hash grid, "
+                                  "losses, Adam: fp32.  The reference's DEFAULT is --dtype float32 (see value_fp32_fit)",
                 "fit_dtype": a.fit_dtype,
                 "weights": "random init (no network for checkpoints)",
-                "t_extract_s_serial": t_ext / a.steps, "t_fit_s_serial": t_fit / a.steps,
+                "t_extract_s_serial": split["t_extract"], "t_fit_s_serial": split["t_fit"],
                 "pipeline_depth": a.pipeline_depth, "fit_batch": a.fit_batch,
                 "images_per_rank": a.steps, "parallelism": f"images sharded over {world} GPU(s), no collective",
+                "per_rank": [{"rank": i, "images": int(r[0]), "seconds": r[1]} for i, r in enumerate(per_rank)],
             },
         }
+        if second is not None:
+            key = "value_fp32_fit" if other == "float32" else "value_bf16_fit"
+            out[key] = second["images_per_s"]
+            out["config"][key + "_detail"] = second
+
         def kernel_table(pr, images):
             kern = {}
             for n, p in pr.items():
@@ -226,7 +285,9 @@ def main():
                 kern[n].update(frac=kern[n]["achieved"] / kern[n]["peak"],
                                traffic=PMC_TRAFFIC_BYTES_PER_LAUNCH.get(n),
                                launches=p["launches"], avg_us=1e3 * p["total_ms"] / p["launches"],
-                               ms_per_image=p["total_ms"] / images)
+                               ms_per_image=p["total_ms"] / images,
+                               # work = ALGORITHMIC flops / bytes (1370 tokens, K = 588 patch): frac follows from it
+                               work_per_launch=p["work"] / p["launches"])
             return kern
 
         kern = kernel_table(prof, a.steps)
@@ -238,12 +299,11 @@ def main():
             out["kernels_isolated"] = kernel_table(prof_iso, 1)  # serial pass, one stream
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(a)
+                out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(a, vit, device)
             except Exception as exc:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    D.finish()
 
 
 if __name__ == "__main__":

@@ -79,6 +79,7 @@ struct GemmBArgs {
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
+  double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -902,7 +903,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     while (g > 1 && nt % g) --g;  // prefer a divisor of the tile count (equal groups)
     a.group = g;
   }
-  DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+  DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, a.work > 0.0 ? a.work : 2.0 * a.M * a.N * a.K);
   if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK &&
       (g_vit_gemm_variant == 0 || g_vit_gemm_variant == 4)) {
     const int nt = a.N / 256;
@@ -1356,6 +1357,8 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
   VitWork k;
   vit_carve(c, batch, (char*)workspace, &k);
   const int T = batch * c->s_pad, D = c->dim;
+  // algorithmic GEMM rows: the real tokens, not the rows padded to a multiple of 128
+  const double rows = (double)batch * c->n_tokens;
 
 #define DVT_TRY(x)         \
   do {                     \
@@ -1372,6 +1375,7 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
     a.bias = w->patch_b; a.x = k.x; a.pos = w->pos_embed; a.cls = w->cls_token;
     a.s_pad = c->s_pad; a.n_tokens = c->n_tokens; a.dim = D; a.heads = c->heads;
     a.n_prefix = c->n_prefix; a.pos_has_cls = c->pos_has_cls;
+    a.work = 2.0 * (double)batch * c->grid_h * c->grid_w * D * (3.0 * c->patch * c->patch);
     DVT_TRY(launch_gemm<EPI_EMBED>(a, s));
   }
   for (int l = 0; l < n_blocks; ++l) {
@@ -1382,6 +1386,7 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
       a.A = k.xn; a.W = (const bf16_t*)bw.qkv_w; a.M = T; a.N = 3 * D; a.K = D;
       a.bias = bw.qkv_b; a.out = k.qk; a.vt = k.vt;
       a.dim = D; a.heads = c->heads; a.s_pad = c->s_pad; a.n_tokens = c->n_tokens;
+      a.work = 2.0 * rows * 3.0 * D * D;
       DVT_TRY(launch_gemm<EPI_QKV>(a, s));
     }
     DVT_TRY(dvt_vit_attention(k.qk, k.vt, k.xn, batch, c->heads, c->s_pad, c->n_tokens, s));
@@ -1389,6 +1394,7 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
       GemmBArgs a{};
       a.A = k.xn; a.W = (const bf16_t*)bw.proj_w; a.M = T; a.N = D; a.K = D;
       a.bias = bw.proj_b; a.x = k.x; a.gamma = bw.ls1;
+      a.work = 2.0 * rows * D * D;
       DVT_TRY(launch_gemm<EPI_RESID>(a, s));
     }
     DVT_TRY(dvt_vit_layernorm(k.x, bw.norm2_w, bw.norm2_b, k.xn, T, D, c->ln_eps, s));
@@ -1396,12 +1402,14 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
       GemmBArgs a{};
       a.A = k.xn; a.W = (const bf16_t*)bw.fc1_w; a.M = T; a.N = c->mlp_dim; a.K = D;
       a.bias = bw.fc1_b; a.out = k.hid;
+      a.work = 2.0 * rows * (double)c->mlp_dim * D;
       DVT_TRY(launch_gemm<EPI_GELU>(a, s));
     }
     {
       GemmBArgs a{};
       a.A = k.hid; a.W = (const bf16_t*)bw.fc2_w; a.M = T; a.N = D; a.K = c->mlp_dim;
       a.bias = bw.fc2_b; a.x = k.x; a.gamma = bw.ls2;
+      a.work = 2.0 * rows * (double)c->mlp_dim * D;
       DVT_TRY(launch_gemm<EPI_RESID>(a, s));
     }
   }

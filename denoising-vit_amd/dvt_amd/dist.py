@@ -1,0 +1,76 @@
+"""Process-group plumbing of the N > 1 runs (one process per GPU, `torch.distributed`).
+
+Stage 1 shards images statically (`misc.shard_range`, the arithmetic of the reference's
+sample_scripts/stage1.sh:8-20: eight independent processes, disjoint `--start_idx/--num_imgs`
+slices) and needs NO collective in its data path.  What the ranks do share is bookkeeping: a
+barrier on either side of a timed region, the maximum elapsed time over ranks, and ONE gather of
+per-rank (images, seconds) at the end of a run.  Backend "nccl" is RCCL on ROCm; on a CPU-only
+host (the world-size-2 tests) the same code runs over gloo.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+def env_ranks() -> tuple[int, int, int]:
+    """(rank, world_size, local_rank) as exported by torch.distributed.run; (0, 1, 0) standalone."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),
+            int(os.environ.get("LOCAL_RANK", 0)))
+
+
+def init(device: torch.device, world: int) -> bool:
+    """Join the env:// rendezvous when world > 1 (RCCL for a HIP device, gloo for cpu)."""
+    if world <= 1 or dist.is_initialized():
+        return dist.is_initialized()
+    if device.type == "cuda":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group("gloo")
+    return True
+
+
+def _sync(device: torch.device) -> None:
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def barrier(device: torch.device) -> None:
+    """All queued device work done on every rank (device sync, process barrier, device sync)."""
+    _sync(device)
+    if dist.is_initialized():
+        dist.barrier()
+    _sync(device)
+
+
+def gather_stats(values, device: torch.device) -> list[list[float]]:
+    """The one collective of a run: every rank's small vector of doubles, on every rank."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not dist.is_initialized():
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def timed(fn: Callable[[], int], device: torch.device) -> tuple[int, float, list[list[float]]]:
+    """Run `fn` (returns the units this rank processed) between two barriers.
+    Returns (units of this rank, MAX elapsed seconds over ranks, per-rank [units, seconds])."""
+    barrier(device)
+    t0 = time.perf_counter()
+    n = int(fn())
+    _sync(device)
+    mine = time.perf_counter() - t0
+    barrier(device)
+    elapsed = time.perf_counter() - t0
+    per_rank = gather_stats([n, mine, elapsed], device)
+    return n, max(r[2] for r in per_rank), [[r[0], r[1]] for r in per_rank]
+
+
+def finish() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -147,8 +147,10 @@ class PretrainedViTWrapper(nn.Module):
         else:
             warnings.warn(f"{model_identifier}: RANDOM ViT weights (seed 0) on request -- synthetic "
                           "benchmarks and tests only")
+            # O(1) LayerScale / biases / norm affines: with DINOv2's LayerScale init (1e-5) twelve
+            # random blocks would be a numerical no-op and neither parity nor power draw would mean much
             sd = _vit.random_state_dict(self.spec.dim, self.spec.depth, self.spec.patch, n_tokens,
-                                        seed=0, ls_gamma=self.spec.ls_init, n_reg=self.spec.n_reg)
+                                        seed=0, well_conditioned=True, n_reg=self.spec.n_reg)
         # timm data config of the DINOv2 models: ImageNet mean/std
         return sd, Compose([Normalize(IMAGENET_MEAN, IMAGENET_STD)])
 

@@ -25,6 +25,7 @@ import time
 import numpy as np
 import torch
 
+from . import dist as D
 from . import views as V
 from .fit import FIT_BATCH_MAX, FitEngine, FitSettings, fit_many
 from .models import MODEL_LIST, PretrainedViTWrapper
@@ -370,17 +371,25 @@ class Stage1:
         return raw_h, den_h
 
 
-def main(args, rank: int = 0, world: int = 1):
+def main(args, rank: int = 0, world: int = 1, stage_factory=None, device=None):
+    """The sweep of one rank.  `stage_factory(args, device)` builds the per-GPU engine (default:
+    `Stage1`); tests inject a host-only stand-in to drive this function under gloo."""
     os.makedirs(args.output_dir, exist_ok=True)
     misc.fix_random_seeds(args.seed)
     if rank == 0:
-        print(f"Arguments:\n{json.dumps(vars(args), indent=4)}")
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
-    torch.cuda.set_device(device)
+        print(f"Arguments:\n{json.dumps(vars(args), indent=4, default=str)}")
+    if device is None:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    dist_on = D.init(device, world)
     names = work_list(args)
     lo, hi = misc.shard_range(0, len(names), rank, world)
     names = names[lo:hi]
-    st = Stage1(args, device, fit_batch=getattr(args, "fit_batch", 1))
+    if stage_factory is None:
+        st = Stage1(args, device, fit_batch=getattr(args, "fit_batch", 1))
+    else:
+        st = stage_factory(args, device)
     norm = st.vit.transformation.transforms[-1]
     start = time.time()
     # Crop parameters come from their own generator: in the reference they are drawn by the
@@ -426,11 +435,23 @@ def main(args, rank: int = 0, world: int = 1):
             f.write(json.dumps({"file": filename, "elapsed_s": el}) + "\n")
 
     done = st.run(jobs(), on_result)
-    print(f"[rank {rank}] {done} images in {time.time() - start:.1f}s")
+    seconds = time.time() - start
+    print(f"[rank {rank}] {done} images in {seconds:.1f}s")
+    # the ONE collective of the sweep: per-rank (images, seconds) -> a summary on rank 0
+    per_rank = D.gather_stats([done, seconds], device) if dist_on else [[float(done), seconds]]
+    if rank == 0:
+        total, slowest = sum(r[0] for r in per_rank), max(r[1] for r in per_rank)
+        summary = {"world_size": world, "images": int(total), "seconds": slowest,
+                   "images_per_s": total / slowest if slowest > 0 else 0.0,
+                   "per_rank": [{"rank": i, "images": int(r[0]), "seconds": r[1]} for i, r in enumerate(per_rank)]}
+        with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        print(json.dumps(summary))
     return done
 
 
 if __name__ == "__main__":
     a = get_args()
-    r, w = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    r, w, _ = D.env_ranks()
     main(a, r, w)
+    D.finish()

@@ -275,7 +275,8 @@ int dvt_tune_set(int key, int value);
  * timed region (torch.cuda.Event only sees torch's current stream).
  * ---------------------------------------------------------------------------------- */
 #define DVT_PROBE_ADAM 0      /* fused Adam launches; work = algorithmic bytes (24 B/param + grads) */
-#define DVT_PROBE_VIT_GEMM 1  /* bf16 MFMA GEMM launches of the ViT; work = 2*M*N*K flops */
+#define DVT_PROBE_VIT_GEMM 1  /* bf16 MFMA GEMM launches of the ViT; work = ALGORITHMIC flops: 2 * real tokens
+                               * (1370/image, not the rows padded to 1408) * N * real K (588 for the patch embedding) */
 #define DVT_PROBE_VIT_ATTN 2  /* attention launches; work = 4*S*S*64*heads*batch flops */
 #define DVT_PROBE_FIT_GEMM 3  /* fp32 MFMA linear fwd/bwd launches; work = flops */
 #define DVT_PROBE_GRID 4      /* hash-grid fwd+bwd launches; work = algorithmic bytes */

@@ -1,57 +1,85 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the stage-1 driver shards images with no
-data-path collective; ranks only meet in the barrier / max-over-ranks timing that bench.py
-uses.  (sample_scripts/stage1.sh:8-20 semantics; resume = misc.check_if_file_exists.)"""
+"""CPU, world_size 2 over gloo: the REAL N > 1 code of the stage-1 driver and of bench.py.
+
+`dvt_amd.stage1.main(args, rank, world, ...)` is driven with a host-only stand-in for the per-GPU
+engine (so work-list slicing, sharding, resume-by-existence, the output layout, atomic writes and
+the single end-of-run gather all execute), and `dvt_amd.dist.timed` -- the barrier / max-over-ranks
+/ gather bracket bench.py uses -- runs over gloo exactly as it runs over RCCL on the GPUs.
+(sample_scripts/stage1.sh:8-20 semantics: disjoint contiguous slices, no data-path collective.)"""
+import json
 import os
 import sys
-from argparse import Namespace
+import time
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
 import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODEL = "vit_base_patch14_dinov2.lvd142m"
+
+
+def _fake_stage(rank):
+    class FakeStage:  # what main() touches of Stage1: .vit.transformation, .pos_h/.pos_w, .run()
+        def __init__(self, args, device):
+            norm = SimpleNamespace(mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0))
+            self.vit = SimpleNamespace(transformation=SimpleNamespace(transforms=[norm]))
+            self.pos_h = self.pos_w = 2
+
+        def run(self, jobs, on_result):
+            n = 0
+            for tag, _set_views in jobs:
+                on_result(tag, np.full((2, 2, 4), rank, np.float32), np.full((1, 2, 2, 4), rank, np.float32))
+                n += 1
+            return n
+    return FakeStage
 
 
 def _worker(rank, world, port, tmp, n_images):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "denoising-vit_amd")]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from dvt_amd.utils import misc
-    args = Namespace(save_root=os.path.join(tmp, "out"), model="m", data_root=os.path.join(tmp, "data"))
-    names = [os.path.join(args.data_root, f"d{i % 3}", f"img{i}.jpg") for i in range(n_images)]
-    lo, hi = misc.shard_range(0, len(names), rank, world)
-    done = 0
-    for fn in names[lo:hi]:
-        if misc.check_if_file_exists(args, fn):
-            continue
-        raw_p, den_p = misc.output_paths(args.save_root, args.model, args.data_root, fn)
-        misc.atomic_save_npy(raw_p, np.full((2, 2, 4), rank, np.float32))
-        misc.atomic_save_npy(den_p, np.full((1, 2, 2, 4), rank, np.float32))
-        done += 1
-    dist.barrier()
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)  # stand-in for elapsed seconds
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    total = torch.tensor([done])
-    dist.all_reduce(total)
-    if rank == 0:
-        np.save(os.path.join(tmp, "summary.npy"), np.array([t.item(), total.item()]))
-    dist.destroy_process_group()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from dvt_amd import dist as D
+    from dvt_amd import stage1
+    assert D.env_ranks() == (rank, world, rank)
+    data_root = os.path.join(tmp, "data")
+    lst = os.path.join(tmp, "list.txt")
+    argv = ["--img_path", lst, "--data_root", data_root, "--save_root", os.path.join(tmp, "out"),
+            "--output_dir", os.path.join(tmp, "work"), "--num_imgs", str(n_images + 5), "--model", MODEL]
+    args = stage1.get_args(argv)
+    cpu = torch.device("cpu")
+    done = stage1.main(args, rank, world, stage_factory=_fake_stage(rank), device=cpu)
+    # bench.py's bracket: barrier, K units, barrier, MAX over ranks, one gather
+    n, elapsed, per_rank = D.timed(lambda: (time.sleep(0.05 * (rank + 1)), 3 + rank)[1], cpu)
+    assert n == 3 + rank and len(per_rank) == world and [int(r[0]) for r in per_rank] == [3, 4]
+    assert elapsed >= 0.1 and all(r[1] <= elapsed + 1e-6 for r in per_rank)  # the slowest rank sets the time
+    np.save(os.path.join(tmp, f"done{rank}.npy"), np.array([done]))
+    D.finish()
 
 
 @pytest.mark.parametrize("n_images", [7])
 def test_two_rank_sharded_sweep(tmp_path, n_images):
+    names = [f"d{i % 3}/img{i}.jpg" for i in range(n_images)]
+    (tmp_path / "list.txt").write_text("".join(f"{n} some-label\n" for n in names))
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path), n_images), nprocs=2, join=True)
-    t_max, total = np.load(tmp_path / "summary.npy")
-    assert t_max == 2.0 and total == n_images
-    files = sorted(p.name for p in (tmp_path / "out" / "denoised_features" / "m").rglob("*.npy"))
+    done = [int(np.load(tmp_path / f"done{r}.npy")[0]) for r in range(2)]
+    assert done == [4, 3]  # rank 0 owns the first ceil(7/2) images
+    den_dir = tmp_path / "out" / "denoised_features" / MODEL
+    files = sorted(p.name for p in den_dir.rglob("*.npy"))
     assert files == sorted(f"img{i}.npy" for i in range(n_images))
-    # rank 0 owns the first ceil(7/2) = 4 images
-    owner = [int(np.load(p)[0, 0, 0, 0]) for p in sorted(
-        (tmp_path / "out" / "denoised_features" / "m").rglob("*.npy"), key=lambda q: int(q.stem[3:]))]
+    owner = [int(np.load(p)[0, 0, 0, 0]) for p in sorted(den_dir.rglob("*.npy"), key=lambda q: int(q.stem[3:]))]
     assert owner == [0, 0, 0, 0, 1, 1, 1]
-    # rerun: everything is skipped (idempotent resume)
+    raw = np.load(tmp_path / "out" / "raw_features" / MODEL / "d0" / "img0.npy")
+    assert raw.shape == (2, 2, 4)
+    summary = json.loads((tmp_path / "work" / "summary.json").read_text())  # the end-of-run gather, rank 0
+    assert summary["world_size"] == 2 and summary["images"] == n_images
+    assert [r["images"] for r in summary["per_rank"]] == [4, 3]
+    for r in range(2):
+        lines = (tmp_path / "work" / f"timings_rank{r}.jsonl").read_text().splitlines()
+        assert len(lines) == done[r]
+    # rerun: everything is skipped (idempotent resume by file existence)
     mp.spawn(_worker, args=(2, port + 1, str(tmp_path), n_images), nprocs=2, join=True)
-    assert np.load(tmp_path / "summary.npy")[1] == 0
+    assert [int(np.load(tmp_path / f"done{r}.npy")[0]) for r in range(2)] == [0, 0]
+    assert json.loads((tmp_path / "work" / "summary.json").read_text())["images"] == 0
