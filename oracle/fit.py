@@ -67,7 +67,7 @@ def fit_image(denoiser, neural_field, all_raw_features, all_pixel_coords, idx_st
         (out["loss"] * grad_scale).backward()  # :88 (scale, never unscaled)
         optimizer.step()  # :89
         if log_every and (step % log_every == 0 or step == num_iters - 1):
-            logs[step] = {k: float(v) for k, v in out.items()}
+            logs[step] = {k: float(v.detach()) for k, v in out.items()}
     return logs
 
 
