@@ -60,13 +60,78 @@ struct DvtAdamRowGather {
   const uint16_t* perm[DVT_FIT_BATCH_MAX];  // [batch] of this step, per fit
   const float* rows[DVT_FIT_BATCH_MAX];     // d_pred [batch, c], per fit
 };
+struct DvtShadowLayout;
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
-                    const DvtAdamRowGather* gather = nullptr);
+                    const DvtAdamRowGather* gather = nullptr, const DvtShadowLayout* shadow_layout = nullptr,
+                    uint16_t* const* shadow = nullptr);
 // offs [steps, lattice + 1] / perm [steps, batch] for steps [0, steps) of idx [steps, batch]; lattice <= 8192,
 // batch <= 65535
 int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,
                         uint16_t* perm, hipStream_t stream);
+
+// ---- fused row kernel of the fit (dvt_fit_fused.hip) ----
+// bf16 SHADOW copies of the five MLP weight matrices (W1, W2, Wh1, Wh2, Wh3), kept next to the fp32
+// master weights by the Adam kernel: [N][K] as stored (forward operand) and, where a data gradient
+// flows back through the layer, [K][N] (dgrad operand), so that every MFMA B fragment of the fused
+// kernel is ONE 16-byte k-contiguous global load.
+#define DVT_SHADOW_MATS 5
+struct DvtShadowLayout {
+  int n;                         // matrices present (0: no shadow maintained)
+  int N[DVT_SHADOW_MATS];        // rows of the fp32 matrix (output features)
+  int K[DVT_SHADOW_MATS];        // columns (input features), K % 8 == 0
+  long long begin[DVT_SHADOW_MATS];   // arena float offset of the matrix
+  long long direct[DVT_SHADOW_MATS];  // shadow element offset of the [N][K] copy
+  long long transp[DVT_SHADOW_MATS];  // shadow element offset of the [K][N] copy, -1: none
+  long long lo, hi;              // arena float range covering all matrices (quick wave-uniform reject)
+  long long total;               // bf16 elements
+};
+int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* out);
+// (re)build the whole shadow from the fp32 arena (start of a run; Adam keeps it current afterwards)
+int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, uint16_t* const* shadow,
+                       long long arena_floats, hipStream_t s);
+struct DvtFusedFit {  // per fit: inputs, arena, shadow and the fp32 side outputs the wgrad / grid / Adam kernels read
+  const float* xy;
+  const int32_t* ridx;
+  const float* feat;
+  const float* params;
+  const uint16_t* shadow;
+  float *enc, *h1, *F, *raw, *dF, *dh1, *denc, *rows, *r1, *r2, *Hres, *dH, *dr2, *dr1;
+};
+#if defined(__HIPCC__)
+typedef __bf16 dvt_hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float dvt_f32x2 __attribute__((ext_vector_type(2)));
+// fp32 pair -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t dvt_pack_bf16x2(float a, float b) {
+  const dvt_hwbf16x2 v = __builtin_convertvector((dvt_f32x2){a, b}, dvt_hwbf16x2);
+  return __builtin_bit_cast(uint32_t, v);
+}
+// The four consecutive arena floats v at float offset e (e % 4 == 0) -> their bf16 shadow copies, when e
+// lies inside one of the shadowed matrices (row-major [N][K], K % 4 == 0: the four share a row).
+__device__ __forceinline__ void dvt_shadow_store(const DvtShadowLayout& L, uint16_t* __restrict__ sh, long long e,
+                                                 float4 v) {
+#pragma unroll
+  for (int i = 0; i < DVT_SHADOW_MATS; ++i) {
+    const long long rel = e - L.begin[i];
+    if (rel >= 0 && rel < (long long)L.N[i] * L.K[i]) {
+      const int n = (int)(rel / L.K[i]), k = (int)(rel - (long long)n * L.K[i]);
+      const uint32_t lo = dvt_pack_bf16x2(v.x, v.y), hi = dvt_pack_bf16x2(v.z, v.w);
+      *reinterpret_cast<uint2*>(sh + L.direct[i] + rel) = make_uint2(lo, hi);
+      if (L.transp[i] >= 0) {
+        uint16_t* t = sh + L.transp[i] + (long long)k * L.N[i] + n;
+        t[0] = (uint16_t)(lo & 0xffffu);
+        t[L.N[i]] = (uint16_t)(lo >> 16);
+        t[2 * L.N[i]] = (uint16_t)(hi & 0xffffu);
+        t[3 * L.N[i]] = (uint16_t)(hi >> 16);
+      }
+    }
+  }
+}
+#endif
+bool dvt_fit_fused_ok(const DvtFitConfig* c);         // shapes fit AND the bf16-operand mode is selected
+bool dvt_fit_fused_shapes_ok(const DvtFitConfig* c);  // shapes only (workspace carving must not depend on the mode)
+int dvt_fit_rows_k(const DvtFitConfig* c, const DvtShadowLayout* L, int k, const DvtFusedFit* fits, bool phase2,
+                   hipStream_t s);
 
 // ---- profiling probes (dvt_prof.hip) ----
 extern unsigned g_dvt_prof_mask;

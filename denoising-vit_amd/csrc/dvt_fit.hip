@@ -24,6 +24,7 @@ struct Work {
   float *enc, *h1, *F, *raw, *dF, *dh1, *denc, *rows, *r1, *r2, *Hres, *dH, *dr2, *dr1;
   int32_t* g_offs;   // [num_iters, lattice + 1] row lists of the G gradient (nullptr: atomics path)
   uint16_t* g_perm;  // [num_iters, batch]
+  uint16_t* shadow;  // bf16 shadow copies of the MLP weights for the fused row kernel (nullptr: shapes not eligible)
 };
 
 bool row_lists_ok(const DvtFitConfig* c) { return c->lattice <= 8192 && c->batch <= 65535; }
@@ -57,6 +58,11 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
   if (row_lists_ok(c)) {
     t.g_offs = reinterpret_cast<int32_t*>(take((int64_t)c->num_iters * (c->lattice + 1)));
     t.g_perm = reinterpret_cast<uint16_t*>(take(((int64_t)c->num_iters * B + 1) / 2));
+  }
+  t.shadow = nullptr;
+  if (dvt_fit_fused_shapes_ok(c)) {
+    DvtShadowLayout L;
+    if (dvt_shadow_layout(c, &L) == 0) t.shadow = reinterpret_cast<uint16_t*>(take((L.total + 1) / 2));
   }
   if (w) *w = t;
   return o;
@@ -177,12 +183,6 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
   WS_TAB(rows, rows) WS_TAB(denc, denc)
 #undef WS_TAB
 
-  // ---- forward ----
-  {
-    float* gridp[KM];
-    at(P, c->off_grid, gridp);
-    DVT_TRY(dvt_fit_prep_k(&c->grid, k, xy, ridx, gridp, enc, feat, raw, B, C, s));
-  }
   // Linear layers go out as GROUPED launches: independent GEMMs of the step (field branch and
   // residual branch, weight- and data-gradient of one layer, all k fits) share one grid.
   auto fwd_op = [&](int f, const float* x, int64_t ow, int64_t ob, float* y, int n, int kk, int relu) {
@@ -200,9 +200,30 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     o.kind = 2; o.dy = dy; o.w = P[f] + ow; o.dx = dx; o.relu_mask = mask; o.m = B; o.n = n; o.k = kk;
     return o;
   };
-  DvtLinearOp ops[4 * KM];
+  DvtLinearOp ops[4 * KM];  // <= 16 problems per grouped launch (MULTI_MAX)
   int n_ops;
   auto launch = [&]() { return dvt_linear_group(ops, n_ops, s, c->mlp_bf16); };
+  const bool fused = dvt_fit_fused_ok(c) && ws[0].shadow != nullptr && ws[0].g_offs != nullptr;
+  DvtShadowLayout shl{};
+  uint16_t* shadow[KM] = {nullptr, nullptr, nullptr, nullptr};
+  if (fused) {
+    // ---- ONE launch for everything row-local: gather, grid forward, MLP forward, loss, dgrad chain ----
+    DVT_TRY(dvt_shadow_layout(c, &shl));
+    DvtFusedFit ff[KM];
+    for (int f = 0; f < k; ++f) {
+      const Work& w = ws[f];
+      shadow[f] = w.shadow;
+      ff[f] = DvtFusedFit{xy[f], ridx[f], feat[f], P[f], w.shadow, w.enc, w.h1, w.F, w.raw, w.dF, w.dh1, w.denc,
+                          w.rows, w.r1, w.r2, w.Hres, w.dH, w.dr2, w.dr1};
+    }
+    DVT_TRY(dvt_fit_rows_k(c, &shl, k, ff, use_res, s));
+  } else {
+  // ---- forward ----
+  {
+    float* gridp[KM];
+    at(P, c->off_grid, gridp);
+    DVT_TRY(dvt_fit_prep_k(&c->grid, k, xy, ridx, gridp, enc, feat, raw, B, C, s));
+  }
   n_ops = 0;
   for (int f = 0; f < k; ++f) {
     const Work& w = ws[f];
@@ -232,12 +253,36 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     DVT_TRY(dvt_loss_launch_k(k, Fp, Gp, ridx, c->lattice, use_res ? Hres : nullptr, raw, dF, dH, dG,
                               rows, B, C, (float)c->grad_scale, s));
   }
+  }  // !fused
   for (int f = 0; f < k; ++f) {
     const DvtFitBuffers* b = bs[f];
     const bool log = b->losses != nullptr &&
                      ((b->log_every > 0 && step % b->log_every == 0) || step == c->num_iters - 1);
     if (log) DVT_TRY(dvt_loss_reduce(ws[f].rows, b->losses + (size_t)step * 8, B, C, use_res, s));
   }
+  if (fused) {
+    // ---- all weight gradients of the step (the only part that reduces over rows) in ONE grouped launch
+    n_ops = 0;
+    for (int f = 0; f < k; ++f) {
+      const Work& w = ws[f];
+      ops[n_ops++] = wgrad_op(f, w.dF, w.h1, c->off_w2, c->off_b2, C, H);
+      ops[n_ops++] = wgrad_op(f, w.dh1, w.enc, c->off_w1, c->off_b1, H, E);
+    }
+    DVT_TRY(launch());
+    if (use_res) {  // (a grouped launch carries <= 16 problems: 2 + 3 per fit x 4 fits needs two)
+      n_ops = 0;
+      for (int f = 0; f < k; ++f) {
+        const Work& w = ws[f];
+        ops[n_ops++] = wgrad_op(f, w.dH, w.r2, c->off_wh3, c->off_bh3, C, R);
+        ops[n_ops++] = wgrad_op(f, w.dr2, w.r1, c->off_wh2, c->off_bh2, R, R);
+        ops[n_ops++] = wgrad_op(f, w.dr1, w.raw, c->off_wh1, c->off_bh1, R, C);
+      }
+      DVT_TRY(launch());
+    }
+    float* dgrid[KM];
+    at(Gd, c->off_grid, dgrid);
+    DVT_TRY(dvt_grid_bwd_k(&c->grid, k, xy, ridx, denc, dgrid, touched, B, s));
+  } else {
   // ---- backward: {field layer 2, h layer 3}, {field layer 1, h layer 2}, hash grid, {h layer 1}
   n_ops = 0;
   for (int f = 0; f < k; ++f) {
@@ -272,6 +317,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
       ops[n_ops++] = wgrad_op(f, ws[f].dr1, ws[f].raw, c->off_wh1, c->off_bh1, R, C);
     DVT_TRY(launch());
   }
+  }  // !fused
   // ---- Adam (dense) + zero_grad ----
   DvtAdamArgs a{};
   a.beta1 = c->beta1;
@@ -308,7 +354,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
       gather.rows[f] = ws[f].dF;
     }
   }
-  return dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather);
+  return dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather, fused ? &shl : nullptr, fused ? shadow : nullptr);
 }
 #undef DVT_TRY
 
@@ -341,6 +387,21 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
                                w[j].g_perm + (size_t)step_begin * c->batch, (hipStream_t)stream);
       if (rc) return rc;
     }
+  }
+  if (dvt_fit_fused_ok(c) && w[0].shadow != nullptr && w[0].g_offs != nullptr && step_end > step_begin) {
+    // the fp32 arena may have been (re)initialised by the caller: rebuild the bf16 shadow of the MLP
+    // weights once; from here on the Adam kernel keeps it current
+    DvtShadowLayout L;
+    int rc = dvt_shadow_layout(c, &L);
+    if (rc) return rc;
+    const float* pp[DVT_FIT_BATCH_MAX];
+    uint16_t* ss[DVT_FIT_BATCH_MAX];
+    for (int j = 0; j < k; ++j) {
+      pp[j] = bufs[j]->params;
+      ss[j] = w[j].shadow;
+    }
+    rc = dvt_shadow_build_k(&L, k, pp, ss, c->arena_floats, (hipStream_t)stream);
+    if (rc) return rc;
   }
   for (int step = step_begin; step < step_end; ++step) {
     int rc = fit_step(c, k, bufs, w, step, (hipStream_t)stream);

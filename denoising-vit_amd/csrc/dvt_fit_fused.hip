@@ -1,0 +1,345 @@
+// The fused ROW kernel of the fit step: everything of one Adam step that is local to a sampled row
+// runs in ONE launch -- raw-row gather, hash-grid forward, the field MLP and the residual predictor
+// forward, the loss with all its gradients, and the data-gradient (dgrad) chain back to the encoding.
+//
+// Reference: the body of the inner loop, main_img_denoising.py:73-88, through
+// dvt/models/neural_feature_field.py:46-49 (enc -> Linear/ReLU/Linear) and
+// dvt/models/offline_denoiser.py:96-140 (G lookup, residual predictor, losses) and autograd's
+// backward of the same.  bf16-operand mode only (DvtFitConfig.mlp_bf16, the reference's
+// `--dtype bfloat16`): operands are rounded to bf16, accumulation / bias / ReLU / losses stay fp32.
+//
+// Why this shape.  With B = 2048 sampled rows the step used to be 5 dependent grouped-GEMM launches +
+// the loss, each latency-bound (65 TF/s = 2.6 % of the bf16 MFMA peak) with every activation
+// round-tripping HBM.  Forward, loss and dgrad are ROW-LOCAL, only the weight gradients reduce over
+// rows.  So a workgroup owns 16 rows through the whole chain:
+//   * activations never leave the CU between layers: bf16 [16][K] images in LDS (+16 B row padding),
+//     read as MFMA A fragments (v_mfma_f32_16x16x32_bf16, M = 16 rows);
+//   * the 8 waves split every layer's OUTPUT columns (tile t -> wave t % 8), so no two waves share a
+//     weight element: each B fragment goes straight from global/L2 into VGPRs as one 16-byte load of a
+//     k-contiguous bf16 shadow copy (dvt_common.h: DvtShadowLayout) -- an LDS stage would be pure
+//     overhead (operand streamed once per workgroup, the CDNA guide's M <= 16 rule) -- software
+//     pipelined PD k-steps ahead in registers;
+//   * what the weight-gradient GEMMs, the grid backward and Adam need (enc, h1, dF, dh1, denc, ...) is
+//     written once as fp32 rows.
+// Per workgroup the bound is the weight stream through one CU (1.3 MB phase 1 / 2.3 MB phase 2 of L2
+// hits); 128 workgroups cover B = 2048.
+#include "dvt_common.h"
+#include "dvt_grid_dev.h"
+#include "dvt_loss_row.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int FR = 16;   // rows per workgroup = M of the MFMA
+constexpr int FW = 8;    // waves per workgroup
+constexpr int FE = 128;  // encoding width: 16 levels x 8 features
+
+// LDS row pitch of a [16][K] bf16 activation image: +16 B so that the 16 rows of an A-fragment read
+// (ds_read_b128, 16 B per lane) fall on distinct 16-byte bank slots
+__host__ __device__ constexpr int apitch(int K) { return K * 2 + 16; }
+
+struct FusedArgs {
+  DvtGridTable T;
+  DvtShadowLayout S;
+  int n, lattice;
+  float grad_scale;
+  long long off_grid, off_b1, off_b2, off_G, off_bh1, off_bh2, off_bh3;
+  DvtFusedFit f[DVT_FIT_BATCH_MAX];
+};
+
+__device__ __forceinline__ uint16_t bf16_of(float v) { return (uint16_t)(dvt_pack_bf16x2(v, 0.f) & 0xffffu); }
+
+// out[16][N] = act(A[16][K] . W[N][K]^T + bias)  (optionally masked by mask[16][N] > 0)
+//   actA    LDS bf16 image [16][K], pitch apitch(K)
+//   W       global bf16 [N][K] (shadow copy), k-contiguous rows
+//   act_out LDS bf16 image [16][N] for the next layer (may alias `mask`: every element is read, then
+//           written, by the one lane that owns it), or nullptr
+//   gout    global fp32 [16][N] (this workgroup's rows), or nullptr
+template <int K, int N, bool RELU, bool MASK>
+__device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __restrict__ W,
+                                          const float* __restrict__ bias, char* act_out,
+                                          float* __restrict__ gout, const char* mask, int wave, int lane) {
+  constexpr int NTILES = N / 16, NT = (NTILES + FW - 1) / FW, S = K / 32;
+  constexpr int PD0 = NT >= 6 ? 2 : (NT >= 3 ? 4 : 8);
+  constexpr int PD = PD0 < S ? PD0 : S;  // k-steps of weights in flight per wave
+  static_assert(K % 32 == 0 && N % 16 == 0, "layer shape");
+  const int lc = lane & 15, g = lane >> 4;
+  f32x4 acc[NT];
+  const uint16_t* wp[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int t = wave + FW * i;
+    const int tt = (NTILES % FW == 0 || t < NTILES) ? t : 0;  // surplus tiles compute tile 0 again, never stored
+    wp[i] = W + (size_t)(tt * 16 + lc) * K + 8 * g;
+  }
+  bf16x8 b[PD][NT];
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) b[p][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 32 * p);
+  const char* ap = actA + lc * apitch(K) + g * 16;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const bf16x8 av = *reinterpret_cast<const bf16x8*>(ap + s * 64);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[s % PD][i], acc[i], 0, 0, 0);
+    if (s + PD < S) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) b[s % PD][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 32 * (s + PD));
+    }
+  }
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int t = wave + FW * i;
+    if (NTILES % FW != 0 && t >= NTILES) continue;  // wave-uniform
+    const int n = t * 16 + lc;
+    const float bv = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * g + r;
+      float v = acc[i][r] + bv;
+      if (RELU) v = fmaxf(v, 0.f);
+      if (MASK) {
+        const uint16_t m = *reinterpret_cast<const uint16_t*>(mask + row * apitch(N) + n * 2);
+        v = (m != 0 && !(m & 0x8000u)) ? v : 0.f;  // ReLU output > 0
+      }
+      if (act_out != nullptr) *reinterpret_cast<uint16_t*>(act_out + row * apitch(N) + n * 2) = bf16_of(v);
+      if (gout != nullptr) gout[(size_t)row * N + n] = v;
+    }
+  }
+}
+
+template <int C, bool PH2>
+struct FusedLds {
+  static constexpr int H = C / 2, R = C / 4;
+  static constexpr int O_ENC = 0;
+  static constexpr int O_H1 = O_ENC + FR * apitch(FE);   // h1, later dh1 in place
+  static constexpr int O_DF = O_H1 + FR * apitch(H);     // d(pred)
+  static constexpr int O_RAW = O_DF + FR * apitch(C);    // phase 2: raw rows, later d(Hres)
+  static constexpr int O_R1 = O_RAW + FR * apitch(C);    // phase 2: r1
+  static constexpr int O_R2 = O_R1 + FR * apitch(R);     // phase 2: r2, later dr2 in place
+  static constexpr int TOTAL = PH2 ? O_R2 + FR * apitch(R) : O_RAW;
+};
+
+template <int C, bool PH2>
+__global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
+  using L = FusedLds<C, PH2>;
+  constexpr int H = C / 2, R = C / 4, E = FE, cq = C / 4;
+  __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
+  const DvtFusedFit& f = a.f[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * FR;
+  const uint16_t* __restrict__ sh = f.shadow;
+  const float* __restrict__ P = f.params;
+  const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(f.feat);
+
+  // ---- prologue: hash-grid forward of the 16 rows (one (row, level) pair per thread, tcnn semantics in
+  //      dvt_grid.hip) and, in phase 2, the raw rows as the residual predictor's input
+  if (tid < FR * 16) {
+    const int r = tid >> 4, l = tid & 15;
+    const float2 p = reinterpret_cast<const float2*>(f.xy)[f.ridx[row0 + r]];
+    uint32_t idx[4];
+    float w[4];
+    corners2d(a.T, l, p.x, p.y, idx, w);
+    const float4* __restrict__ grid = reinterpret_cast<const float4*>(P + a.off_grid);
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 u = grid[(size_t)idx[c] * 2], v = grid[(size_t)idx[c] * 2 + 1];
+      lo.x = fmaf(w[c], u.x, lo.x);
+      lo.y = fmaf(w[c], u.y, lo.y);
+      lo.z = fmaf(w[c], u.z, lo.z);
+      lo.w = fmaf(w[c], u.w, lo.w);
+      hi.x = fmaf(w[c], v.x, hi.x);
+      hi.y = fmaf(w[c], v.y, hi.y);
+      hi.z = fmaf(w[c], v.z, hi.z);
+      hi.w = fmaf(w[c], v.w, hi.w);
+    }
+    float4* eg = reinterpret_cast<float4*>(f.enc + (size_t)(row0 + r) * E + l * 8);
+    eg[0] = lo;
+    eg[1] = hi;
+    *reinterpret_cast<uint4*>(smem + L::O_ENC + r * apitch(E) + l * 16) =
+        make_uint4(dvt_pack_bf16x2(lo.x, lo.y), dvt_pack_bf16x2(lo.z, lo.w), dvt_pack_bf16x2(hi.x, hi.y),
+                   dvt_pack_bf16x2(hi.z, hi.w));
+  }
+  if (PH2) {
+    for (int i = tid; i < FR * cq; i += 64 * FW) {
+      const int r = i / cq, q = i - r * cq;
+      const float4 v = feat4[(size_t)f.ridx[row0 + r] * cq + q];
+      reinterpret_cast<float4*>(f.raw)[(size_t)(row0 + r) * cq + q] = v;  // B operand of the Wh1 weight gradient
+      *reinterpret_cast<uint2*>(smem + L::O_RAW + r * apitch(C) + q * 8) =
+          make_uint2(dvt_pack_bf16x2(v.x, v.y), dvt_pack_bf16x2(v.z, v.w));
+    }
+  }
+  __syncthreads();
+
+  // ---- forward: field MLP (neural_feature_field.py:40-44, :49), residual predictor (offline_denoiser.py:107)
+  mlp_layer<E, H, true, false>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1,
+                               f.h1 + (size_t)row0 * H, nullptr, wave, lane);
+  if (PH2)
+    mlp_layer<C, R, true, false>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1,
+                                 f.r1 + (size_t)row0 * R, nullptr, wave, lane);
+  __syncthreads();
+  mlp_layer<H, C, false, false>(smem + L::O_H1, sh + a.S.direct[1], P + a.off_b2, nullptr,
+                                f.F + (size_t)row0 * C, nullptr, wave, lane);
+  if (PH2) {
+    mlp_layer<R, R, true, false>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2,
+                                 f.r2 + (size_t)row0 * R, nullptr, wave, lane);
+    __syncthreads();
+    mlp_layer<R, C, false, false>(smem + L::O_R2, sh + a.S.direct[4], P + a.off_bh3, nullptr,
+                                  f.Hres + (size_t)row0 * C, nullptr, wave, lane);
+  }
+  __syncthreads();  // F (and Hres) rows of this workgroup are visible to all of its waves
+
+  // ---- loss + gradients (offline_denoiser.py:113-140), one wave per row, two rows per wave; the
+  //      gradient of G is gathered inside Adam from the d(pred) rows written here
+#pragma unroll
+  for (int rr = 0; rr < FR / FW; ++rr) {
+    const int row = wave + FW * rr, gr = row0 + row;
+    const int ri = f.ridx[gr];
+    const int grow = ri % a.lattice;
+    dvt_loss_row<PH2>(reinterpret_cast<const float4*>(f.F) + (size_t)gr * cq,
+                      reinterpret_cast<const float4*>(P + a.off_G) + (size_t)grow * cq,
+                      PH2 ? reinterpret_cast<const float4*>(f.Hres) + (size_t)gr * cq : nullptr,
+                      feat4 + (size_t)ri * cq, reinterpret_cast<float4*>(f.dF) + (size_t)gr * cq,
+                      PH2 ? reinterpret_cast<float4*>(f.dH) + (size_t)gr * cq : nullptr, nullptr,
+                      f.rows + (size_t)gr * 8, a.n, cq, a.grad_scale, lane,
+                      reinterpret_cast<uint2*>(smem + L::O_DF + row * apitch(C)),
+                      PH2 ? reinterpret_cast<uint2*>(smem + L::O_RAW + row * apitch(C)) : nullptr);
+  }
+  __syncthreads();
+
+  // ---- data gradients: dh1 = (dF . W2) * (h1 > 0), denc = dh1 . W1; dr2 = (dH . Wh3) * (r2 > 0),
+  //      dr1 = (dr2 . Wh2) * (r1 > 0)  (the [K][N] shadow copies make these k-contiguous as well)
+  mlp_layer<C, H, false, true>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1,
+                               f.dh1 + (size_t)row0 * H, smem + L::O_H1, wave, lane);
+  if (PH2)
+    mlp_layer<C, R, false, true>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2,
+                                 f.dr2 + (size_t)row0 * R, smem + L::O_R2, wave, lane);
+  __syncthreads();
+  mlp_layer<H, E, false, false>(smem + L::O_H1, sh + a.S.transp[0], nullptr, nullptr,
+                                f.denc + (size_t)row0 * E, nullptr, wave, lane);
+  if (PH2)
+    mlp_layer<R, R, false, true>(smem + L::O_R2, sh + a.S.transp[3], nullptr, nullptr,
+                                 f.dr1 + (size_t)row0 * R, smem + L::O_R1, wave, lane);
+}
+
+// one float4 of the arena per thread -> its bf16 shadow copies
+__global__ __launch_bounds__(256) void shadow_build_kernel(DvtShadowLayout L, const float* const p0,
+                                                           const float* const p1, const float* const p2,
+                                                           const float* const p3, uint16_t* s0, uint16_t* s1,
+                                                           uint16_t* s2, uint16_t* s3, long long q_lo, long long q_hi) {
+  const float* p = blockIdx.y == 0 ? p0 : (blockIdx.y == 1 ? p1 : (blockIdx.y == 2 ? p2 : p3));
+  uint16_t* sh = blockIdx.y == 0 ? s0 : (blockIdx.y == 1 ? s1 : (blockIdx.y == 2 ? s2 : s3));
+  const long long q = q_lo + (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= q_hi) return;
+  dvt_shadow_store(L, sh, q * 4, reinterpret_cast<const float4*>(p)[q]);
+}
+
+template <int C>
+int launch_rows(const FusedArgs& a, int k, bool phase2, hipStream_t s) {
+  dim3 grid(a.n / FR, k), block(64 * FW);
+  if (phase2)
+    hipLaunchKernelGGL((fit_rows_kernel<C, true>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((fit_rows_kernel<C, false>), grid, block, 0, s, a);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* L) {
+  if (!c || !L) return DVT_E_BADARG;
+  const int C = c->feat_dim, H = c->hidden, R = c->res_hidden;
+  const int E = c->grid.n_levels * c->grid.n_features;
+  const int Ns[DVT_SHADOW_MATS] = {H, C, R, R, C}, Ks[DVT_SHADOW_MATS] = {E, H, C, R, R};
+  const long long begins[DVT_SHADOW_MATS] = {c->off_w1, c->off_w2, c->off_wh1, c->off_wh2, c->off_wh3};
+  const bool tr[DVT_SHADOW_MATS] = {true, true, false, true, true};  // no data gradient flows into `raw`
+  long long o = 0;
+  L->n = DVT_SHADOW_MATS;
+  L->lo = begins[0];
+  L->hi = 0;
+  for (int i = 0; i < DVT_SHADOW_MATS; ++i) {
+    if (Ks[i] % 8 || Ns[i] % 8) return DVT_E_BADARG;
+    L->N[i] = Ns[i];
+    L->K[i] = Ks[i];
+    L->begin[i] = begins[i];
+    const long long sz = (long long)Ns[i] * Ks[i];
+    L->direct[i] = o;
+    o += sz;
+    L->transp[i] = tr[i] ? o : -1;
+    if (tr[i]) o += sz;
+    if (begins[i] < L->lo) L->lo = begins[i];
+    if (begins[i] + sz > L->hi) L->hi = begins[i] + sz;
+  }
+  L->total = o;
+  return 0;
+}
+
+int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, uint16_t* const* shadow,
+                       long long arena_floats, hipStream_t s) {
+  if (!L || k < 1 || k > DVT_FIT_BATCH_MAX || L->n <= 0) return DVT_E_BADARG;
+  const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint16_t* sh[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int f = 0; f < k; ++f) {
+    if (!params[f] || !shadow[f]) return DVT_E_BADARG;
+    p[f] = params[f];
+    sh[f] = shadow[f];
+  }
+  const long long q_lo = L->lo / 4, q_hi = (L->hi < arena_floats ? L->hi : arena_floats) / 4;
+  if (q_hi <= q_lo) return 0;
+  hipLaunchKernelGGL(shadow_build_kernel, dim3(dvt_cdiv(q_hi - q_lo, 256), k), dim3(256), 0, s, *L, p[0], p[1],
+                     p[2], p[3], sh[0], sh[1], sh[2], sh[3], q_lo, q_hi);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+int g_fit_fused_enable = 1;  // dvt_tune_set(6, 0): the unfused launch sequence (same results, A/B timing + parity)
+bool dvt_fit_fused_ok(const DvtFitConfig* c) {
+  return g_fit_fused_enable && c && c->mlp_bf16 && dvt_fit_fused_shapes_ok(c);
+}
+
+bool dvt_fit_fused_shapes_ok(const DvtFitConfig* c) {
+  if (!c) return false;
+  if (c->grid.n_levels != 16 || c->grid.n_features != 8) return false;
+  const int C = c->feat_dim;
+  if (C != 384 && C != 768 && C != 1024) return false;
+  if (c->hidden != C / 2 || c->res_hidden != C / 4) return false;
+  if (c->batch % FR || c->batch <= 0) return false;
+  return c->lattice <= 8192 && c->batch <= 65535;  // G gradient through Adam's row lists
+}
+
+int dvt_fit_rows_k(const DvtFitConfig* c, const DvtShadowLayout* L, int k, const DvtFusedFit* fits, bool phase2,
+                   hipStream_t s) {
+  if (!dvt_fit_fused_ok(c) || !L || !fits || k < 1 || k > DVT_FIT_BATCH_MAX) return DVT_E_BADARG;
+  FusedArgs a{};
+  a.T = c->grid;
+  a.S = *L;
+  a.n = c->batch;
+  a.lattice = c->lattice;
+  a.grad_scale = (float)c->grad_scale;
+  a.off_grid = c->off_grid;
+  a.off_b1 = c->off_b1;
+  a.off_b2 = c->off_b2;
+  a.off_G = c->off_G;
+  a.off_bh1 = c->off_bh1;
+  a.off_bh2 = c->off_bh2;
+  a.off_bh3 = c->off_bh3;
+  for (int f = 0; f < k; ++f) a.f[f] = fits[f];
+  const double C = c->feat_dim, H = c->hidden, R = c->res_hidden, E = FE, B = c->batch;
+  // forward + dgrad flops of the row chain (the wgrad half of the step runs in the grouped GEMM launch)
+  const double flops = 2.0 * B * (2.0 * (E * H + H * C) + (phase2 ? (C * R + 2.0 * R * R + 2.0 * R * C) : 0.0));
+  DvtProbeScope probe(DVT_PROBE_FIT_ROWS, s, flops * k);
+  switch (c->feat_dim) {
+    case 384: return launch_rows<384>(a, k, phase2, s);
+    case 768: return launch_rows<768>(a, k, phase2, s);
+    default: return launch_rows<1024>(a, k, phase2, s);
+  }
+}

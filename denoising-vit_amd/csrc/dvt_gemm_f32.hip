@@ -690,6 +690,7 @@ int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s, int bf16_
 namespace {
 extern int g_cfg_override;
 }
+extern int g_fit_fused_enable;
 extern "C" int dvt_tune_set(int key, int value) {
   if (key == 0) {
     g_cfg_override = value;
@@ -702,6 +703,10 @@ extern "C" int dvt_tune_set(int key, int value) {
   if (key == 5) {
     if (value != 16 && value != 32 && value != 64) return DVT_E_BADARG;
     g_f32_bk = value;
+    return 0;
+  }
+  if (key == 6) {
+    g_fit_fused_enable = value != 0;
     return 0;
   }
   if (key == 1) return dvt_vit_tune(value);

@@ -13,10 +13,11 @@
 // One wave (64 lanes) owns one row of C <= 1024 channels, kept in registers as float4 so
 // that every tensor is read exactly once and the gradient rows are written exactly once.
 #include "dvt_common.h"
+#include "dvt_loss_row.h"
 
 namespace {
 
-constexpr int MAXQ = 4;  // float4 slots per lane: C <= 64*4*4 = 1024
+constexpr int MAXQ = DVT_LOSS_MAXQ;
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restrict__ src,
                                                           const int32_t* __restrict__ idx,
@@ -108,11 +109,6 @@ __global__ __launch_bounds__(256) void bilinear_rows_bwd_kernel(const float* __r
   }
 }
 
-__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
-  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
-__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
-
 // HAS_RES: the residual predictor output Hres participates (phase 2).
 struct LossPtrs {  // per fit of a batched launch (blockIdx.y)
   const float4* F[DVT_FIT_BATCH_MAX];
@@ -129,109 +125,24 @@ struct LossPtrs {  // per fit of a batched launch (blockIdx.y)
 template <bool HAS_RES>
 __global__ __launch_bounds__(256) void loss_kernel(LossPtrs q, int lattice, int n, int cq,
                                                    float grad_scale) {
-  const float4* __restrict__ F = q.F[blockIdx.y];
-  const float4* __restrict__ G = q.G[blockIdx.y];
   const int32_t* __restrict__ g_idx = q.g_idx[blockIdx.y];
-  const float4* __restrict__ Hres = q.Hres[blockIdx.y];
-  const float4* __restrict__ raw = q.raw[blockIdx.y];
-  float4* __restrict__ d_pred = q.d_pred[blockIdx.y];
-  float4* __restrict__ d_hres = q.d_hres[blockIdx.y];
-  float* __restrict__ d_G = q.d_G[blockIdx.y];
-  float* __restrict__ row_sums = q.row_sums[blockIdx.y];
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
   int grow = g_idx != nullptr ? g_idx[row] : row;
   if (lattice > 0) grow %= lattice;
   const size_t base = (size_t)row * cq, gbase = (size_t)grow * cq;
-
-  float4 vp[MAXQ], vr[MAXQ], vh[MAXQ], vfg[MAXQ];
-  float sse = 0.f, dot = 0.f, np = 0.f, nr = 0.f, rsse = 0.f, rabs = 0.f;
-#pragma unroll
-  for (int s = 0; s < MAXQ; ++s) {
-    const int q = lane + 64 * s;
-    if (q < cq) {
-      const float4 f = F[base + q], g = G[gbase + q], r = raw[base + q];
-      float4 fg = f4_add(f, g);
-      float4 p = fg;
-      if (HAS_RES) {
-        const float4 h = Hres[base + q];
-        vh[s] = h;
-        p = f4_add(fg, h);
-        // gt_residual = raw - F - G ; residual terms use (h - gt)
-        const float ex = h.x - (r.x - fg.x), ey = h.y - (r.y - fg.y), ez = h.z - (r.z - fg.z),
-                    ew = h.w - (r.w - fg.w);
-        rsse += ex * ex + ey * ey + ez * ez + ew * ew;
-        rabs += fabsf(h.x) + fabsf(h.y) + fabsf(h.z) + fabsf(h.w);
-      }
-      vp[s] = p;
-      vr[s] = r;
-      vfg[s] = fg;
-      const float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z, dw = p.w - r.w;
-      sse += dx * dx + dy * dy + dz * dz + dw * dw;
-      dot += p.x * r.x + p.y * r.y + p.z * r.z + p.w * r.w;
-      np += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
-      nr += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
-    }
-  }
-  sse = wave_sum(sse);
-  dot = wave_sum(dot);
-  np = wave_sum(np);
-  nr = wave_sum(nr);
-  if (HAS_RES) {
-    rsse = wave_sum(rsse);
-    rabs = wave_sum(rabs);
-  }
-  // torch (ATen cosine_similarity): sum(x/max(|x|,eps) * y/max(|y|,eps)), eps = 1e-8
-  const float n1 = sqrtf(np), n2 = sqrtf(nr);
-  const bool clamped = n1 < 1e-8f;
-  const float denom = fmaxf(n1, 1e-8f) * fmaxf(n2, 1e-8f);
-  const float cosv = dot / denom;
-  if (lane == 0 && row_sums != nullptr) {
-    float* o = row_sums + (size_t)row * 8;
-    o[0] = sse;
-    o[1] = cosv;
-    o[2] = rsse;
-    o[3] = rabs;
-  }
-  if (d_pred == nullptr) return;
-  const float inv_nc = 1.0f / ((float)n * (float)(cq * 4));
-  const float inv_n = 1.0f / (float)n;
-  // d/dp [mse] = 2 (p - r) / (n c);  d/dp [1 - mean cos] = -(1/n) (r/denom - cos * p / |p|^2)
-  // (when the clamp is active the denominator is constant: gradient = -(1/n) r / denom)
-  const float a_r = -inv_n / denom;
-  const float a_p = clamped ? 0.f : inv_n * cosv / np;
-  const float c_mse = 2.0f * inv_nc;
-#pragma unroll
-  for (int s = 0; s < MAXQ; ++s) {
-    const int q = lane + 64 * s;
-    if (q < cq) {
-      const float4 p = vp[s], r = vr[s];
-      float4 d;
-      d.x = grad_scale * (c_mse * (p.x - r.x) + a_r * r.x + a_p * p.x);
-      d.y = grad_scale * (c_mse * (p.y - r.y) + a_r * r.y + a_p * p.y);
-      d.z = grad_scale * (c_mse * (p.z - r.z) + a_r * r.z + a_p * p.z);
-      d.w = grad_scale * (c_mse * (p.w - r.w) + a_r * r.w + a_p * p.w);
-      d_pred[base + q] = d;
-      if (d_G != nullptr) {
-        float* g = d_G + (gbase + q) * 4;
-        atomic_add_f32(g + 0, d.x);
-        atomic_add_f32(g + 1, d.y);
-        atomic_add_f32(g + 2, d.z);
-        atomic_add_f32(g + 3, d.w);
-      }
-      if (HAS_RES && d_hres != nullptr) {
-        const float4 h = vh[s], fg = vfg[s];
-        const float c_res = 0.1f * 2.0f * inv_nc, c_abs = 0.02f * inv_nc;
-        float4 e;
-        e.x = grad_scale * (c_res * (h.x - (r.x - fg.x)) + c_abs * sgn(h.x));
-        e.y = grad_scale * (c_res * (h.y - (r.y - fg.y)) + c_abs * sgn(h.y));
-        e.z = grad_scale * (c_res * (h.z - (r.z - fg.z)) + c_abs * sgn(h.z));
-        e.w = grad_scale * (c_res * (h.w - (r.w - fg.w)) + c_abs * sgn(h.w));
-        d_hres[base + q] = e;
-      }
-    }
-  }
+  float4* d_pred = q.d_pred[blockIdx.y];
+  float4* d_hres = q.d_hres[blockIdx.y];
+  float* d_G = q.d_G[blockIdx.y];
+  float* row_sums = q.row_sums[blockIdx.y];
+  dvt_loss_row<HAS_RES>(q.F[blockIdx.y] + base, q.G[blockIdx.y] + gbase,
+                        HAS_RES ? q.Hres[blockIdx.y] + base : nullptr, q.raw[blockIdx.y] + base,
+                        d_pred != nullptr ? d_pred + base : nullptr,
+                        (HAS_RES && d_hres != nullptr) ? d_hres + base : nullptr,
+                        d_G != nullptr ? d_G + gbase * 4 : nullptr,
+                        row_sums != nullptr ? row_sums + (size_t)row * 8 : nullptr, n, cq, grad_scale, lane,
+                        nullptr, nullptr);
 }
 
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ row_sums,

@@ -21,6 +21,7 @@ HIP_SOURCES = [
     "dvt_loss.hip",
     "dvt_adam.hip",
     "dvt_fit.hip",
+    "dvt_fit_fused.hip",
     "dvt_vit.hip",
     "dvt_prof.hip",
     "dvt_views.hip",
@@ -156,7 +157,7 @@ _SIGNATURES = {
     "dvt_prof_collect": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
-PROBES = {"adam": 0, "vit_gemm": 1, "vit_attn": 2, "fit_gemm": 3, "grid": 4}
+PROBES = {"adam": 0, "vit_gemm": 1, "vit_attn": 2, "fit_gemm": 3, "grid": 4, "fit_rows": 5}
 
 
 def prof_enable(names=()) -> None:

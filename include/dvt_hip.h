@@ -266,6 +266,7 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);
  * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
+ * key 6 = bf16-mode fit step: 1 (default) the fused row kernel (dvt_fit_fused.hip), 0 = one launch per layer;
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);
 
@@ -280,6 +281,7 @@ int dvt_tune_set(int key, int value);
 #define DVT_PROBE_VIT_ATTN 2  /* attention launches; work = 4*S*S*64*heads*batch flops */
 #define DVT_PROBE_FIT_GEMM 3  /* fp32 MFMA linear fwd/bwd launches; work = flops */
 #define DVT_PROBE_GRID 4      /* hash-grid fwd+bwd launches; work = algorithmic bytes */
+#define DVT_PROBE_FIT_ROWS 5  /* fused row kernel of the fit (forward + loss + dgrad); work = its MLP flops */
 #define DVT_N_PROBES 8
 /* HOST: enable probes whose bit is set in mask (0 disables all); resets accumulated samples. */
 int dvt_prof_enable(unsigned mask);

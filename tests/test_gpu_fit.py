@@ -240,3 +240,46 @@ def test_bf16_operand_fit_vs_oracles(built_lib):
     for step in (0, 5, iters // 2 + 3, iters - 1):                 # losses track the fp32 loop
         a, b = logs["bfloat16"][step]["loss"], want32_log[step]["loss"]
         assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (step, a, b)
+
+
+@pytest.mark.parametrize("C,V", [(768, 6), (1024, 4), (384, 6)])
+def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
+    """The fused row kernel of the bf16-mode step (dvt_fit_fused.hip: gather + grid forward + MLP forward +
+    loss + dgrad in one launch, bf16 shadow weights maintained by Adam) against the layer-by-layer launch
+    sequence (dvt_tune_set(6, 0)) on identical inputs, across the phase switch.  Both round the same operands
+    to bf16 and accumulate in fp32; only the summation order inside the MFMAs differs, so parameters and
+    losses must agree far tighter than any bf16 effect -- an indexing / layout bug cannot hide here."""
+    from dvt_amd.fit import FitEngine, FitSettings
+    H = W = 37
+    feats, xy = synthetic_image(V, H, W, C, seed=C)
+    n_rows = V * H * W
+    T = 16
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=2, mlp_dtype="bfloat16")
+    idx = np.random.RandomState(C).randint(0, n_rows, (T, s.pixel_bsz)).astype(np.int32)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    res = {}
+    try:
+        for fused in (1, 0):
+            assert built_lib.dvt_tune_set(6, fused) == 0
+            eng = FitEngine(s, n_rows, DEV)
+            eng.reset(torch.Generator(device=DEV).manual_seed(1))
+            eng.fit(f, c, idx, log_every=1)
+            torch.cuda.synchronize()
+            res[fused] = (eng.params.clone(), eng.loss_log(), eng.infer(xy[-1].to(DEV)).cpu())
+            assert float(eng.grads.abs().max()) == 0.0 and int(eng.touched.abs().max()) == 0
+            del eng
+    finally:
+        built_lib.dvt_tune_set(6, 1)
+    (p1, l1, o1), (p0, l0, o0) = res[1], res[0]
+    for step in range(T):
+        for k, v in l0[step].items():
+            assert abs(l1[step][k] - v) <= 2e-4 * max(1.0, abs(v)), (step, k, l1[step][k], v)
+    assert "residual_loss" in l1[T - 1] and l1[T - 1]["residual_loss"] != 0.0
+    d = (p1 - p0).abs()
+    scale = float(p0.abs().max())
+    print(f"fused vs layer-by-layer (C={C}): params max |diff| {float(d.max()):.3e} (scale {scale:.2f}), "
+          f"mean {float(d.mean()):.3e}")
+    # Adam normalises every step to ~lr, so a sign flip of a near-zero gradient moves a parameter by ~2 lr;
+    # the bulk must be tight, single elements may differ by a few lr
+    assert float(d.mean()) < 2e-5 and float(d.max()) < 0.05
+    assert per_patch_cos(o1, o0).min() > 0.9999
