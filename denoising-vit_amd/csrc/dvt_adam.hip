@@ -65,16 +65,14 @@ struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
   float4* V[DVT_FIT_BATCH_MAX];
   float4* G[DVT_FIT_BATCH_MAX];
   uint32_t* touched[DVT_FIT_BATCH_MAX];
-  uint16_t* shadow[DVT_FIT_BATCH_MAX];  // bf16 shadow copies of the MLP weights (fused fit kernel), or nullptr
 };
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, AdamGather gr, DvtShadowLayout sh) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, AdamGather gr) {
   float4* __restrict__ P = q.P[blockIdx.y];
   float4* __restrict__ M = q.M[blockIdx.y];
   float4* __restrict__ V = q.V[blockIdx.y];
   float4* __restrict__ G = q.G[blockIdx.y];
   uint32_t* __restrict__ touched = q.touched[blockIdx.y];
-  uint16_t* __restrict__ shadow = q.shadow[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long wave_stride = (long long)gridDim.x * 4;
@@ -125,9 +123,6 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
     P[q] = p;
     M[q] = m;
     V[q] = v;
-    // the updated MLP weights also go out as bf16 (direct + transposed): next step's fused row kernel
-    // reads its MFMA operands from these copies (wave-uniform range test: grid chunks never enter)
-    if (sh.n > 0 && q0 * 4 + 256 > sh.lo && q0 * 4 < sh.hi) dvt_shadow_store(sh, shadow, q * 4, p);
     if (has || (sparse && a.zero_all)) G[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero_grad
     if (sparse && word != 0u && lane == 0) touched[q0 >> 6] = 0u;
   }
@@ -147,8 +142,7 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
 
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
-                    const DvtAdamRowGather* gather, const DvtShadowLayout* shadow_layout,
-                    uint16_t* const* shadow) {
+                    const DvtAdamRowGather* gather) {
   if (!h || k < 1 || k > DVT_FIT_BATCH_MAX || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
     return DVT_E_BADARG;
   if (h->sparse_end & 255) return DVT_E_BADARG;
@@ -160,13 +154,6 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
     q.V[f] = (float4*)v[f];
     q.G[f] = (float4*)g[f];
     q.touched[f] = touched[f];
-    q.shadow[f] = (shadow_layout != nullptr && shadow != nullptr) ? shadow[f] : nullptr;
-  }
-  DvtShadowLayout sh{};
-  if (shadow_layout != nullptr && shadow != nullptr) {
-    sh = *shadow_layout;
-    for (int f = 0; f < k; ++f)
-      if (!shadow[f]) return DVT_E_BADARG;
   }
   AdamGather gr{};
   gr.q_begin = gr.q_end = -1;
@@ -221,7 +208,7 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
   if (blocks > 256 * 16) blocks = 256 * 16;
   {
     DvtProbeScope probe(DVT_PROBE_ADAM, stream, work * k);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr, sh);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
     DVT_CHECK_LAUNCH();
   }
   return 0;

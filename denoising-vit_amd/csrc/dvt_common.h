@@ -60,21 +60,19 @@ struct DvtAdamRowGather {
   const uint16_t* perm[DVT_FIT_BATCH_MAX];  // [batch] of this step, per fit
   const float* rows[DVT_FIT_BATCH_MAX];     // d_pred [batch, c], per fit
 };
-struct DvtShadowLayout;
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
-                    const DvtAdamRowGather* gather = nullptr, const DvtShadowLayout* shadow_layout = nullptr,
-                    uint16_t* const* shadow = nullptr);
+                    const DvtAdamRowGather* gather = nullptr);
 // offs [steps, lattice + 1] / perm [steps, batch] for steps [0, steps) of idx [steps, batch]; lattice <= 8192,
 // batch <= 65535
 int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,
                         uint16_t* perm, hipStream_t stream);
 
 // ---- fused row kernel of the fit (dvt_fit_fused.hip) ----
-// bf16 SHADOW copies of the five MLP weight matrices (W1, W2, Wh1, Wh2, Wh3), kept next to the fp32
-// master weights by the Adam kernel: [N][K] as stored (forward operand) and, where a data gradient
-// flows back through the layer, [K][N] (dgrad operand), so that every MFMA B fragment of the fused
-// kernel is ONE 16-byte k-contiguous global load.
+// bf16 SHADOW copies of the five MLP weight matrices (W1, W2, Wh1, Wh2, Wh3), rebuilt from the fp32
+// master weights after every Adam step: [N][K] (forward operand) and, where a data gradient flows back
+// through the layer, [K][N] (dgrad operand), both in MFMA-fragment-major order (dvt_frag_off) so that
+// every B fragment of the fused kernel is one fully coalesced 16-byte-per-lane global load.
 #define DVT_SHADOW_MATS 5
 struct DvtShadowLayout {
   int n;                         // matrices present (0: no shadow maintained)
@@ -87,9 +85,12 @@ struct DvtShadowLayout {
   long long total;               // bf16 elements
 };
 int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* out);
-// (re)build the whole shadow from the fp32 arena (start of a run; Adam keeps it current afterwards)
+
+// (re)build the shadow copies of the matrices inside arena floats [lo, hi) from the fp32 master weights: the
+// whole range at the start of a run, the ranges Adam just stepped after every step (a 2-3 us launch; inside
+// the Adam kernel the extra scalar registers cost its streaming loop a wave per SIMD, ~10 % bandwidth)
 int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, uint16_t* const* shadow,
-                       long long arena_floats, hipStream_t s);
+                       long long lo, long long hi, hipStream_t s);
 struct DvtFusedFit {  // per fit: inputs, arena, shadow and the fp32 side outputs the wgrad / grid / Adam kernels read
   const float* xy;
   const int32_t* ridx;
@@ -106,23 +107,35 @@ __device__ __forceinline__ uint32_t dvt_pack_bf16x2(float a, float b) {
   const dvt_hwbf16x2 v = __builtin_convertvector((dvt_f32x2){a, b}, dvt_hwbf16x2);
   return __builtin_bit_cast(uint32_t, v);
 }
+// Element offset of W[n][k] (k-contiguous matrix with K columns, N % 16 == 0, K % 32 == 0) inside its
+// FRAGMENT-MAJOR shadow copy: the 16 x 32 block (tile n / 16, k-step k / 32) is one contiguous 1-KB piece
+// holding, lane by lane, exactly the B fragment of v_mfma_f32_16x16x32_bf16 (lane = 16 * ((k % 32) / 8) +
+// n % 16, 8 consecutive k per lane).  One wave-wide 16-byte load then touches 8 full 128-B lines; with a
+// plain row-major copy the four lanes that share a 64-B segment are 16 lanes apart, the address coalescer
+// only merges neighbours, and every load cost 64 L1 tag look-ups (measured: the row kernel was bound by
+// exactly that, 14.4 M TCP accesses per launch = 55 us).
+__host__ __device__ __forceinline__ long long dvt_frag_off(int n, int k, int K) {
+  return ((long long)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + (((((k >> 3) & 3) << 4) + (n & 15)) << 3) + (k & 7);
+}
 // The four consecutive arena floats v at float offset e (e % 4 == 0) -> their bf16 shadow copies, when e
 // lies inside one of the shadowed matrices (row-major [N][K], K % 4 == 0: the four share a row).
 __device__ __forceinline__ void dvt_shadow_store(const DvtShadowLayout& L, uint16_t* __restrict__ sh, long long e,
                                                  float4 v) {
 #pragma unroll
   for (int i = 0; i < DVT_SHADOW_MATS; ++i) {
-    const long long rel = e - L.begin[i];
-    if (rel >= 0 && rel < (long long)L.N[i] * L.K[i]) {
-      const int n = (int)(rel / L.K[i]), k = (int)(rel - (long long)n * L.K[i]);
+    const long long rel64 = e - L.begin[i];
+    const int N = L.N[i], K = L.K[i];
+    if (rel64 >= 0 && rel64 < (long long)N * K) {
+      const int rel = (int)rel64, n = rel / K, k = rel - n * K;
       const uint32_t lo = dvt_pack_bf16x2(v.x, v.y), hi = dvt_pack_bf16x2(v.z, v.w);
-      *reinterpret_cast<uint2*>(sh + L.direct[i] + rel) = make_uint2(lo, hi);
-      if (L.transp[i] >= 0) {
-        uint16_t* t = sh + L.transp[i] + (long long)k * L.N[i] + n;
-        t[0] = (uint16_t)(lo & 0xffffu);
-        t[L.N[i]] = (uint16_t)(lo >> 16);
-        t[2 * L.N[i]] = (uint16_t)(hi & 0xffffu);
-        t[3 * L.N[i]] = (uint16_t)(hi >> 16);
+      // forward operand W[n][k..k+3]: four consecutive k stay inside one lane's 8-element run
+      *reinterpret_cast<uint2*>(sh + L.direct[i] + dvt_frag_off(n, k, K)) = make_uint2(lo, hi);
+      if (L.transp[i] >= 0) {  // dgrad operand Wt[k][n] = W[n][k]: an [K][N] matrix, n is its contiguous index
+        uint16_t* t = sh + L.transp[i];
+        t[dvt_frag_off(k + 0, n, N)] = (uint16_t)(lo & 0xffffu);
+        t[dvt_frag_off(k + 1, n, N)] = (uint16_t)(lo >> 16);
+        t[dvt_frag_off(k + 2, n, N)] = (uint16_t)(hi & 0xffffu);
+        t[dvt_frag_off(k + 3, n, N)] = (uint16_t)(hi >> 16);
       }
     }
   }

@@ -354,7 +354,13 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
       gather.rows[f] = ws[f].dF;
     }
   }
-  return dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather, fused ? &shl : nullptr, fused ? shadow : nullptr);
+  DVT_TRY(dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather));
+  if (fused) {  // bf16 shadow copies of the weights Adam just stepped, for the next step's row kernel
+    const float* pp[KM];
+    for (int f = 0; f < k; ++f) pp[f] = P[f];
+    DVT_TRY(dvt_shadow_build_k(&shl, k, pp, shadow, c->off_w1, use_res ? c->arena_floats : c->off_b2, s));
+  }
+  return 0;
 }
 #undef DVT_TRY
 
@@ -400,7 +406,7 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
       pp[j] = bufs[j]->params;
       ss[j] = w[j].shadow;
     }
-    rc = dvt_shadow_build_k(&L, k, pp, ss, c->arena_floats, (hipStream_t)stream);
+    rc = dvt_shadow_build_k(&L, k, pp, ss, 0, c->arena_floats, (hipStream_t)stream);
     if (rc) return rc;
   }
   for (int step = step_begin; step < step_end; ++step) {

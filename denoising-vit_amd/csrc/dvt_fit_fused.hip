@@ -53,7 +53,7 @@ __device__ __forceinline__ uint16_t bf16_of(float v) { return (uint16_t)(dvt_pac
 
 // out[16][N] = act(A[16][K] . W[N][K]^T + bias)  (optionally masked by mask[16][N] > 0)
 //   actA    LDS bf16 image [16][K], pitch apitch(K)
-//   W       global bf16 [N][K] (shadow copy), k-contiguous rows
+//   W       global bf16 shadow copy of the [N][K] weight matrix in fragment-major order (dvt_frag_off)
 //   act_out LDS bf16 image [16][N] for the next layer (may alias `mask`: every element is read, then
 //           written, by the one lane that owns it), or nullptr
 //   gout    global fp32 [16][N] (this workgroup's rows), or nullptr
@@ -62,8 +62,11 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
                                           const float* __restrict__ bias, char* act_out,
                                           float* __restrict__ gout, const char* mask, int wave, int lane) {
   constexpr int NTILES = N / 16, NT = (NTILES + FW - 1) / FW, S = K / 32;
-  constexpr int PD0 = NT >= 6 ? 2 : (NT >= 3 ? 4 : 8);
-  constexpr int PD = PD0 < S ? PD0 : S;  // k-steps of weights in flight per wave
+  // k-steps of weights in flight per wave: ~24 x 1 KB.  The weights are L2 hits at best and memory-side
+  // cache hits on first touch (every kernel starts with a cold L2), i.e. 0.3-2 us of latency: with 6 loads
+  // in flight per wave the first version of this kernel streamed its 1.3 MB at 24 GB/s per CU (54 us).
+  constexpr int PD0 = 24 / NT > 16 ? 16 : 24 / NT;
+  constexpr int PD = PD0 < S ? PD0 : S;
   static_assert(K % 32 == 0 && N % 16 == 0, "layer shape");
   const int lc = lane & 15, g = lane >> 4;
   f32x4 acc[NT];
@@ -73,13 +76,16 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
     acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int t = wave + FW * i;
     const int tt = (NTILES % FW == 0 || t < NTILES) ? t : 0;  // surplus tiles compute tile 0 again, never stored
-    wp[i] = W + (size_t)(tt * 16 + lc) * K + 8 * g;
+    wp[i] = W + (size_t)tt * S * 512 + lane * 8;  // fragment-major copy: 1 KB per (tile, k-step), lane-linear
   }
   bf16x8 b[PD][NT];
 #pragma unroll
   for (int p = 0; p < PD; ++p)
 #pragma unroll
-    for (int i = 0; i < NT; ++i) b[p][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 32 * p);
+    for (int i = 0; i < NT; ++i) b[p][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 512 * p);
+  // The order below is pinned with sched_barrier: left alone, the scheduler sinks every prefetch to just
+  // before its use (register pressure) and the kernel runs with ~6 loads in flight per wave instead of PD*NT.
+  __builtin_amdgcn_sched_barrier(0);
   const char* ap = actA + lc * apitch(K) + g * 16;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -89,8 +95,9 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[s % PD][i], acc[i], 0, 0, 0);
     if (s + PD < S) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i) b[s % PD][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 32 * (s + PD));
+      for (int i = 0; i < NT; ++i) b[s % PD][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 512 * (s + PD));
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
@@ -138,6 +145,37 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   const uint16_t* __restrict__ sh = f.shadow;
   const float* __restrict__ P = f.params;
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(f.feat);
+
+  // ---- cooperative L2 warm-up.  Every launch starts with a cold L2 (the previous kernel's write-back /
+  // invalidate), and the 16 workgroups that share an XCD walk the SAME weight lines in lock step, so
+  // without this every one of them pays the fabric latency for every line.  Here each workgroup touches
+  // a different 1/16 of the shadow weights once (one dword per 128-B line); the loads stay in flight
+  // under the prologue and whatever the k-loops read afterwards is an L2 hit.  (Placement assumption --
+  // workgroup b runs on XCD b % 8 -- is for speed only.)
+  uint32_t warm[5] = {0u, 0u, 0u, 0u, 0u};
+  {  // the rows the loss stage will read much later: this wave's sampled feature rows (random HBM rows) and
+     // their lattice rows of G, one dword per 128-B line, so that their latency hides under the forward pass
+    constexpr int LPR = (C * 4 + 127) / 128;  // lines per row
+    const int rr = lane / 32, j = lane % 32;  // 2 rows per wave, <= 32 lines each (C <= 1024)
+    if (rr < FR / FW && j < LPR) {
+      const int ri = f.ridx[row0 + wave + FW * rr];
+      warm[4] = __float_as_uint(f.feat[(size_t)ri * C + j * 32]) ^
+                __float_as_uint(P[a.off_G + (size_t)(ri % a.lattice) * C + j * 32]);
+    }
+  }
+  {
+    const int nslot = (int)gridDim.x >= 128 ? 16 : ((int)gridDim.x + 7) / 8;
+    const int slot = ((int)blockIdx.x >> 3) % nslot;
+    const long long lines = ((PH2 ? a.S.total : a.S.direct[2]) * 2 + 127) / 128;
+    const long long per = (lines + nslot - 1) / nslot;
+    const long long l0 = slot * per, l1 = l0 + per < lines ? l0 + per : lines;
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(sh);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long li = l0 + tid + (long long)j * 64 * FW;
+      if (li < l1) warm[j] = w32[li * 32];
+    }
+  }
 
   // ---- prologue: hash-grid forward of the 16 rows (one (row, level) pair per thread, tcnn semantics in
   //      dvt_grid.hip) and, in phase 2, the raw rows as the residual predictor's input
@@ -199,19 +237,32 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
 
   // ---- loss + gradients (offline_denoiser.py:113-140), one wave per row, two rows per wave; the
   //      gradient of G is gathered inside Adam from the d(pred) rows written here
+  static_assert(FR / FW == 2 && C <= 1024, "row warm-up above assumes 2 rows per wave, <= 32 lines per row");
+  {
+    constexpr int NR = FR / FW;
+    constexpr int NB = (C <= 768) ? NR : 1;  // rows whose loads are in flight together (register budget)
+    DvtLossRowRegs<PH2> lr[NB];
 #pragma unroll
-  for (int rr = 0; rr < FR / FW; ++rr) {
-    const int row = wave + FW * rr, gr = row0 + row;
-    const int ri = f.ridx[gr];
-    const int grow = ri % a.lattice;
-    dvt_loss_row<PH2>(reinterpret_cast<const float4*>(f.F) + (size_t)gr * cq,
-                      reinterpret_cast<const float4*>(P + a.off_G) + (size_t)grow * cq,
-                      PH2 ? reinterpret_cast<const float4*>(f.Hres) + (size_t)gr * cq : nullptr,
-                      feat4 + (size_t)ri * cq, reinterpret_cast<float4*>(f.dF) + (size_t)gr * cq,
-                      PH2 ? reinterpret_cast<float4*>(f.dH) + (size_t)gr * cq : nullptr, nullptr,
-                      f.rows + (size_t)gr * 8, a.n, cq, a.grad_scale, lane,
-                      reinterpret_cast<uint2*>(smem + L::O_DF + row * apitch(C)),
-                      PH2 ? reinterpret_cast<uint2*>(smem + L::O_RAW + row * apitch(C)) : nullptr);
+    for (int r0 = 0; r0 < NR; r0 += NB) {
+#pragma unroll
+    for (int rr = r0; rr < r0 + NB; ++rr) {  // the rows' loads in flight before the first reduction
+      const int gr = row0 + wave + FW * rr;
+      const int ri = f.ridx[gr];
+      dvt_loss_row_load<PH2>(lr[rr - r0], reinterpret_cast<const float4*>(f.F) + (size_t)gr * cq,
+                             reinterpret_cast<const float4*>(P + a.off_G) + (size_t)(ri % a.lattice) * cq,
+                             PH2 ? reinterpret_cast<const float4*>(f.Hres) + (size_t)gr * cq : nullptr,
+                             feat4 + (size_t)ri * cq, cq, lane);
+    }
+#pragma unroll
+    for (int rr = r0; rr < r0 + NB; ++rr) {
+      const int row = wave + FW * rr, gr = row0 + row;
+      dvt_loss_row_compute<PH2>(lr[rr - r0], reinterpret_cast<float4*>(f.dF) + (size_t)gr * cq,
+                                PH2 ? reinterpret_cast<float4*>(f.dH) + (size_t)gr * cq : nullptr, nullptr,
+                                f.rows + (size_t)gr * 8, a.n, cq, a.grad_scale, lane,
+                                reinterpret_cast<uint2*>(smem + L::O_DF + row * apitch(C)),
+                                PH2 ? reinterpret_cast<uint2*>(smem + L::O_RAW + row * apitch(C)) : nullptr);
+    }
+    }
   }
   __syncthreads();
 
@@ -228,6 +279,8 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   if (PH2)
     mlp_layer<R, R, false, true>(smem + L::O_R2, sh + a.S.transp[3], nullptr, nullptr,
                                  f.dr1 + (size_t)row0 * R, smem + L::O_R1, wave, lane);
+  // keeps the warm-up loads alive (a.n is never negative)
+  if (a.n < 0) f.rows[tid] = __uint_as_float(warm[0] ^ warm[1] ^ warm[2] ^ warm[3] ^ warm[4]);
 }
 
 // one float4 of the arena per thread -> its bf16 shadow copies
@@ -267,7 +320,7 @@ int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* L) {
   L->lo = begins[0];
   L->hi = 0;
   for (int i = 0; i < DVT_SHADOW_MATS; ++i) {
-    if (Ks[i] % 8 || Ns[i] % 8) return DVT_E_BADARG;
+    if (Ks[i] % 32 || Ns[i] % 16 || (tr[i] && (Ns[i] % 32 || Ks[i] % 16))) return DVT_E_BADARG;
     L->N[i] = Ns[i];
     L->K[i] = Ks[i];
     L->begin[i] = begins[i];
@@ -284,7 +337,7 @@ int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* L) {
 }
 
 int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, uint16_t* const* shadow,
-                       long long arena_floats, hipStream_t s) {
+                       long long lo, long long hi, hipStream_t s) {
   if (!L || k < 1 || k > DVT_FIT_BATCH_MAX || L->n <= 0) return DVT_E_BADARG;
   const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
   uint16_t* sh[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -293,7 +346,7 @@ int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* para
     p[f] = params[f];
     sh[f] = shadow[f];
   }
-  const long long q_lo = L->lo / 4, q_hi = (L->hi < arena_floats ? L->hi : arena_floats) / 4;
+  const long long q_lo = (lo > L->lo ? lo : L->lo) / 4, q_hi = (hi < L->hi ? hi : L->hi) / 4;
   if (q_hi <= q_lo) return 0;
   hipLaunchKernelGGL(shadow_build_kernel, dim3(dvt_cdiv(q_hi - q_lo, 256), k), dim3(256), 0, s, *L, p[0], p[1],
                      p[2], p[3], sh[0], sh[1], sh[2], sh[3], q_lo, q_hi);

@@ -9,28 +9,49 @@ constexpr int DVT_LOSS_MAXQ = 4;  // float4 slots per lane: C <= 64*4*4 = 1024
 
 __device__ __forceinline__ float dvt_sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-// F, G, Hres, raw: this row's data (G already offset to its lattice row).  Outputs (each optional):
+// Registers of one row, loaded first (so that a caller can put several rows' loads in flight) ...
+template <bool HAS_RES>
+struct DvtLossRowRegs {
+  float4 f[DVT_LOSS_MAXQ], g[DVT_LOSS_MAXQ], r[DVT_LOSS_MAXQ], h[HAS_RES ? DVT_LOSS_MAXQ : 1];
+};
+
+template <bool HAS_RES>
+__device__ __forceinline__ void dvt_loss_row_load(DvtLossRowRegs<HAS_RES>& x, const float4* __restrict__ F,
+                                                  const float4* __restrict__ G, const float4* __restrict__ Hres,
+                                                  const float4* __restrict__ raw, int cq, int lane) {
+#pragma unroll
+  for (int s = 0; s < DVT_LOSS_MAXQ; ++s) {
+    const int q = lane + 64 * s;
+    if (q < cq) {
+      x.f[s] = F[q];
+      x.g[s] = G[q];
+      x.r[s] = raw[q];
+      if (HAS_RES) x.h[s] = Hres[q];
+    }
+  }
+}
+
+// ... then reduced and differentiated.  Outputs (each optional):
 //   d_pred / d_hres : global fp32 gradient rows (grad_scale * dloss/dpred, .../dh)
 //   d_G             : fp32 atomics into the lattice row of the G gradient
 //   row_sums        : {sse, cos, res_sse, res_abs, ...} of this row (lane 0)
 //   b_pred / b_hres : the same gradient rows rounded to bf16 (4 values = 8 B per float4), e.g. in LDS
 template <bool HAS_RES>
-__device__ __forceinline__ void dvt_loss_row(const float4* __restrict__ F, const float4* __restrict__ G,
-                                             const float4* __restrict__ Hres, const float4* __restrict__ raw,
-                                             float4* __restrict__ d_pred, float4* __restrict__ d_hres,
-                                             float* __restrict__ d_G, float* __restrict__ row_sums, int n,
-                                             int cq, float grad_scale, int lane, uint2* b_pred, uint2* b_hres) {
+__device__ __forceinline__ void dvt_loss_row_compute(const DvtLossRowRegs<HAS_RES>& x, float4* __restrict__ d_pred,
+                                                     float4* __restrict__ d_hres, float* __restrict__ d_G,
+                                                     float* __restrict__ row_sums, int n, int cq, float grad_scale,
+                                                     int lane, uint2* b_pred, uint2* b_hres) {
   float4 vp[DVT_LOSS_MAXQ], vr[DVT_LOSS_MAXQ], vh[DVT_LOSS_MAXQ], vfg[DVT_LOSS_MAXQ];
   float sse = 0.f, dot = 0.f, np = 0.f, nr = 0.f, rsse = 0.f, rabs = 0.f;
 #pragma unroll
   for (int s = 0; s < DVT_LOSS_MAXQ; ++s) {
     const int q = lane + 64 * s;
     if (q < cq) {
-      const float4 f = F[q], g = G[q], r = raw[q];
+      const float4 f = x.f[s], g = x.g[s], r = x.r[s];
       float4 fg = make_float4(f.x + g.x, f.y + g.y, f.z + g.z, f.w + g.w);
       float4 p = fg;
       if (HAS_RES) {
-        const float4 h = Hres[q];
+        const float4 h = x.h[s];
         vh[s] = h;
         p = make_float4(fg.x + h.x, fg.y + h.y, fg.z + h.z, fg.w + h.w);
         // gt_residual = raw - F - G ; residual terms use (h - gt)
@@ -108,4 +129,16 @@ __device__ __forceinline__ void dvt_loss_row(const float4* __restrict__ F, const
       }
     }
   }
+}
+
+// F, G, Hres, raw: this row's data (G already offset to its lattice row); load + compute in one go.
+template <bool HAS_RES>
+__device__ __forceinline__ void dvt_loss_row(const float4* __restrict__ F, const float4* __restrict__ G,
+                                             const float4* __restrict__ Hres, const float4* __restrict__ raw,
+                                             float4* __restrict__ d_pred, float4* __restrict__ d_hres,
+                                             float* __restrict__ d_G, float* __restrict__ row_sums, int n,
+                                             int cq, float grad_scale, int lane, uint2* b_pred, uint2* b_hres) {
+  DvtLossRowRegs<HAS_RES> x;
+  dvt_loss_row_load<HAS_RES>(x, F, G, Hres, raw, cq, lane);
+  dvt_loss_row_compute<HAS_RES>(x, d_pred, d_hres, d_G, row_sums, n, cq, grad_scale, lane, b_pred, b_hres);
 }

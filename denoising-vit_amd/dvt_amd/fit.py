@@ -245,9 +245,15 @@ class FitEngine:
         _lib.check(_lib.lib().dvt_fit_run(C.byref(self.cfg), C.byref(b), step_begin, end,
                                           _lib.stream()), "dvt_fit_run")
 
-    def check_inputs(self) -> None:
-        """Raise if the coordinates handed to the last fit left [0, 1] (synchronises on the flag)."""
-        flag = getattr(self, "_range_bad", None)
+    @property
+    def range_flag(self):
+        """Device flag of the LAST `buffers()` call (a pipelined driver must keep it with the image: the
+        engine is already preparing the next image when this one retires)."""
+        return getattr(self, "_range_bad", None)
+
+    def check_inputs(self, flag=None) -> None:
+        """Raise if the coordinates handed to a fit left [0, 1] (synchronises on the flag)."""
+        flag = self.range_flag if flag is None else flag
         if flag is not None and bool(flag.item()):
             raise _lib.DvtError("coordinates should be in [0, 1] (neural_feature_field.py:47): the fit of this "
                                 "image consumed out-of-range coordinates, its result is invalid")

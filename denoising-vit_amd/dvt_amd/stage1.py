@@ -122,6 +122,7 @@ class _Slot:
         self.extracted = torch.cuda.Event()
         self.fitted = torch.cuda.Event()
         self.tag = None
+        self.range_flag = None
 
 
 class Stage1:
@@ -222,6 +223,8 @@ class Stage1:
             e.reset(self.gen)
         fit_many(engines, [sl.features.view(-1, C) for sl in group],
                  [sl.coords.view(-1, 2) for sl in group], idxs, log_every=log_every)
+        for e, sl in zip(engines, group):
+            sl.range_flag = e.range_flag  # travels with the image; the engine moves on to the next one
         return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
 
     # -- the pipeline --------------------------------------------------------------------------
@@ -274,8 +277,8 @@ class Stage1:
                     if group is None:
                         return
                     group[-1].fitted.synchronize()  # recorded after the whole group's D2H copies
-                    for eng in self.engines[:len(group)]:
-                        eng.check_inputs()  # the asynchronous coordinate-range flag (free: already synced)
+                    for slot in group:
+                        self.engine.check_inputs(slot.range_flag)  # asynchronous range check, already complete
                     for slot in group:
                         if on_result is not None:
                             on_result(slot.tag, slot.raw_host.numpy(), slot.den_host.numpy())

@@ -214,6 +214,15 @@ def test_vit_outlier_stress(built_lib):
     got = HipViT(sd, 14, 14, (518, 518), DEV).forward_features(x.to(DEV)).cpu()
     cos = per_patch_cos(got, want)
     err = float((got - want).norm() / want.norm())
-    print(f"[ViT outlier stress] per-token cosine mean {cos.mean():.6f} min {cos.min():.6f} rel-L2 {err:.4f}")
+    # the hot channels dominate every token's norm after the final LayerNorm, so the full cosine is
+    # trivially ~1: the informative number is the cosine over the OTHER channels, whose values were
+    # squeezed into the low bits of the bf16 operands next to the massive ones
+    cold = torch.ones(768, dtype=torch.bool)
+    cold[hot] = False
+    cos_cold = per_patch_cos(got[..., cold], want[..., cold])
+    ratio = float(want[..., hot].abs().mean() / want[..., cold].abs().mean())
+    print(f"[ViT outlier stress] hot/cold magnitude {ratio:.0f}x; per-token cosine all channels mean {cos.mean():.6f} "
+          f"min {cos.min():.6f}; cold channels only mean {cos_cold.mean():.6f} min {cos_cold.min():.6f}; rel-L2 {err:.4f}")
     assert bool(torch.isfinite(got).all())
     assert cos.mean() > 0.999 and cos.min() > 0.99
+    assert cos_cold.mean() > 0.99, float(cos_cold.mean())
