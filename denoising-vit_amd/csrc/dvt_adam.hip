@@ -28,6 +28,7 @@ int g_adam_zero_all = 0;
 
 struct AdamKArgs {
   int zero_all;
+  int reverse;  // sweep the chunks from the end: consecutive steps alternate, see dvt_adam_step_k
   float one_m_b1, beta2, one_m_b2, eps, wd;
   long long q_sparse_end;  // float4 index
   int n_segs;
@@ -67,6 +68,14 @@ struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
   uint32_t* touched[DVT_FIT_BATCH_MAX];
 };
 
+// <= 48 VGPRs: the extractor's 8-phase GEMM keeps two 232-register waves on every SIMD, which leaves exactly
+// 48 registers -- one Adam wave -- per SIMD.  At 52 registers the HBM-bound Adam and the MFMA-bound GEMM could
+// only time-slice whole CUs (the pipelined image time was t_extract + 0.96 * t_fit).
+// GATHER = false is the pure streaming kernel: 48 VGPRs, which is exactly what the extractor's 8-phase GEMM
+// (two 232-register waves per SIMD) leaves free -- one Adam wave per SIMD then shares the CU with it and the
+// HBM-bound update overlaps the MFMA-bound GEMM instead of time-slicing whole CUs (at 52 registers, with the
+// gather path compiled in, nothing fitted and the pipelined image time was t_extract + 0.96 t_fit).
+template <bool GATHER>
 __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, AdamGather gr) {
   float4* __restrict__ P = q.P[blockIdx.y];
   float4* __restrict__ M = q.M[blockIdx.y];
@@ -78,7 +87,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
   const long long wave_stride = (long long)gridDim.x * 4;
   const float one_m_b1 = a.one_m_b1, one_m_b2 = a.one_m_b2;
   const long long n_chunks = a.chunk0[a.n_active];
-  for (long long ch = wave_global; ch < n_chunks; ch += wave_stride) {
+  for (long long ci = wave_global; ci < n_chunks; ci += wave_stride) {
+    const long long ch = a.reverse ? n_chunks - 1 - ci : ci;
     int k = 0;
 #pragma unroll
     for (int j = 1; j < DVT_ADAM_MAX_SEGS; ++j)
@@ -96,8 +106,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
       has = (word >> (lane >> 1)) & 1u;
     }
     float4 p = P[q], m = M[q], v = V[q];
-    const bool gathered = q0 >= gr.q_begin && q0 < gr.q_end;  // wave-uniform: chunk inside G
-    if (gathered) {
+    const bool gathered = GATHER && q0 >= gr.q_begin && q0 < gr.q_end;  // wave-uniform: chunk inside G
+    if (GATHER && gathered) {
       // dG[row] = sum of the d_pred rows of this step's samples on lattice row `row`
       const int e = (int)(q - gr.q_begin) * 4, row = e / gr.c, col4 = (e - row * gr.c) >> 2;
       const int32_t* offs = gr.offs[blockIdx.y];
@@ -142,7 +152,7 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
 
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
-                    const DvtAdamRowGather* gather) {
+                    const DvtAdamRowGather* gather, int reverse) {
   if (!h || k < 1 || k > DVT_FIT_BATCH_MAX || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
     return DVT_E_BADARG;
   if (h->sparse_end & 255) return DVT_E_BADARG;
@@ -173,6 +183,11 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
   }
   AdamKArgs a{};
   a.zero_all = g_adam_zero_all;
+  // Direction of the sweep over the arena.  p + m + v (258 MB) is a hair larger than the 256-MB memory-side
+  // cache: a forward sweep every step evicts each line just before it is needed again (LRU streaming
+  // pathology, 0 % hits); alternating the direction lets a step START on the lines the previous step touched
+  // LAST.  The update of a chunk does not depend on the order, so results are unchanged.
+  a.reverse = reverse ? 1 : 0;
   // torch narrows the python doubles (1 - beta1), beta2, (1 - beta2), eps, wd to fp32 scalars
   a.one_m_b1 = (float)(1.0 - h->beta1);
   a.beta2 = (float)h->beta2;
@@ -208,7 +223,10 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
   if (blocks > 256 * 16) blocks = 256 * 16;
   {
     DvtProbeScope probe(DVT_PROBE_ADAM, stream, work * k);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
+    if (gr.q_end > gr.q_begin)
+      hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
+    else
+      hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
     DVT_CHECK_LAUNCH();
   }
   return 0;

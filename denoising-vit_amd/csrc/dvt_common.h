@@ -62,7 +62,7 @@ struct DvtAdamRowGather {
 };
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
-                    const DvtAdamRowGather* gather = nullptr);
+                    const DvtAdamRowGather* gather = nullptr, int reverse = 0);
 // offs [steps, lattice + 1] / perm [steps, batch] for steps [0, steps) of idx [steps, batch]; lattice <= 8192,
 // batch <= 65535
 int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,
@@ -91,13 +91,29 @@ int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* out);
 // the Adam kernel the extra scalar registers cost its streaming loop a wave per SIMD, ~10 % bandwidth)
 int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, uint16_t* const* shadow,
                        long long lo, long long hi, hipStream_t s);
-struct DvtFusedFit {  // per fit: inputs, arena, shadow and the fp32 side outputs the wgrad / grid / Adam kernels read
+// Operands of the weight-gradient GEMMs, written by the row kernel as bf16 [cols][batch] matrices in
+// fragment-major order (dvt_frag_off with K = batch): the batch index is the contraction index there.
+enum { DVT_T_DF = 0, DVT_T_H1, DVT_T_DH1, DVT_T_ENC, DVT_T_RAW, DVT_T_R1, DVT_T_R2, DVT_T_DH, DVT_T_DR2, DVT_T_DR1, DVT_T_COUNT };
+struct DvtTLayout {
+  long long off[DVT_T_COUNT];  // element offsets
+  int cols[DVT_T_COUNT];
+  long long total;
+};
+void dvt_t_layout(const DvtFitConfig* c, DvtTLayout* out);
+struct DvtFusedFit {  // per fit: inputs, arena, shadow weights and what the row kernel hands to the rest of the step
   const float* xy;
   const int32_t* ridx;
   const float* feat;
   const float* params;
   const uint16_t* shadow;
-  float *enc, *h1, *F, *raw, *dF, *dh1, *denc, *rows, *r1, *r2, *Hres, *dH, *dr2, *dr1;
+  uint16_t* T;        // transposed bf16 operand copies (DvtTLayout) -> weight-gradient kernel
+  float *F, *Hres;    // fp32 rows the loss stage reads back
+  float *dF;          // fp32 d(pred) rows -> Adam gathers the gradient of G from them
+  float *denc;        // fp32 d(enc) rows -> grid backward
+  float *rows;        // per-row loss sums -> loss logging
+  float* grads;       // gradient arena (weight gradients accumulate here with fp32 atomics)
+  const int32_t* g_offs;   // this step's row lists of the G gradient (DvtAdamRowGather), phase 1 only
+  const uint16_t* g_perm;
 };
 #if defined(__HIPCC__)
 typedef __bf16 dvt_hwbf16x2 __attribute__((ext_vector_type(2)));
@@ -145,6 +161,8 @@ bool dvt_fit_fused_ok(const DvtFitConfig* c);         // shapes fit AND the bf16
 bool dvt_fit_fused_shapes_ok(const DvtFitConfig* c);  // shapes only (workspace carving must not depend on the mode)
 int dvt_fit_rows_k(const DvtFitConfig* c, const DvtShadowLayout* L, int k, const DvtFusedFit* fits, bool phase2,
                    hipStream_t s);
+// all weight (and bias) gradients of the step from the transposed operand copies, one launch
+int dvt_fit_wgrad_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bool phase2, hipStream_t s);
 
 // ---- profiling probes (dvt_prof.hip) ----
 extern unsigned g_dvt_prof_mask;

@@ -16,6 +16,9 @@
 
 #include "dvt_common.h"
 
+int g_adam_pingpong = 1;  // dvt_tune_set(8, 0): always sweep forward (A/B timing)
+int g_wgrad_ksplit = 4;   // dvt_tune_set(7, v): batch slices per weight-gradient block (4 or 8)
+
 namespace {
 
 inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -25,6 +28,7 @@ struct Work {
   int32_t* g_offs;   // [num_iters, lattice + 1] row lists of the G gradient (nullptr: atomics path)
   uint16_t* g_perm;  // [num_iters, batch]
   uint16_t* shadow;  // bf16 shadow copies of the MLP weights for the fused row kernel (nullptr: shapes not eligible)
+  uint16_t* T;       // transposed bf16 operand copies for the weight-gradient kernel (with `shadow`)
 };
 
 bool row_lists_ok(const DvtFitConfig* c) { return c->lattice <= 8192 && c->batch <= 65535; }
@@ -60,9 +64,15 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
     t.g_perm = reinterpret_cast<uint16_t*>(take(((int64_t)c->num_iters * B + 1) / 2));
   }
   t.shadow = nullptr;
+  t.T = nullptr;
   if (dvt_fit_fused_shapes_ok(c)) {
     DvtShadowLayout L;
-    if (dvt_shadow_layout(c, &L) == 0) t.shadow = reinterpret_cast<uint16_t*>(take((L.total + 1) / 2));
+    if (dvt_shadow_layout(c, &L) == 0) {
+      t.shadow = reinterpret_cast<uint16_t*>(take((L.total + 1) / 2));
+      DvtTLayout TL;
+      dvt_t_layout(c, &TL);
+      t.T = reinterpret_cast<uint16_t*>(take((TL.total + 1) / 2));
+    }
   }
   if (w) *w = t;
   return o;
@@ -206,15 +216,15 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
   const bool fused = dvt_fit_fused_ok(c) && ws[0].shadow != nullptr && ws[0].g_offs != nullptr;
   DvtShadowLayout shl{};
   uint16_t* shadow[KM] = {nullptr, nullptr, nullptr, nullptr};
+  DvtFusedFit ff[KM];
   if (fused) {
     // ---- ONE launch for everything row-local: gather, grid forward, MLP forward, loss, dgrad chain ----
     DVT_TRY(dvt_shadow_layout(c, &shl));
-    DvtFusedFit ff[KM];
     for (int f = 0; f < k; ++f) {
       const Work& w = ws[f];
       shadow[f] = w.shadow;
-      ff[f] = DvtFusedFit{xy[f], ridx[f], feat[f], P[f], w.shadow, w.enc, w.h1, w.F, w.raw, w.dF, w.dh1, w.denc,
-                          w.rows, w.r1, w.r2, w.Hres, w.dH, w.dr2, w.dr1};
+      ff[f] = DvtFusedFit{xy[f], ridx[f], feat[f], P[f], w.shadow, w.T, w.F, w.Hres, w.dF, w.denc, w.rows, Gd[f],
+                          w.g_offs + (size_t)step * (c->lattice + 1), w.g_perm + (size_t)step * B};
     }
     DVT_TRY(dvt_fit_rows_k(c, &shl, k, ff, use_res, s));
   } else {
@@ -261,24 +271,8 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     if (log) DVT_TRY(dvt_loss_reduce(ws[f].rows, b->losses + (size_t)step * 8, B, C, use_res, s));
   }
   if (fused) {
-    // ---- all weight gradients of the step (the only part that reduces over rows) in ONE grouped launch
-    n_ops = 0;
-    for (int f = 0; f < k; ++f) {
-      const Work& w = ws[f];
-      ops[n_ops++] = wgrad_op(f, w.dF, w.h1, c->off_w2, c->off_b2, C, H);
-      ops[n_ops++] = wgrad_op(f, w.dh1, w.enc, c->off_w1, c->off_b1, H, E);
-    }
-    DVT_TRY(launch());
-    if (use_res) {  // (a grouped launch carries <= 16 problems: 2 + 3 per fit x 4 fits needs two)
-      n_ops = 0;
-      for (int f = 0; f < k; ++f) {
-        const Work& w = ws[f];
-        ops[n_ops++] = wgrad_op(f, w.dH, w.r2, c->off_wh3, c->off_bh3, C, R);
-        ops[n_ops++] = wgrad_op(f, w.dr2, w.r1, c->off_wh2, c->off_bh2, R, R);
-        ops[n_ops++] = wgrad_op(f, w.dr1, w.raw, c->off_wh1, c->off_bh1, R, C);
-      }
-      DVT_TRY(launch());
-    }
+    // ---- all weight gradients of the step (the only part that reduces over rows) in ONE launch
+    DVT_TRY(dvt_fit_wgrad_k(c, k, ff, use_res, s));
     float* dgrid[KM];
     at(Gd, c->off_grid, dgrid);
     DVT_TRY(dvt_grid_bwd_k(&c->grid, k, xy, ridx, denc, dgrid, touched, B, s));
@@ -343,7 +337,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
   }
   DvtAdamRowGather gather{};
-  if (!phase2 && ws[0].g_offs != nullptr) {
+  if (!phase2 && ws[0].g_offs != nullptr && !fused) {  // (fused step: the weight-gradient launch wrote dG densely)
     gather.begin = c->off_G;
     gather.end = c->off_wh1;
     gather.c = C;
@@ -354,7 +348,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
       gather.rows[f] = ws[f].dF;
     }
   }
-  DVT_TRY(dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather));
+  DVT_TRY(dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather, g_adam_pingpong ? (step & 1) : 0));
   if (fused) {  // bf16 shadow copies of the weights Adam just stepped, for the next step's row kernel
     const float* pp[KM];
     for (int f = 0; f < k; ++f) pp[f] = P[f];

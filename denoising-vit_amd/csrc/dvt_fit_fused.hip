@@ -30,6 +30,8 @@
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+extern int g_wgrad_ksplit;
+
 namespace {
 
 constexpr int FR = 16;   // rows per workgroup = M of the MFMA
@@ -43,6 +45,7 @@ __host__ __device__ constexpr int apitch(int K) { return K * 2 + 16; }
 struct FusedArgs {
   DvtGridTable T;
   DvtShadowLayout S;
+  DvtTLayout TL;
   int n, lattice;
   float grad_scale;
   long long off_grid, off_b1, off_b2, off_G, off_bh1, off_bh2, off_bh3;
@@ -50,6 +53,27 @@ struct FusedArgs {
 };
 
 __device__ __forceinline__ uint16_t bf16_of(float v) { return (uint16_t)(dvt_pack_bf16x2(v, 0.f) & 0xffffu); }
+
+// One [16][NC] bf16 LDS image (pitch apitch(NC)) -> its slice of the transposed, fragment-major operand copy
+// dstT = [NC][B]: for every column the 16 batch rows of this workgroup are two 16-byte pieces (8 rows each)
+// of the 1-KB fragment block (tile col / 16, k-step b0 / 32).  Adjacent threads take adjacent columns.
+template <int NC>
+__device__ __forceinline__ void store_T(const char* img, uint16_t* __restrict__ dstT, int B, int b0, int tid) {
+  const int kstep = b0 >> 5, g0 = (b0 >> 3) & 3;
+  for (int item = tid; item < NC * 2; item += 64 * FW) {
+    const int half = item / NC, col = item - half * NC;
+    const char* src = img + half * 8 * apitch(NC) + col * 2;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = *reinterpret_cast<const uint16_t*>(src + (2 * j) * apitch(NC));
+      const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * j + 1) * apitch(NC));
+      w[j] = lo | (hi << 16);
+    }
+    const long long off = ((long long)(col >> 4) * (B >> 5) + kstep) * 512 + ((((g0 + half) << 4) + (col & 15)) << 3);
+    *reinterpret_cast<uint4*>(dstT + off) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
 
 // out[16][N] = act(A[16][K] . W[N][K]^T + bias)  (optionally masked by mask[16][N] > 0)
 //   actA    LDS bf16 image [16][K], pitch apitch(K)
@@ -199,9 +223,6 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
       hi.z = fmaf(w[c], v.z, hi.z);
       hi.w = fmaf(w[c], v.w, hi.w);
     }
-    float4* eg = reinterpret_cast<float4*>(f.enc + (size_t)(row0 + r) * E + l * 8);
-    eg[0] = lo;
-    eg[1] = hi;
     *reinterpret_cast<uint4*>(smem + L::O_ENC + r * apitch(E) + l * 16) =
         make_uint4(dvt_pack_bf16x2(lo.x, lo.y), dvt_pack_bf16x2(lo.z, lo.w), dvt_pack_bf16x2(hi.x, hi.y),
                    dvt_pack_bf16x2(hi.z, hi.w));
@@ -210,7 +231,6 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
     for (int i = tid; i < FR * cq; i += 64 * FW) {
       const int r = i / cq, q = i - r * cq;
       const float4 v = feat4[(size_t)f.ridx[row0 + r] * cq + q];
-      reinterpret_cast<float4*>(f.raw)[(size_t)(row0 + r) * cq + q] = v;  // B operand of the Wh1 weight gradient
       *reinterpret_cast<uint2*>(smem + L::O_RAW + r * apitch(C) + q * 8) =
           make_uint2(dvt_pack_bf16x2(v.x, v.y), dvt_pack_bf16x2(v.z, v.w));
     }
@@ -218,20 +238,28 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   __syncthreads();
 
   // ---- forward: field MLP (neural_feature_field.py:40-44, :49), residual predictor (offline_denoiser.py:107)
-  mlp_layer<E, H, true, false>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1,
-                               f.h1 + (size_t)row0 * H, nullptr, wave, lane);
+  const int B = a.n;
+  uint16_t* __restrict__ T = f.T;
+  mlp_layer<E, H, true, false>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1, nullptr,
+                               nullptr, wave, lane);
   if (PH2)
-    mlp_layer<C, R, true, false>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1,
-                                 f.r1 + (size_t)row0 * R, nullptr, wave, lane);
+    mlp_layer<C, R, true, false>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1, nullptr,
+                                 nullptr, wave, lane);
   __syncthreads();
   mlp_layer<H, C, false, false>(smem + L::O_H1, sh + a.S.direct[1], P + a.off_b2, nullptr,
                                 f.F + (size_t)row0 * C, nullptr, wave, lane);
+  // operands of the weight gradients leave as transposed bf16 copies while their LDS images are stable
+  store_T<H>(smem + L::O_H1, T + a.TL.off[DVT_T_H1], B, row0, tid);
+  store_T<E>(smem + L::O_ENC, T + a.TL.off[DVT_T_ENC], B, row0, tid);
   if (PH2) {
-    mlp_layer<R, R, true, false>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2,
-                                 f.r2 + (size_t)row0 * R, nullptr, wave, lane);
+    mlp_layer<R, R, true, false>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2, nullptr,
+                                 nullptr, wave, lane);
+    store_T<C>(smem + L::O_RAW, T + a.TL.off[DVT_T_RAW], B, row0, tid);
+    store_T<R>(smem + L::O_R1, T + a.TL.off[DVT_T_R1], B, row0, tid);
     __syncthreads();
     mlp_layer<R, C, false, false>(smem + L::O_R2, sh + a.S.direct[4], P + a.off_bh3, nullptr,
                                   f.Hres + (size_t)row0 * C, nullptr, wave, lane);
+    store_T<R>(smem + L::O_R2, T + a.TL.off[DVT_T_R2], B, row0, tid);
   }
   __syncthreads();  // F (and Hres) rows of this workgroup are visible to all of its waves
 
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
     for (int rr = r0; rr < r0 + NB; ++rr) {
       const int row = wave + FW * rr, gr = row0 + row;
       dvt_loss_row_compute<PH2>(lr[rr - r0], reinterpret_cast<float4*>(f.dF) + (size_t)gr * cq,
-                                PH2 ? reinterpret_cast<float4*>(f.dH) + (size_t)gr * cq : nullptr, nullptr,
+                                nullptr, nullptr,
                                 f.rows + (size_t)gr * 8, a.n, cq, a.grad_scale, lane,
                                 reinterpret_cast<uint2*>(smem + L::O_DF + row * apitch(C)),
                                 PH2 ? reinterpret_cast<uint2*>(smem + L::O_RAW + row * apitch(C)) : nullptr);
@@ -268,17 +296,25 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
 
   // ---- data gradients: dh1 = (dF . W2) * (h1 > 0), denc = dh1 . W1; dr2 = (dH . Wh3) * (r2 > 0),
   //      dr1 = (dr2 . Wh2) * (r1 > 0)  (the [K][N] shadow copies make these k-contiguous as well)
-  mlp_layer<C, H, false, true>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1,
-                               f.dh1 + (size_t)row0 * H, smem + L::O_H1, wave, lane);
-  if (PH2)
-    mlp_layer<C, R, false, true>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2,
-                                 f.dr2 + (size_t)row0 * R, smem + L::O_R2, wave, lane);
+  mlp_layer<C, H, false, true>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1, nullptr,
+                               smem + L::O_H1, wave, lane);
+  store_T<C>(smem + L::O_DF, T + a.TL.off[DVT_T_DF], B, row0, tid);
+  if (PH2) {
+    mlp_layer<C, R, false, true>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2, nullptr,
+                                 smem + L::O_R2, wave, lane);
+    store_T<C>(smem + L::O_RAW, T + a.TL.off[DVT_T_DH], B, row0, tid);
+  }
   __syncthreads();
   mlp_layer<H, E, false, false>(smem + L::O_H1, sh + a.S.transp[0], nullptr, nullptr,
                                 f.denc + (size_t)row0 * E, nullptr, wave, lane);
-  if (PH2)
-    mlp_layer<R, R, false, true>(smem + L::O_R2, sh + a.S.transp[3], nullptr, nullptr,
-                                 f.dr1 + (size_t)row0 * R, smem + L::O_R1, wave, lane);
+  store_T<H>(smem + L::O_H1, T + a.TL.off[DVT_T_DH1], B, row0, tid);
+  if (PH2) {
+    mlp_layer<R, R, false, true>(smem + L::O_R2, sh + a.S.transp[3], nullptr, smem + L::O_R1, nullptr,
+                                 smem + L::O_R1, wave, lane);
+    store_T<R>(smem + L::O_R2, T + a.TL.off[DVT_T_DR2], B, row0, tid);
+    __syncthreads();
+    store_T<R>(smem + L::O_R1, T + a.TL.off[DVT_T_DR1], B, row0, tid);
+  }
   // keeps the warm-up loads alive (a.n is never negative)
   if (a.n < 0) f.rows[tid] = __uint_as_float(warm[0] ^ warm[1] ^ warm[2] ^ warm[3] ^ warm[4]);
 }
@@ -293,6 +329,141 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(DvtShadowLayout L, co
   const long long q = q_lo + (long long)blockIdx.x * 256 + threadIdx.x;
   if (q >= q_hi) return;
   dvt_shadow_store(L, sh, q * 4, reinterpret_cast<const float4*>(p)[q]);
+}
+
+
+// ======================================================================================================
+// Weight gradients of the step: dW[m][n] += sum_b dY[b][m] * X[b][n] for every layer, one launch.
+// Both operands arrive as bf16 [cols][batch] fragment-major copies (store_T above), so A and B fragments of
+// v_mfma_f32_16x16x32_bf16 are single coalesced 16-byte-per-lane loads, straight to VGPRs: every WAVE owns
+// a 32 x 32 block of one dW and one quarter of the batch -- no LDS, no barrier, 16 loads in flight --
+// and adds its partial sums with fp32 atomics (4 per element) into the gradient arena that Adam clears.
+// Bias gradients (column sums of dY, i.e. of the A operand) ride along in the waves of the first n-block.
+// ======================================================================================================
+constexpr int WG_MAX_PROB = 5 * DVT_FIT_BATCH_MAX;
+struct WgradProb {
+  const uint16_t* AT;  // dY^T [M][B]
+  const uint16_t* BT;  // X^T  [N][B]
+  float* dW;           // [M][N] fp32, += (atomics)
+  float* db;           // [M] or nullptr
+  int M, N;
+};
+struct WgradGather {  // gradient of the shared-artifact map G: row r = sum of the d(pred) rows of its samples
+  const int32_t* offs;  // [lattice + 1]
+  const uint16_t* perm; // [B], sorted inside a list (deterministic sums)
+  const float4* rows;   // d(pred) [B][C] fp32
+  float4* dG;           // gradient arena at G, [lattice][C]
+};
+struct WgradArgs {
+  int n_prob, B, ksplit, units_total;
+  int n_gather, lattice, cq;  // fits with a G gradient this step (0 in phase 2), rows of G, float4 per row
+  WgradGather gg[DVT_FIT_BATCH_MAX];
+  int unit0[WG_MAX_PROB + 1];
+  WgradProb p[WG_MAX_PROB];
+};
+
+__global__ __launch_bounds__(256) void wgrad_frag_kernel(WgradArgs a) {
+  constexpr int PD = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int id = blockIdx.x * 4 + wave;
+  if (id >= a.units_total * a.ksplit) {
+    // ---- surplus waves: the gradient of G, one wave per lattice row (lists average 1.5 samples).  Plain
+    // stores into the zeroed gradient arena; Adam then reads G like any dense-gradient tensor -- which keeps
+    // the gather's registers out of the Adam kernel (see adam_kernel).
+    const int u = id - a.units_total * a.ksplit;
+    if (u >= a.n_gather * a.lattice) return;
+    const int fi = u / a.lattice, r = u - fi * a.lattice;
+    const WgradGather& gg = a.gg[fi];
+    const int o0 = gg.offs[r], o1 = gg.offs[r + 1];
+    if (o1 == o0) return;
+    for (int q = lane; q < a.cq; q += 64) {
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = o0; o < o1; ++o) {
+        const float4 d = gg.rows[(size_t)gg.perm[o] * a.cq + q];
+        acc4.x += d.x;
+        acc4.y += d.y;
+        acc4.z += d.z;
+        acc4.w += d.w;
+      }
+      gg.dG[(size_t)r * a.cq + q] = acc4;
+    }
+    return;
+  }
+  const int ks = id / a.units_total, unit = id - ks * a.units_total;
+  int pi = 0;
+#pragma unroll
+  for (int j = 1; j < WG_MAX_PROB; ++j)
+    if (j < a.n_prob && unit >= a.unit0[j]) pi = j;
+  const WgradProb& p = a.p[pi];
+  const int local = unit - a.unit0[pi], nbn = p.N >> 5;
+  const int mb = local / nbn, nb = local - mb * nbn;
+  const int ksteps = a.B >> 5, S = ksteps / a.ksplit, s_begin = ks * S;  // S % PD == 0 (host)
+  const uint16_t* ap[2];
+  const uint16_t* bp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ap[i] = p.AT + ((size_t)(mb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
+    bp[i] = p.BT + ((size_t)(nb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.db != nullptr && nb == 0;  // wave-uniform
+  float bsum[2] = {0.f, 0.f};
+  bf16x8 fa[PD][2], fb[PD][2];
+#pragma unroll
+  for (int q = 0; q < PD; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * q);
+      fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * q);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  for (int s0 = 0; s0 < S; s0 += PD) {
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((uint32_t)(uint16_t)fa[q][i][e]) << 16);
+      }
+      if (s0 + q + PD < S) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * (s0 + q + PD));
+          fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * (s0 + q + PD));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // D[row = m][col = n]: col = lane & 15, row = 4 * (lane >> 4) + r
+  const int lc = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomic_add_f32(p.dW + (size_t)(mb * 32 + i * 16 + 4 * g + r) * p.N + nb * 32 + j * 16 + lc, acc[i][j][r]);
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // lane (lc, g) holds 8 of the 32 batch rows of a k-step for column lc: fold the 4 groups
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) atomic_add_f32(p.db + mb * 32 + i * 16 + lc, v);
+    }
+  }
 }
 
 template <int C>
@@ -365,7 +536,7 @@ bool dvt_fit_fused_shapes_ok(const DvtFitConfig* c) {
   const int C = c->feat_dim;
   if (C != 384 && C != 768 && C != 1024) return false;
   if (c->hidden != C / 2 || c->res_hidden != C / 4) return false;
-  if (c->batch % FR || c->batch <= 0) return false;
+  if (c->batch % 128 || c->batch <= 0) return false;  // whole MFMA k-steps per workgroup pair; 4 k-steps per wgrad quarter
   return c->lattice <= 8192 && c->batch <= 65535;  // G gradient through Adam's row lists
 }
 
@@ -375,6 +546,7 @@ int dvt_fit_rows_k(const DvtFitConfig* c, const DvtShadowLayout* L, int k, const
   FusedArgs a{};
   a.T = c->grid;
   a.S = *L;
+  dvt_t_layout(c, &a.TL);
   a.n = c->batch;
   a.lattice = c->lattice;
   a.grad_scale = (float)c->grad_scale;
@@ -395,4 +567,69 @@ int dvt_fit_rows_k(const DvtFitConfig* c, const DvtShadowLayout* L, int k, const
     case 768: return launch_rows<768>(a, k, phase2, s);
     default: return launch_rows<1024>(a, k, phase2, s);
   }
+}
+
+void dvt_t_layout(const DvtFitConfig* c, DvtTLayout* L) {
+  const int C = c->feat_dim, H = c->hidden, R = c->res_hidden, E = c->grid.n_levels * c->grid.n_features;
+  const int cols[DVT_T_COUNT] = {C, H, H, E, C, R, R, C, R, R};
+  long long o = 0;
+  for (int i = 0; i < DVT_T_COUNT; ++i) {
+    L->off[i] = o;
+    L->cols[i] = cols[i];
+    o += (long long)cols[i] * c->batch;
+  }
+  L->total = o;
+}
+
+int dvt_fit_wgrad_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bool phase2, hipStream_t s) {
+  if (!dvt_fit_fused_ok(c) || !fits || k < 1 || k > DVT_FIT_BATCH_MAX) return DVT_E_BADARG;
+  DvtTLayout TL;
+  dvt_t_layout(c, &TL);
+  const int C = c->feat_dim, H = c->hidden, R = c->res_hidden, E = c->grid.n_levels * c->grid.n_features;
+  WgradArgs a{};
+  a.B = c->batch;
+  const int ksteps = a.B / 32;
+  a.ksplit = g_wgrad_ksplit;  // batch slices; S = ksteps / ksplit must be a multiple of 4
+  while (a.ksplit > 1 && (ksteps % (4 * a.ksplit))) a.ksplit >>= 1;
+  if ((ksteps / a.ksplit) % 4) return DVT_E_BADARG;
+  int units = 0;
+  double flops = 0.0;
+  auto add = [&](const DvtFusedFit& f, int tA, int tB, long long ow, long long ob, int M, int N) {
+    WgradProb& p = a.p[a.n_prob];
+    p.AT = f.T + TL.off[tA];
+    p.BT = f.T + TL.off[tB];
+    p.dW = f.grads + ow;
+    p.db = f.grads + ob;
+    p.M = M;
+    p.N = N;
+    a.unit0[a.n_prob++] = units;
+    units += (M / 32) * (N / 32);
+    flops += 2.0 * M * N * a.B;
+  };
+  for (int f = 0; f < k; ++f) {
+    add(fits[f], DVT_T_DF, DVT_T_H1, c->off_w2, c->off_b2, C, H);    // dW2 = dF^T . h1
+    add(fits[f], DVT_T_DH1, DVT_T_ENC, c->off_w1, c->off_b1, H, E);  // dW1 = dh1^T . enc
+    if (phase2) {
+      add(fits[f], DVT_T_DH, DVT_T_R2, c->off_wh3, c->off_bh3, C, R);    // dWh3 = dH^T . r2
+      add(fits[f], DVT_T_DR2, DVT_T_R1, c->off_wh2, c->off_bh2, R, R);   // dWh2 = dr2^T . r1
+      add(fits[f], DVT_T_DR1, DVT_T_RAW, c->off_wh1, c->off_bh1, R, C);  // dWh1 = dr1^T . raw
+    }
+  }
+  a.unit0[a.n_prob] = units;
+  a.units_total = units;
+  a.lattice = c->lattice;
+  a.cq = C / 4;
+  if (!phase2) {
+    for (int f = 0; f < k; ++f) {
+      if (!fits[f].g_offs || !fits[f].g_perm) return DVT_E_BADARG;
+      a.gg[f] = WgradGather{fits[f].g_offs, fits[f].g_perm, reinterpret_cast<const float4*>(fits[f].dF),
+                            reinterpret_cast<float4*>(fits[f].grads + c->off_G)};
+    }
+    a.n_gather = k;
+  }
+  DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, flops);
+  hipLaunchKernelGGL(wgrad_frag_kernel, dim3(dvt_cdiv((long long)units * a.ksplit + a.n_gather * a.lattice, 4)),
+                     dim3(256), 0, s, a);
+  DVT_CHECK_LAUNCH();
+  return 0;
 }

@@ -333,7 +333,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   } else {
     const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
     const int c8 = (lane & 7) * 8;  // 8 lanes x 8 columns = one row; 8 rows per pass
-#pragma unroll 4
+    // (GELU: one row at a time -- four rows of erf polynomials in flight took the fc1 kernel to 254 VGPRs,
+    // and at 2 x 256 registers per SIMD no wave of the fit's streaming kernels can share the CU)
+#pragma unroll(EPI == EPI_GELU ? 1 : 4)
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3);
       float4 a = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8);
@@ -764,6 +766,9 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
 
+// 224 VGPRs, not the 256 that two waves per SIMD would allow: 2 x 224 leaves 64 registers per SIMD, room
+// for one wave of the fit's streaming kernels (Adam: 56) beside the two GEMM waves.  With 228-254 registers
+// nothing else fitted and the HBM-bound fit could only time-slice whole CUs with the MFMA-bound extractor.
 template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
@@ -887,7 +892,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
 }
 
-int g_vit_group_bytes = 2400 * 1024;  // W bytes kept L2-resident per group (tunable)
+// W bytes kept L2-resident per N-tile group.  4800 KiB = every N tile of a K = 768 GEMM in ONE group (qkv: 9
+// tiles, fc1: 12): each 393-KB A panel is then fetched once instead of once per group (measured: GEMMs 907 ->
+// 931 TF/s in the extractor; 9600 KiB the same, 1200 KiB 900).
+int g_vit_group_bytes = 4800 * 1024;
 
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
