@@ -114,6 +114,7 @@ struct DvtFusedFit {  // per fit: inputs, arena, shadow weights and what the row
   float* grads;       // gradient arena (weight gradients accumulate here with fp32 atomics)
   const int32_t* g_offs;   // this step's row lists of the G gradient (DvtAdamRowGather), phase 1 only
   const uint16_t* g_perm;
+  uint32_t* touched;       // bitmap of grid entries with a gradient (grid backward -> Adam)
 };
 #if defined(__HIPCC__)
 typedef __bf16 dvt_hwbf16x2 __attribute__((ext_vector_type(2)));
@@ -161,8 +162,9 @@ bool dvt_fit_fused_ok(const DvtFitConfig* c);         // shapes fit AND the bf16
 bool dvt_fit_fused_shapes_ok(const DvtFitConfig* c);  // shapes only (workspace carving must not depend on the mode)
 int dvt_fit_rows_k(const DvtFitConfig* c, const DvtShadowLayout* L, int k, const DvtFusedFit* fits, bool phase2,
                    hipStream_t s);
-// all weight (and bias) gradients of the step from the transposed operand copies, one launch
-int dvt_fit_wgrad_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bool phase2, hipStream_t s);
+// everything of the backward pass that reduces over rows, one launch: hash-grid backward || all weight (and
+// bias) gradients from the transposed operand copies (+ the gradient of G)
+int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bool phase2, hipStream_t s);
 
 // ---- profiling probes (dvt_prof.hip) ----
 extern unsigned g_dvt_prof_mask;

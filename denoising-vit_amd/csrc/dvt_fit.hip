@@ -17,7 +17,6 @@
 #include "dvt_common.h"
 
 int g_adam_pingpong = 1;  // dvt_tune_set(8, 0): always sweep forward (A/B timing)
-int g_wgrad_ksplit = 4;   // dvt_tune_set(7, v): batch slices per weight-gradient block (4 or 8)
 
 namespace {
 
@@ -224,7 +223,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
       const Work& w = ws[f];
       shadow[f] = w.shadow;
       ff[f] = DvtFusedFit{xy[f], ridx[f], feat[f], P[f], w.shadow, w.T, w.F, w.Hres, w.dF, w.denc, w.rows, Gd[f],
-                          w.g_offs + (size_t)step * (c->lattice + 1), w.g_perm + (size_t)step * B};
+                          w.g_offs + (size_t)step * (c->lattice + 1), w.g_perm + (size_t)step * B, touched[f]};
     }
     DVT_TRY(dvt_fit_rows_k(c, &shl, k, ff, use_res, s));
   } else {
@@ -271,11 +270,8 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     if (log) DVT_TRY(dvt_loss_reduce(ws[f].rows, b->losses + (size_t)step * 8, B, C, use_res, s));
   }
   if (fused) {
-    // ---- all weight gradients of the step (the only part that reduces over rows) in ONE launch
-    DVT_TRY(dvt_fit_wgrad_k(c, k, ff, use_res, s));
-    float* dgrid[KM];
-    at(Gd, c->off_grid, dgrid);
-    DVT_TRY(dvt_grid_bwd_k(&c->grid, k, xy, ridx, denc, dgrid, touched, B, s));
+    // ---- everything that reduces over rows in ONE launch: grid backward || weight gradients (+ dG)
+    DVT_TRY(dvt_fit_backward_k(c, k, ff, use_res, s));
   } else {
   // ---- backward: {field layer 2, h layer 3}, {field layer 1, h layer 2}, hash grid, {h layer 1}
   n_ops = 0;

@@ -30,8 +30,6 @@
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-extern int g_wgrad_ksplit;
-
 namespace {
 
 constexpr int FR = 16;   // rows per workgroup = M of the MFMA
@@ -362,108 +360,168 @@ struct WgradArgs {
   WgradProb p[WG_MAX_PROB];
 };
 
-__global__ __launch_bounds__(256) void wgrad_frag_kernel(WgradArgs a) {
+// One 1024-thread block = 4 output blocks x 4 batch quarters: wave w works on unit (4 * blk + w / 4), quarter
+// w % 4; the four partial 32 x 32 sums of a unit meet in LDS and ONE wave stores the total with plain stores
+// (the gradient arena is zero between steps) -- no atomics, deterministic sums.  (With fp32 atomics, 4 per
+// element, this half and the grid backward were both bound by the L2 atomic rate: side by side in one launch
+// they took exactly the sum of their stand-alone times.)
+constexpr int WG_PART_FLOATS = 32 * 32 + 32;  // a wave's partial block + its bias partials
+__device__ __forceinline__ void wgrad_block(const WgradArgs& a, int blk, int wave, int lane, float* red) {
   constexpr int PD = 4;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int id = blockIdx.x * 4 + wave;
-  if (id >= a.units_total * a.ksplit) {
-    // ---- surplus waves: the gradient of G, one wave per lattice row (lists average 1.5 samples).  Plain
-    // stores into the zeroed gradient arena; Adam then reads G like any dense-gradient tensor -- which keeps
-    // the gather's registers out of the Adam kernel (see adam_kernel).
-    const int u = id - a.units_total * a.ksplit;
-    if (u >= a.n_gather * a.lattice) return;
-    const int fi = u / a.lattice, r = u - fi * a.lattice;
-    const WgradGather& gg = a.gg[fi];
-    const int o0 = gg.offs[r], o1 = gg.offs[r + 1];
-    if (o1 == o0) return;
-    for (int q = lane; q < a.cq; q += 64) {
-      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int o = o0; o < o1; ++o) {
-        const float4 d = gg.rows[(size_t)gg.perm[o] * a.cq + q];
-        acc4.x += d.x;
-        acc4.y += d.y;
-        acc4.z += d.z;
-        acc4.w += d.w;
-      }
-      gg.dG[(size_t)r * a.cq + q] = acc4;
-    }
-    return;
-  }
-  const int ks = id / a.units_total, unit = id - ks * a.units_total;
-  int pi = 0;
+  const int slot = wave >> 2, ks = wave & 3;
+  const int unit = blk * 4 + slot;
+  float* mine = red + (slot * 4 + ks) * WG_PART_FLOATS;
+  const bool is_w = unit < a.units_total;
+  const int gu = unit - a.units_total;  // gradient-of-G rows ride in the surplus units (4 rows per unit)
+  float* out_w = nullptr;  // (plain values, not a pointer into the kernel arguments: that forces a stack copy)
+  float* out_b = nullptr;
+  int out_n = 0;
+  int mb = 0, nb = 0;
+  bool do_bias = false;
+  if (is_w) {
+    int pi = 0;
 #pragma unroll
-  for (int j = 1; j < WG_MAX_PROB; ++j)
-    if (j < a.n_prob && unit >= a.unit0[j]) pi = j;
-  const WgradProb& p = a.p[pi];
-  const int local = unit - a.unit0[pi], nbn = p.N >> 5;
-  const int mb = local / nbn, nb = local - mb * nbn;
-  const int ksteps = a.B >> 5, S = ksteps / a.ksplit, s_begin = ks * S;  // S % PD == 0 (host)
-  const uint16_t* ap[2];
-  const uint16_t* bp[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    ap[i] = p.AT + ((size_t)(mb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
-    bp[i] = p.BT + ((size_t)(nb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
-  }
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.db != nullptr && nb == 0;  // wave-uniform
-  float bsum[2] = {0.f, 0.f};
-  bf16x8 fa[PD][2], fb[PD][2];
-#pragma unroll
-  for (int q = 0; q < PD; ++q)
+    for (int j = 1; j < WG_MAX_PROB; ++j)
+      if (j < a.n_prob && unit >= a.unit0[j]) pi = j;
+    const WgradProb& p = a.p[pi];
+    out_w = p.dW;
+    out_b = p.db;
+    out_n = p.N;
+    const int local = unit - a.unit0[pi], nbn = p.N >> 5;
+    mb = local / nbn;
+    nb = local - mb * nbn;
+    const int ksteps = a.B >> 5, S = ksteps >> 2, s_begin = ks * S;  // S % PD == 0 (host)
+    const uint16_t* ap[2];
+    const uint16_t* bp[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * q);
-      fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * q);
+      ap[i] = p.AT + ((size_t)(mb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
+      bp[i] = p.BT + ((size_t)(nb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
     }
-  __builtin_amdgcn_sched_barrier(0);
-  for (int s0 = 0; s0 < S; s0 += PD) {
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int q = 0; q < PD; ++q) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    do_bias = p.db != nullptr && nb == 0;  // wave-uniform
+    float bsum[2] = {0.f, 0.f};
+    bf16x8 fa[PD][2], fb[PD][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
-      if (do_bias) {
+    for (int q = 0; q < PD; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * q);
+        fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * q);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < S; s0 += PD) {
+#pragma unroll
+      for (int q = 0; q < PD; ++q) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((uint32_t)(uint16_t)fa[q][i][e]) << 16);
-      }
-      if (s0 + q + PD < S) {
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * (s0 + q + PD));
-          fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * (s0 + q + PD));
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((uint32_t)(uint16_t)fa[q][i][e]) << 16);
         }
+        if (s0 + q + PD < S) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * (s0 + q + PD));
+            fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * (s0 + q + PD));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    }
+    // partial block -> LDS, element (i, j, r) of lane l at ((i * 2 + j) * 4 + r) * 64 + l (conflict-free)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[((i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {  // lane (lc, g) holds 8 of a k-step's 32 batch rows for column lc: fold the 4 groups
+        float v = bsum[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) mine[1024 + i * 16 + lane] = v;
+      }
     }
   }
-  // D[row = m][col = n]: col = lane & 15, row = 4 * (lane >> 4) + r
-  const int lc = lane & 15, g = lane >> 4;
+  __syncthreads();
+  if (is_w) {
+    if (ks != 0) return;
+    const float* base = red + slot * 4 * WG_PART_FLOATS;
+    // D[row = m][col = n]: col = lane & 15, row = 4 * (lane >> 4) + r
+    const int lc = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        atomic_add_f32(p.dW + (size_t)(mb * 32 + i * 16 + 4 * g + r) * p.N + nb * 32 + j * 16 + lc, acc[i][j][r]);
-  if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {  // lane (lc, g) holds 8 of the 32 batch rows of a k-step for column lc: fold the 4 groups
-      float v = bsum[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (g == 0) atomic_add_f32(p.db + mb * 32 + i * 16 + lc, v);
+        for (int r = 0; r < 4; ++r) {
+          const int o = ((i * 2 + j) * 4 + r) * 64 + lane;
+          const float v = (base[o] + base[WG_PART_FLOATS + o]) + (base[2 * WG_PART_FLOATS + o] + base[3 * WG_PART_FLOATS + o]);
+          out_w[(size_t)(mb * 32 + i * 16 + 4 * g + r) * out_n + nb * 32 + j * 16 + lc] = v;
+        }
+    if (do_bias && lane < 32) {
+      const int o = 1024 + lane;
+      out_b[mb * 32 + lane] = (base[o] + base[WG_PART_FLOATS + o]) + (base[2 * WG_PART_FLOATS + o] + base[3 * WG_PART_FLOATS + o]);
     }
+    return;
   }
+  // ---- surplus units: the gradient of G, one wave per lattice row (lists average 1.5 samples).  Plain stores
+  // into the zeroed gradient arena; Adam then reads G like any dense-gradient tensor -- which keeps the
+  // gather's registers out of the Adam kernel (see adam_kernel).
+  const int u = gu * 4 + ks;
+  if (u >= a.n_gather * a.lattice) return;
+  const int fi = u / a.lattice, r = u - fi * a.lattice;
+  const WgradGather& gg = a.gg[fi];
+  const int o0 = gg.offs[r], o1 = gg.offs[r + 1];
+  if (o1 == o0) return;
+  for (int q = lane; q < a.cq; q += 64) {
+    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = o0; o < o1; ++o) {
+      const float4 d = gg.rows[(size_t)gg.perm[o] * a.cq + q];
+      acc4.x += d.x;
+      acc4.y += d.y;
+      acc4.z += d.z;
+      acc4.w += d.w;
+    }
+    gg.dG[(size_t)r * a.cq + q] = acc4;
+  }
+}
+
+// ONE launch for the two independent halves of the backward pass that reduce over rows: the hash-grid
+// backward (blocks [0, grid_blocks): LDS-accumulated coarse levels + atomics for the fine ones, dvt_grid.hip)
+// and the weight gradients (the rest: 16 independent waves per block).  Back to back they cost 27 + 17 us and
+// a launch boundary; side by side the longer one.
+struct BackwardArgs {
+  DvtGridTable T;
+  GridBwdPlan plan;
+  GridBwdPtrs gp;
+  int n, grid_blocks_per_fit, k, wg_blocks;
+  WgradArgs w;
+};
+__global__ __launch_bounds__(1024) void fit_backward_kernel(BackwardArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[16 * WG_PART_FLOATS];  // 66 KB: grid half uses the first 8.2 KB
+  // weight-gradient blocks FIRST: the grid half alone is more blocks than the chip holds at once, behind
+  // it the other half would only start when it drains (measured: the sum of the two, not the maximum)
+  if ((int)blockIdx.x >= a.wg_blocks) {
+    const int b = (int)blockIdx.x - a.wg_blocks;
+    grid_bwd_body<256>(a.T, a.plan, a.gp, a.n, b % a.grid_blocks_per_fit, b / a.grid_blocks_per_fit, smem,
+                       reinterpret_cast<uint32_t*>(smem + 256 * 8));
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  wgrad_block(a.w, (int)blockIdx.x, wave, threadIdx.x & 63, smem);
 }
 
 template <int C>
@@ -581,17 +639,17 @@ void dvt_t_layout(const DvtFitConfig* c, DvtTLayout* L) {
   L->total = o;
 }
 
-int dvt_fit_wgrad_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bool phase2, hipStream_t s) {
+int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bool phase2, hipStream_t s) {
   if (!dvt_fit_fused_ok(c) || !fits || k < 1 || k > DVT_FIT_BATCH_MAX) return DVT_E_BADARG;
   DvtTLayout TL;
   dvt_t_layout(c, &TL);
   const int C = c->feat_dim, H = c->hidden, R = c->res_hidden, E = c->grid.n_levels * c->grid.n_features;
-  WgradArgs a{};
+  BackwardArgs ba{};
+  WgradArgs& a = ba.w;
   a.B = c->batch;
   const int ksteps = a.B / 32;
-  a.ksplit = g_wgrad_ksplit;  // batch slices; S = ksteps / ksplit must be a multiple of 4
-  while (a.ksplit > 1 && (ksteps % (4 * a.ksplit))) a.ksplit >>= 1;
-  if ((ksteps / a.ksplit) % 4) return DVT_E_BADARG;
+  a.ksplit = 4;  // batch quarters = the 4 waves of a unit; S = ksteps / 4 must be a multiple of the prefetch depth 4
+  if (ksteps % 16) return DVT_E_BADARG;
   int units = 0;
   double flops = 0.0;
   auto add = [&](const DvtFusedFit& f, int tA, int tB, long long ow, long long ob, int M, int N) {
@@ -627,9 +685,27 @@ int dvt_fit_wgrad_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bool 
     }
     a.n_gather = k;
   }
+  // hash-grid backward half (same plan / body as dvt_grid_bwd_k, 256-entry LDS chunks)
+  ba.T = c->grid;
+  ba.n = c->batch;
+  ba.k = k;
+  const int saved_chunk = g_grid_lds_chunk;
+  g_grid_lds_chunk = 256;
+  dvt_grid_bwd_plan(c->grid, c->batch, &ba.plan);
+  g_grid_lds_chunk = saved_chunk;
+  const long long direct_threads = (long long)c->batch * (c->grid.n_levels - ba.plan.first_direct_level) * 8;
+  ba.grid_blocks_per_fit = ba.plan.n_lds_blocks + dvt_cdiv(direct_threads, 1024);
+  for (int f = 0; f < k; ++f) {
+    ba.gp.xy[f] = reinterpret_cast<const float2*>(fits[f].xy);
+    ba.gp.ridx[f] = fits[f].ridx;
+    ba.gp.d_enc[f] = fits[f].denc;
+    ba.gp.d_params[f] = fits[f].grads + c->off_grid;
+    ba.gp.touched[f] = fits[f].touched;
+  }
+  const int wg_blocks = dvt_cdiv((long long)units + dvt_cdiv((long long)a.n_gather * a.lattice, 4), 4);
+  ba.wg_blocks = wg_blocks;
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, flops);
-  hipLaunchKernelGGL(wgrad_frag_kernel, dim3(dvt_cdiv((long long)units * a.ksplit + a.n_gather * a.lattice, 4)),
-                     dim3(256), 0, s, a);
+  hipLaunchKernelGGL(fit_backward_kernel, dim3(ba.grid_blocks_per_fit * k + wg_blocks), dim3(1024), 0, s, ba);
   DVT_CHECK_LAUNCH();
   return 0;
 }

@@ -692,7 +692,7 @@ extern int g_cfg_override;
 }
 extern int g_fit_fused_enable;
 extern int g_adam_pingpong;
-extern int g_wgrad_ksplit;
+
 extern "C" int dvt_tune_set(int key, int value) {
   if (key == 0) {
     g_cfg_override = value;
@@ -705,11 +705,6 @@ extern "C" int dvt_tune_set(int key, int value) {
   if (key == 5) {
     if (value != 16 && value != 32 && value != 64) return DVT_E_BADARG;
     g_f32_bk = value;
-    return 0;
-  }
-  if (key == 7) {
-    if (value != 2 && value != 4 && value != 8) return DVT_E_BADARG;
-    g_wgrad_ksplit = value;
     return 0;
   }
   if (key == 8) {

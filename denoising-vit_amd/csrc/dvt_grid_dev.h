@@ -27,3 +27,131 @@ __device__ __forceinline__ void corners2d(const DvtGridTable& T, int l, float x,
   }
 }
 
+
+// ---- backward ------------------------------------------------------------------------------------------
+// (design notes: dvt_grid.hip)
+struct GridBwdPlan {
+  int n_lds_blocks;
+  int first_direct_level;  // levels [first_direct_level, L) use global atomics
+  int chunk_start[DVT_MAX_LEVELS + 1];  // first LDS block of each LDS level (prefix sum)
+  int splits[DVT_MAX_LEVELS];           // sample slices per chunk of that level
+};
+
+struct GridBwdPtrs {  // per fit of a batched launch
+  const float2* xy[DVT_FIT_BATCH_MAX];
+  const int32_t* ridx[DVT_FIT_BATCH_MAX];
+  const float* d_enc[DVT_FIT_BATCH_MAX];
+  float* d_params[DVT_FIT_BATCH_MAX];
+  uint32_t* touched[DVT_FIT_BATCH_MAX];
+};
+
+// Body of the grid backward for workgroup `bx` of fit `fy` (1024 threads); `acc` / `flags` are the caller's
+// LDS ([LDS_CHUNK * 8] floats, [LDS_CHUNK / 32 + 1] words).  Shared by grid_bwd_kernel (dvt_grid.hip) and the
+// merged backward launch of the fused fit step (dvt_fit_fused.hip).
+template <int LDS_CHUNK>
+__device__ __forceinline__ void grid_bwd_body(const DvtGridTable& T, const GridBwdPlan& plan, const GridBwdPtrs& q,
+                                              int n, int bx, int fy, float* acc, uint32_t* flags) {
+  const float2* __restrict__ xy = q.xy[fy];
+  const int32_t* __restrict__ ridx = q.ridx[fy];
+  const float* __restrict__ d_enc = q.d_enc[fy];
+  float* __restrict__ d_params = q.d_params[fy];
+  uint32_t* __restrict__ touched = q.touched[fy];
+  const int L = T.n_levels;
+  const int tid = threadIdx.x;
+  if (bx < plan.n_lds_blocks) {
+    int l = 0;
+    while (l + 1 < plan.first_direct_level && bx >= plan.chunk_start[l + 1]) ++l;
+    const int nsplit = plan.splits[l];
+    const int local = bx - plan.chunk_start[l];
+    const int split = local % nsplit;
+    const uint32_t e0 = (uint32_t)(local / nsplit) * LDS_CHUNK;
+    const int per = (n + nsplit - 1) / nsplit;  // samples of this slice
+    const int b_begin = split * per, b_end = min(n, b_begin + per);
+    const uint32_t abs0 = T.offset[l] + e0;  // first absolute entry
+    const uint32_t cnt = min((uint32_t)LDS_CHUNK, T.entries[l] - e0);
+    const uint32_t base32 = abs0 & ~31u;  // flags are kept in GLOBAL bitmap word alignment
+    for (int i = tid; i < LDS_CHUNK * 8; i += 1024) acc[i] = 0.f;
+    if (tid < LDS_CHUNK / 32 + 1) flags[tid] = 0u;
+    __syncthreads();
+    for (int b = b_begin + tid; b < b_end; b += 1024) {
+      const float2 p = xy[ridx != nullptr ? ridx[b] : b];
+      uint32_t idx[4];
+      float w[4];
+      corners2d(T, l, p.x, p.y, idx, w);
+      bool any = false;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) any |= (idx[c] - abs0) < cnt;
+      if (!any) continue;
+      const float4* gp = reinterpret_cast<const float4*>(d_enc + ((size_t)b * L + l) * 8);
+      const float4 g0 = gp[0], g1 = gp[1];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t rel = idx[c] - abs0;
+        if (rel < cnt) {
+          float* a = acc + rel;  // feature-major: bank = rel % 32, no stride-8 conflicts
+          atomicAdd(a + 0 * LDS_CHUNK, w[c] * g0.x);
+          atomicAdd(a + 1 * LDS_CHUNK, w[c] * g0.y);
+          atomicAdd(a + 2 * LDS_CHUNK, w[c] * g0.z);
+          atomicAdd(a + 3 * LDS_CHUNK, w[c] * g0.w);
+          atomicAdd(a + 4 * LDS_CHUNK, w[c] * g1.x);
+          atomicAdd(a + 5 * LDS_CHUNK, w[c] * g1.y);
+          atomicAdd(a + 6 * LDS_CHUNK, w[c] * g1.z);
+          atomicAdd(a + 7 * LDS_CHUNK, w[c] * g1.w);
+          atomicOr(&flags[(idx[c] - base32) >> 5], 1u << (idx[c] & 31u));
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < cnt; e += 1024) {
+      const uint32_t a = abs0 + e;
+      if ((flags[(a - base32) >> 5] >> (a & 31u)) & 1u) {
+        float4* dst = reinterpret_cast<float4*>(d_params + (size_t)a * 8);
+        if (nsplit > 1) {  // several slices own this entry: combine with global atomics
+          float* d = d_params + (size_t)a * 8;
+#pragma unroll
+          for (int f = 0; f < 8; ++f) atomic_add_f32(d + f, acc[f * LDS_CHUNK + e]);
+          continue;
+        }
+        // single writer per entry within this launch: plain read-modify-write keeps the
+        // documented "+=" semantics without atomics
+        const float4 o0 = dst[0], o1 = dst[1];
+        const float4 s0 = make_float4(acc[e], acc[LDS_CHUNK + e], acc[2 * LDS_CHUNK + e],
+                                      acc[3 * LDS_CHUNK + e]);
+        const float4 s1 = make_float4(acc[4 * LDS_CHUNK + e], acc[5 * LDS_CHUNK + e],
+                                      acc[6 * LDS_CHUNK + e], acc[7 * LDS_CHUNK + e]);
+        dst[0] = make_float4(o0.x + s0.x, o0.y + s0.y, o0.z + s0.z, o0.w + s0.w);
+        dst[1] = make_float4(o1.x + s1.x, o1.y + s1.y, o1.z + s1.z, o1.w + s1.w);
+      }
+    }
+    if (touched != nullptr && tid < LDS_CHUNK / 32 + 1 && flags[tid] != 0u)
+      __hip_atomic_fetch_or(touched + (base32 >> 5) + tid, flags[tid], __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- direct atomics for the fine levels ----
+  const int nd = L - plan.first_direct_level;
+  const long long t = (long long)(bx - plan.n_lds_blocks) * 1024 + tid;
+  if (nd <= 0 || t >= (long long)n * nd * 8) return;
+  const int f = (int)(t & 7);
+  const long long bl = t >> 3;
+  const int b = (int)(bl / nd), l = plan.first_direct_level + (int)(bl - (long long)b * nd);
+  const float2 p = xy[ridx != nullptr ? ridx[b] : b];
+  uint32_t idx[4];
+  float w[4];
+  corners2d(T, l, p.x, p.y, idx, w);
+  const float g = d_enc[((size_t)b * L + l) * 8 + f];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    atomic_add_f32(d_params + (size_t)idx[c] * 8 + f, w[c] * g);
+    if (touched != nullptr && f == 0) {
+      const uint32_t bit = 1u << (idx[c] & 31u);
+      uint32_t* wp = touched + (idx[c] >> 5);
+      if ((__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0u)
+        __hip_atomic_fetch_or(wp, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+
+void dvt_grid_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan);
+extern int g_grid_lds_chunk;

@@ -267,7 +267,6 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);
  * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
  * key 6 = bf16-mode fit step: 1 (default) the fused row kernel (dvt_fit_fused.hip), 0 = one launch per layer;
- * key 7 = weight-gradient kernel of the fused step: batch slices per 32 x 32 block (2, 4 default, 8);
  * key 8 = Adam sweeps the arena in alternating directions on consecutive steps (1, default) or always forward (0);
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);
