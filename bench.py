@@ -239,6 +239,19 @@ def main():
         second = {"images_per_s": world * n2 / el2, "images_timed_per_rank": n2,
                   "t_fit_s_serial": st.timings[-1]["t_fit"]}
         set_fit_dtype(a.fit_dtype)
+    full_fp32 = None
+    if not a.no_fp32_fit and rank == 0 and world == 1:
+        # the reference's DEFAULT precision end to end (--dtype float32: fp32 extractor + fp32 fit), one image,
+        # strictly serial (exact-fp32 matrix cores: 1/16 of the bf16 rate)
+        set_fit_dtype("float32")
+        st.extract_dtype = "float32"
+        st.process(lambda slot: None)  # first call builds the fp32 weight copies / workspace
+        st.process(lambda slot: None)
+        t = st.timings[-1]
+        full_fp32 = {"images_per_s": 1.0 / (t["t_extract"] + t["t_fit"]), "t_extract_s": t["t_extract"],
+                     "t_fit_s": t["t_fit"], "images_timed": 1, "flow": "serial"}
+        st.extract_dtype = "bfloat16"
+        set_fit_dtype(a.fit_dtype)
 
     if rank == 0:
         out = {
@@ -267,6 +280,9 @@ def main():
             key = "value_fp32_fit" if other == "float32" else "value_bf16_fit"
             out[key] = second["images_per_s"]
             out["config"][key + "_detail"] = second
+        if full_fp32 is not None:
+            out["value_fp32"] = full_fp32["images_per_s"]
+            out["config"]["value_fp32_detail"] = full_fp32
 
         def kernel_table(pr, images):
             kern = {}

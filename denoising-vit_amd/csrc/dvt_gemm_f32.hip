@@ -721,6 +721,21 @@ extern "C" int dvt_tune_set(int key, int value) {
   return DVT_E_BADARG;
 }
 
+// Forward linear for LARGE m (the fp32 extractor: m = views x 1408 tokens): always the 3-stage LDS-DMA kernel
+// when the shape is eligible, whatever the co-residency knob of the fit says.
+int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s) {
+  if (!x || !w || !y || m <= 0 || n <= 0 || k <= 0 || (k & 3) || (n & 3)) return DVT_E_BADARG;
+  const GemmArgs a = make_fwd(x, w, b, y, m, n, k, 0);
+  if ((a.K % BK) == 0 && (a.kchunk % BK) == 0) {
+    dim3 grid(dvt_cdiv(a.N, 64), dvt_cdiv(a.M, 64), 1);
+    DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<true, true>), grid, dim3(256), 0, s, a);
+    DVT_CHECK_LAUNCH();
+    return 0;
+  }
+  return launch<true, true>(a, 1, s);
+}
+
 extern "C" int dvt_linear_fwd(const float* x, const float* w, const float* b, float* y, int m,
                               int n, int k, int relu, void* stream) {
   if (!x || !w || !y || m < 0 || n <= 0 || k <= 0 || (k & 3) || (n & 3)) return DVT_E_BADARG;

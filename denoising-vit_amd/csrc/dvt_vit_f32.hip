@@ -1,0 +1,339 @@
+// fp32 frozen-ViT forward for gfx950: the reference's DEFAULT precision (`--dtype float32`,
+// main_img_denoising.py:173, :257, :299 -- autocast disabled, timm runs in fp32).  C ABI in include/dvt_vit.h.
+//
+// Same layer sequence and token layout as the bf16 extractor (dvt_vit.hip; reference
+// dvt/models/vit_wrapper.py:122-143 -> timm VisionTransformer.forward_intermediates), every operand fp32:
+//   GEMMs      exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, dvt_gemm_f32.hip: bitwise an fmaf chain),
+//              157 TF/s peak = 1/16 of the bf16 rate -- this mode costs seconds per image, it exists so that
+//              `--dtype float32` means what the reference means, not to be fast;
+//   attention  flash-style on the same instruction: S^T = K.Q^T per 32-key tile so that a query's softmax
+//              statistics are lane-local and P stays in the accumulator registers as the B operand of
+//              O^T = V^T.P^T (no shuffles, no LDS round trip for P);
+//   LayerNorm, exact-erf GELU (erff), LayerScale + residual, position embedding: fp32 element-wise kernels.
+#include <math.h>
+
+#include "../../include/dvt_vit.h"
+#include "dvt_common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s);
+
+namespace {
+
+inline int64_t up256b(int64_t x) { return (x + 255) / 256 * 256; }
+
+struct VitWorkF {
+  float *x, *xn, *qkv, *ao, *hid, *tmp, *col;
+};
+
+int64_t carve_f32(const DvtVitConfig* c, int batch, char* base, VitWorkF* w) {
+  const int64_t T = (int64_t)batch * c->s_pad;
+  int64_t o = 0;
+  auto take = [&](int64_t floats) {
+    char* p = base ? base + o : nullptr;
+    o += up256b(floats * 4);
+    return reinterpret_cast<float*>(p);
+  };
+  VitWorkF t;
+  t.x = take(T * c->dim);
+  t.xn = take(T * c->dim);
+  t.qkv = take(T * 3 * c->dim);
+  t.ao = take(T * c->dim);
+  t.hid = take(T * c->mlp_dim);
+  t.tmp = take(T * c->dim);
+  t.col = take(T * c->k_patch);
+  if (w) *w = t;
+  return o;
+}
+
+__global__ __launch_bounds__(256) void im2col_f32_kernel(const float* __restrict__ img, float* __restrict__ col,
+                                                         DvtVitConfig c) {
+  const int t = blockIdx.x;  // token row in [0, batch*s_pad)
+  const int b = t / c.s_pad, s = t - b * c.s_pad;
+  float* dst = col + (size_t)t * c.k_patch;
+  const int pp = c.patch * c.patch;
+  if (s < c.n_prefix || s >= c.n_tokens) {
+    for (int k = threadIdx.x; k < c.k_patch; k += 256) dst[k] = 0.f;
+    return;
+  }
+  const int py = (s - c.n_prefix) / c.grid_w, px = (s - c.n_prefix) - py * c.grid_w;
+  const float* src = img + (size_t)b * 3 * c.img_h * c.img_w;
+  for (int k = threadIdx.x; k < c.k_patch; k += 256) {
+    float v = 0.f;
+    if (k < 3 * pp) {
+      const int ch = k / pp, rem = k - ch * pp, ky = rem / c.patch, kx = rem - ky * c.patch;
+      v = src[((size_t)ch * c.img_h + py * c.stride + ky) * c.img_w + px * c.stride + kx];
+    }
+    dst[k] = v;
+  }
+}
+
+// x[t] = prefix token (+ pos_embed[0] for cls when the table has a cls row) | patch embedding + pos_embed | 0 (pad)
+__global__ __launch_bounds__(256) void embed_f32_kernel(const float4* __restrict__ y, float4* __restrict__ x,
+                                                        const float4* __restrict__ cls, const float4* __restrict__ pos,
+                                                        DvtVitConfig c) {
+  const int t = blockIdx.x, s = t % c.s_pad, dq = c.dim >> 2;
+  for (int q = threadIdx.x; q < dq; q += 256) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < c.n_prefix) {
+      o = cls[(size_t)s * dq + q];
+      if (c.pos_has_cls && s == 0) {
+        const float4 p = pos[q];
+        o = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+      }
+    } else if (s < c.n_tokens) {
+      const float4 v = y[(size_t)t * dq + q], p = pos[(size_t)(s - c.n_prefix + c.pos_has_cls) * dq + q];
+      o = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+    }
+    x[(size_t)t * dq + q] = o;
+  }
+}
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            int rows, int dim, float eps, int s_pad, int n_tokens,
+                                                            int n_prefix) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  size_t in_row = row;
+  if (FINAL) {  // output row = b*(n_tokens-n_prefix) + (s-n_prefix), input row = b*s_pad + s
+    const int per = n_tokens - n_prefix;
+    const int bb = row / per, s = row - bb * per + n_prefix;
+    in_row = (size_t)bb * s_pad + s;
+  }
+  const float4* xr = reinterpret_cast<const float4*>(x + in_row * dim);
+  const int nq = dim >> 2;
+  float4 v[4];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      v[i] = xr[q];
+      sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)dim;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      const float a = v[i].x - mean, bq = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
+      var += a * a + bq * bq + cq * cq + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(var) / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      const float4 ww = reinterpret_cast<const float4*>(w)[q], bb = reinterpret_cast<const float4*>(b)[q];
+      reinterpret_cast<float4*>(y + (size_t)row * dim)[q] =
+          make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                      (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gelu_f32_kernel(float4* __restrict__ h, long long nq) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+    float4 v = h[q];
+    v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f));  // nn.GELU(): exact erf form
+    v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+    v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f));
+    v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+    h[q] = v;
+  }
+}
+
+// x += gamma * y  (timm Block: x = x + ls(f(norm(x))))
+__global__ __launch_bounds__(256) void resid_f32_kernel(float4* __restrict__ x, const float4* __restrict__ y,
+                                                        const float4* __restrict__ gamma, long long nq, int dq) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+    const float4 g = gamma[q % dq], v = y[q];
+    float4 o = x[q];
+    o.x += g.x * v.x;
+    o.y += g.y * v.y;
+    o.z += g.z * v.z;
+    o.w += g.w * v.w;
+    x[q] = o;
+  }
+}
+
+// ---- attention, head_dim 64, fp32 ------------------------------------------------------------------
+// One workgroup = 128 queries of one (image, head); 4 waves x 32 queries; 32-key tiles of K and V in LDS.
+// MFMA 32x32x2 (A: lane l holds A[i = l & 31][k = l >> 5], B: B[k = l >> 5][j = l & 31], C/D: col = l & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)):
+//   S^T[key][q]  = sum_d K[key][d] * Q[q][d]        A = K tile (LDS), B = Q (registers, pre-scaled by 1/8)
+//   O^T[d][q]   += sum_key V[key][d] * P[key][q]    B = P = the S^T accumulator itself: MFMA step r contracts
+//                                                   the two keys kappa(r) + 4h (h = l >> 5) held in register r,
+//                                                   A = V^T read from the V tile at exactly those keys
+constexpr int FA_Q = 128, FA_K = 32, FA_LD = 65;  // odd pitch: the 32 rows of a K-fragment read hit 32 banks
+
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int heads, int s_pad, int n_valid) {
+  __shared__ float Ks[FA_K * FA_LD];
+  __shared__ float Vs[FA_K * FA_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h2 = lane >> 5;
+  const int nqb = s_pad / FA_Q;
+  const int id = blockIdx.x;
+  const int qb = id % nqb, hd = (id / nqb) % heads, b = id / (nqb * heads);
+  const int dim = heads * 64, ld = 3 * dim;
+  const size_t row0 = (size_t)b * s_pad;
+  const int qrow = qb * FA_Q + wave * 32 + j;
+  // Q fragment values of this lane: Q[q][d = 2 s + h2], scaled by head_dim^-0.5
+  float qf[32];
+  {
+    const float* qp = qkv + (row0 + qrow) * ld + hd * 64 + h2;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qf[s] = qp[2 * s] * 0.125f;
+  }
+  const float* kbase = qkv + row0 * ld + dim + hd * 64;
+  const float* vbase = qkv + row0 * ld + 2 * dim + hd * 64;
+  floatx16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    o0[r] = 0.f;
+    o1[r] = 0.f;
+  }
+  float m_run = -1e30f, l_run = 0.f;
+  const int ntiles = (n_valid + FA_K - 1) / FA_K;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();  // everyone is done with the previous tile
+    {  // stage K / V tile: 32 keys x 64 d each, 256 threads x 2 float4 per operand
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int f = tid + 256 * it, key = f >> 4, dq = f & 15;
+        const size_t g = (size_t)(kt * FA_K + key) * ld + dq * 4;
+        const float4 kv = *reinterpret_cast<const float4*>(kbase + g);
+        const float4 vv = *reinterpret_cast<const float4*>(vbase + g);
+        float* kd = Ks + key * FA_LD + dq * 4;
+        float* vd = Vs + key * FA_LD + dq * 4;
+        kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+        vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+      }
+    }
+    __syncthreads();
+    floatx16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 32; ++t)  // d = 2 t + h2
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[j * FA_LD + 2 * t + h2], qf[t], s, 0, 0, 0);
+    // s[r] = S^T[key = kappa(r) + 4 h2][query j]
+    float tmax = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * FA_K + (r & 3) + 8 * (r >> 2) + 4 * h2;
+      if (key >= n_valid) s[r] = -1e30f;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = expf(s[r] - m_new);
+      psum += s[r];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // contract keys kappa(r) + 4 h2: A = V[key][d = j (+32)], B = P register r
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * h2;
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * FA_LD + j], s[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * FA_LD + 32 + j], s[r], o1, 0, 0, 0);
+    }
+  }
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+  // o0[r] = O^T[d = kappa(r) + 4 h2][query j], o1: d + 32
+  float* op = out + (row0 + qrow) * dim + hd * 64;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * h2;
+    op[d] = o0[r] * inv;
+    op[32 + d] = o1[r] * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t dvt_vit_workspace_bytes_f32(const DvtVitConfig* c, int batch) {
+  if (!c || batch <= 0 || c->s_pad % 128 || c->dim % 64 || c->heads * 64 != c->dim) return -1;
+  return carve_f32(c, batch, nullptr, nullptr);
+}
+
+extern "C" int dvt_vit_attention_f32(const float* qkv, float* out, int batch, int heads, int s_pad, int n_valid,
+                                     void* stream) {
+  if (!qkv || !out || batch <= 0 || heads <= 0 || s_pad % FA_Q || n_valid <= 0 || n_valid > s_pad)
+    return DVT_E_BADARG;
+  hipLaunchKernelGGL(attention_f32_kernel, dim3((s_pad / FA_Q) * heads * batch), dim3(256), 0, (hipStream_t)stream,
+                     qkv, out, heads, s_pad, n_valid);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dvt_vit_forward_f32(const DvtVitConfig* c, const DvtVitWeights* w, const float* img, float* feat,
+                                   int batch, int n_blocks, void* workspace, void* stream) {
+  if (!c || !w || !img || !feat || !workspace || batch <= 0 || n_blocks < 0 || n_blocks > c->depth)
+    return DVT_E_BADARG;
+  if (c->s_pad % 128 || c->dim % 64 || c->heads * 64 != c->dim || c->k_patch % 4) return DVT_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  VitWorkF k;
+  carve_f32(c, batch, (char*)workspace, &k);
+  const int T = batch * c->s_pad, D = c->dim;
+  const long long nqD = (long long)T * D / 4;
+  const int ew_blocks = 256 * 8;
+#define DVT_TRY(x)         \
+  do {                     \
+    int rc__ = (x);        \
+    if (rc__) return rc__; \
+  } while (0)
+  hipLaunchKernelGGL(im2col_f32_kernel, dim3(T), dim3(256), 0, s, img, k.col, *c);
+  DVT_CHECK_LAUNCH();
+  DVT_TRY(dvt_linear_fwd_big(k.col, (const float*)w->patch_w, w->patch_b, k.tmp, T, D, c->k_patch, s));
+  hipLaunchKernelGGL(embed_f32_kernel, dim3(T), dim3(256), 0, s, (const float4*)k.tmp, (float4*)k.x,
+                     (const float4*)w->cls_token, (const float4*)w->pos_embed, *c);
+  DVT_CHECK_LAUNCH();
+  for (int l = 0; l < n_blocks; ++l) {
+    const DvtVitBlockWeights& bw = w->blocks[l];
+    hipLaunchKernelGGL(layernorm_f32_kernel<false>, dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm1_w,
+                       bw.norm1_b, k.xn, T, D, c->ln_eps, 0, 0, 0);
+    DVT_CHECK_LAUNCH();
+    DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.qkv_w, bw.qkv_b, k.qkv, T, 3 * D, D, s));
+    DVT_TRY(dvt_vit_attention_f32(k.qkv, k.ao, batch, c->heads, c->s_pad, c->n_tokens, s));
+    DVT_TRY(dvt_linear_fwd_big(k.ao, (const float*)bw.proj_w, bw.proj_b, k.tmp, T, D, D, s));
+    hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
+                       (const float4*)bw.ls1, nqD, D / 4);
+    DVT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(layernorm_f32_kernel<false>, dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm2_w,
+                       bw.norm2_b, k.xn, T, D, c->ln_eps, 0, 0, 0);
+    DVT_CHECK_LAUNCH();
+    DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, T, c->mlp_dim, D, s));
+    hipLaunchKernelGGL(gelu_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.hid,
+                       (long long)T * c->mlp_dim / 4);
+    DVT_CHECK_LAUNCH();
+    DVT_TRY(dvt_linear_fwd_big(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.tmp, T, D, c->mlp_dim, s));
+    hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
+                       (const float4*)bw.ls2, nqD, D / 4);
+    DVT_CHECK_LAUNCH();
+  }
+#undef DVT_TRY
+  const int out_rows = batch * (c->n_tokens - c->n_prefix);
+  hipLaunchKernelGGL(layernorm_f32_kernel<true>, dim3(dvt_cdiv(out_rows, 4)), dim3(256), 0, s, k.x, w->norm_w,
+                     w->norm_b, feat, out_rows, D, c->ln_eps, c->s_pad, c->n_tokens, c->n_prefix);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}

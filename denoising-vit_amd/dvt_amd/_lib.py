@@ -23,6 +23,7 @@ HIP_SOURCES = [
     "dvt_fit.hip",
     "dvt_fit_fused.hip",
     "dvt_vit.hip",
+    "dvt_vit_f32.hip",
     "dvt_prof.hip",
     "dvt_views.hip",
 ]

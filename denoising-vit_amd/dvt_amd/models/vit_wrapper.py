@@ -110,6 +110,7 @@ class PretrainedViTWrapper(nn.Module):
         checkpoint_path: str | None = None,
         img_size: int | Tuple[int, int] | None = None,
         allow_random_init: bool = False,
+        dtype: str = "bfloat16",
         **kwargs,
     ):
         super().__init__()
@@ -126,6 +127,8 @@ class PretrainedViTWrapper(nn.Module):
         size = img_size or self.spec.img_size
         self.img_size = (size, size) if isinstance(size, int) else tuple(size)
         self.allow_random_init = bool(allow_random_init)
+        # arithmetic of the extractor: "bfloat16" = the reference under autocast, "float32" = its default
+        self.dtype = "float32" if str(dtype) in ("float32", "torch.float32", "fp32") else "bfloat16"
         self._state_dict, self.transformation = self.create_model(model_identifier, checkpoint_path)
         # a grid other than the checkpoint's (stride override vit_wrapper.py:78-91, other input
         # sizes) is handled by resampling pos_embed once on the host (dvt_amd.vit.resample_pos_embed)
@@ -166,19 +169,24 @@ class PretrainedViTWrapper(nn.Module):
     def last_layer_index(self) -> int:
         return self.num_blocks - 1
 
-    def _engine(self, device) -> "_vit.HipViT":
-        if self._hip is None or self._hip.device != torch.device(device):
-            self._hip = _vit.HipViT(self._state_dict, self.patch_size, self.stride, self.img_size,
-                                    device)
-        return self._hip
+    def _engine(self, device, dtype: str | None = None) -> "_vit.HipViT":
+        dtype = dtype or self.dtype
+        if not isinstance(self._hip, dict):
+            self._hip = {}
+        key = (torch.device(device), dtype)
+        if key not in self._hip:
+            self._hip[key] = _vit.HipViT(self._state_dict, self.patch_size, self.stride, self.img_size,
+                                         device, dtype=dtype)
+        return self._hip[key]
 
     def features_nhwc(self, x: torch.Tensor, layer_index: int | None = None,
-                      out: torch.Tensor | None = None, max_batch: int = 128) -> torch.Tensor:
+                      out: torch.Tensor | None = None, max_batch: int = 128,
+                      dtype: str | None = None) -> torch.Tensor:
         """Fast path used by the stage-1 driver: NHWC fp32 patch-token map, optionally written
         straight into a slice of the feature store (no NCHW round trip)."""
         idx = self.last_layer_index if layer_index is None else layer_index
-        return self._engine(x.device).forward_features(x.float(), n_blocks=idx + 1, out=out,
-                                                       max_batch=max_batch)
+        return self._engine(x.device, dtype).forward_features(x.float(), n_blocks=idx + 1, out=out,
+                                                              max_batch=max_batch)
 
     def get_intermediate_layers(
         self,

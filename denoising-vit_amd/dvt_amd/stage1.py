@@ -39,7 +39,9 @@ def get_args(argv=None):
     p.add_argument("--stride_size", type=int, default=14)
     p.add_argument("--layer_depth_ratio", type=float, default=1.0)
     p.add_argument("--img_path", type=str, default="demo/assets/demo/cat.jpg")
-    p.add_argument("--dtype", type=str, default="float32")
+    p.add_argument("--dtype", type=str, default="float32", choices=["float32", "bfloat16"],
+                   help="float32 (reference default): fp32 extractor + fp32-operand fit, exact-fp32 matrix cores, "
+                        "seconds per image; bfloat16: the reference's autocast mode, bf16 MFMA, ~10x faster")
     p.add_argument("--data_root", type=str, default=None)
     p.add_argument("--save_root", type=str, default=None)
     p.add_argument("--start_idx", type=int, default=0)
@@ -141,7 +143,7 @@ class Stage1:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.vit = vit or PretrainedViTWrapper(
             args.model, stride=args.stride_size, checkpoint_path=getattr(args, "vit_checkpoint", None),
-            img_size=args.input_size,
+            img_size=args.input_size, dtype=str(getattr(args, "dtype", "float32")),
             allow_random_init=bool(getattr(args, "synthetic", False) or getattr(args, "allow_random_vit", False)))
         v = self.vit
         self.layer_index = int(args.layer_depth_ratio * v.last_layer_index)
@@ -173,6 +175,10 @@ class Stage1:
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
         self.extract_bsz = max(1, int(getattr(args, "extract_bsz", 128) or 128))
+        # `--dtype` is the reference's one precision switch (main_img_denoising.py:173, :257): float32 = fp32
+        # extractor AND fp32-operand fit (autocast off, its default); bfloat16 = both under bf16 autocast
+        self.extract_dtype = ("bfloat16" if str(getattr(args, "dtype", "float32")) in
+                              ("bfloat16", "bf16", "torch.bfloat16") else "float32")
         # Everything above was allocated / zero-filled on the CURRENT stream; the first writers are the
         # side streams.  One device-wide sync here orders them for good (a zero-fill must never land
         # after set_views / reset).
@@ -187,7 +193,7 @@ class Stage1:
         NCHW round trip; batches of 128 views keep every GEMM at M = 128*1408 rows."""
         with torch.no_grad():
             self.vit.features_nhwc(slot.views, self.layer_index, out=slot.features,
-                                   max_batch=self.extract_bsz)
+                                   max_batch=self.extract_bsz, dtype=self.extract_dtype)
 
     def fit(self, slot: _Slot, log_every: int = 1000) -> torch.Tensor:
         """denoise_an_image (:28-149): fresh models, the loop, then F on the original image's

@@ -47,6 +47,9 @@ _lib.register_signatures({
     "dvt_vit_gemm_bias": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "dvt_vit_layernorm": (_I, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "dvt_vit_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dvt_vit_workspace_bytes_f32": (C.c_int64, [C.POINTER(VitConfig), _I]),
+    "dvt_vit_forward_f32": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
+    "dvt_vit_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
 })
 
 
@@ -147,7 +150,12 @@ class HipViT:
     """Device-resident weights + the forward launcher."""
 
     def __init__(self, state_dict: dict, patch: int, stride: int, img_size: tuple[int, int],
-                 device: torch.device | str = "cuda"):
+                 device: torch.device | str = "cuda", dtype: str = "bfloat16"):
+        """dtype "bfloat16": bf16 operands / fp32 accumulate (the reference's `--dtype bfloat16` autocast mode);
+        "float32": fp32 operands everywhere (its default, autocast off) -- 16x less matrix throughput."""
+        if dtype not in ("bfloat16", "float32"):
+            raise _lib.DvtError(f"ViT dtype must be bfloat16 or float32, not {dtype!r}")
+        self.dtype = dtype
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DvtError("HipViT needs a HIP device; there is no CPU fallback")
@@ -170,8 +178,9 @@ class HipViT:
             self._keep.append(t)
             return t.data_ptr()
 
-        def bf16(t):
-            t = t.to(dev, torch.float32).to(torch.bfloat16).contiguous()
+        def bf16(t):  # the matrix operands: bf16, or fp32 as they are in the fp32 mode
+            t = t.to(dev, torch.float32)
+            t = (t if dtype == "float32" else t.to(torch.bfloat16)).contiguous()
             self._keep.append(t)
             return t.data_ptr()
 
@@ -201,7 +210,9 @@ class HipViT:
 
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch < batch:
-            nbytes = int(_lib.lib().dvt_vit_workspace_bytes(C.byref(self.cfg), batch))
+            size_fn = (_lib.lib().dvt_vit_workspace_bytes_f32 if self.dtype == "float32"
+                       else _lib.lib().dvt_vit_workspace_bytes)
+            nbytes = int(size_fn(C.byref(self.cfg), batch))
             self._ws = torch.zeros(nbytes, device=self.device, dtype=torch.uint8)
             self._ws_batch = batch
         return self._ws
@@ -221,12 +232,14 @@ class HipViT:
             out = torch.empty((B, cfg.grid_h, cfg.grid_w, cfg.dim), device=self.device, dtype=torch.float32)
         if not out.is_contiguous() or tuple(out.shape) != (B, cfg.grid_h, cfg.grid_w, cfg.dim):
             raise _lib.DvtError("out must be a contiguous [B, grid_h, grid_w, dim] fp32 tensor")
+        if self.dtype == "float32":
+            max_batch = min(max_batch, 32)  # fp32 activations: 32 views keep the scratch at ~1.3 GB
         ws = self._workspace(min(B, max_batch))
         L = _lib.lib()
+        fwd = L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward
         for b0 in range(0, B, max_batch):
             nb = min(max_batch, B - b0)
-            _lib.check(L.dvt_vit_forward(C.byref(cfg), C.byref(self.weights), img[b0:].data_ptr(),
-                                         out[b0:].data_ptr(), nb, n_blocks, ws.data_ptr(),
-                                         _lib.stream()), "dvt_vit_forward")
+            _lib.check(fwd(C.byref(cfg), C.byref(self.weights), img[b0:].data_ptr(), out[b0:].data_ptr(), nb,
+                           n_blocks, ws.data_ptr(), _lib.stream()), "dvt_vit_forward")
         return out
 

@@ -82,6 +82,17 @@ int dvt_vit_struct_sizes(int64_t* h_out3); /* {DvtVitConfig, DvtVitBlockWeights,
 int dvt_vit_forward(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img,
                     float* feat, int batch, int n_blocks, void* workspace, void* stream);
 
+/* The same forward with fp32 operands everywhere = the reference's DEFAULT `--dtype float32`
+ * (main_img_denoising.py:173, :299: autocast disabled).  `h_w` is a DvtVitWeights whose matrices are fp32
+ * ([out, in] row-major, patch_w [dim, k_patch] zero padded) instead of bf16.  Exact-fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate): seconds per image; it exists so that the flag means what
+ * the reference means.  Workspace: dvt_vit_workspace_bytes_f32 (no zero-fill needed).                  */
+int64_t dvt_vit_workspace_bytes_f32(const DvtVitConfig* h_cfg, int batch);
+int dvt_vit_forward_f32(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img, float* feat,
+                        int batch, int n_blocks, void* workspace, void* stream);
+/* fp32 attention on qkv [batch*s_pad, 3*heads*64] (q | k | v, head-major inside): out [batch*s_pad, heads*64] */
+int dvt_vit_attention_f32(const float* qkv, float* out, int batch, int heads, int s_pad, int n_valid, void* stream);
+
 /* ---- building blocks, exported for parity tests ---- */
 /* y[m, n] (bf16) = x[m, k] (bf16) . w[n, k]^T (bf16) + b[n]; m % 128 == n % 128 == k % 64 == 0 */
 int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, void* y, int m, int n, int k,

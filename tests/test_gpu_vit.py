@@ -201,3 +201,45 @@ def test_wrapper_api_full_depth(L):
     assert cos.min() > 0.99
     with pytest.raises(NotImplementedError):
         PretrainedViTWrapper("vit_base_patch16_224.mae", stride=16)
+
+
+@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370)])
+def test_attention_f32_vs_torch(L, batch, heads, s_pad, n_valid):
+    """fp32 attention of the `--dtype float32` extractor (exact-fp32 MFMA, P kept in the accumulator registers)"""
+    torch.manual_seed(s_pad + heads)
+    dim = heads * 64
+    q = torch.randn(batch, s_pad, heads, 64)
+    k = torch.randn(batch, s_pad, heads, 64) + torch.linspace(-1, 1, 64)  # asymmetric
+    v = torch.randn(batch, s_pad, heads, 64) * torch.linspace(0.5, 1.5, 64)
+    att = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double() * 0.125, k.double()[:, :n_valid]), -1)
+    want = torch.einsum("bhqk,bkhd->bqhd", att, v.double()[:, :n_valid]).reshape(batch, s_pad, dim)
+    qkv = torch.cat([q.reshape(batch * s_pad, dim), k.reshape(batch * s_pad, dim), v.reshape(batch * s_pad, dim)],
+                    1).contiguous().to(DEV)
+    out = torch.empty((batch * s_pad, dim), device=DEV, dtype=torch.float32)
+    assert L.dvt_vit_attention_f32(qkv.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
+    got = out.reshape(batch, s_pad, dim).cpu()
+    assert rel(got[:, :n_valid], want[:, :n_valid]) < 2e-5
+    assert bool(torch.isfinite(got).all())
+
+
+@pytest.mark.parametrize("dim,depth,img,stride,n_reg", [(128, 2, 56, 14, 0), (256, 2, 98, 7, 4), (768, 2, 518, 14, 0)])
+def test_vit_forward_f32_vs_oracle(L, dim, depth, img, stride, n_reg):
+    """`--dtype float32` (the reference default: autocast off): fp32 operands everywhere.  Against the fp32
+    oracle the result must be fp32-roundoff close, two orders tighter than the bf16 extractor."""
+    from dvt_amd.vit import HipViT, random_state_dict
+    g0 = img // 14
+    sd = random_state_dict(dim, depth, 14, (0 if n_reg else 1) + g0 * g0, seed=dim + 1, well_conditioned=True,
+                           n_reg=n_reg)
+    x = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(3))
+    want = ovit.forward_features(sd, x, 14, stride)
+    vit32 = HipViT(sd, 14, stride, (img, img), DEV, dtype="float32")
+    got = vit32.forward_features(x.to(DEV)).cpu()
+    assert got.shape == want.shape
+    err = float((got - want).norm() / want.norm())
+    cos = F.cosine_similarity(got.reshape(-1, dim), want.reshape(-1, dim), dim=-1)
+    bf = HipViT(sd, 14, stride, (img, img), DEV).forward_features(x.to(DEV)).cpu()
+    err_bf = float((bf - want).norm() / want.norm())
+    print(f"fp32 ViT dim={dim} stride={stride} reg={n_reg}: rel-L2 {err:.2e} (bf16 extractor: {err_bf:.2e}), "
+          f"cos min {cos.min():.8f}")
+    assert err < 2e-5 and cos.min() > 0.999999
+    assert err < 0.02 * err_bf
