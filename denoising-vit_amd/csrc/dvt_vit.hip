@@ -1040,7 +1040,13 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // Attention (head_dim 64): one workgroup = 128 queries of one (image, head); 8 waves x 16 queries
 // ======================================================================================
 constexpr int KV_TILE = 64;
-constexpr int VT_LD = 144;  // bytes per V^T row in LDS (128 + 16): conflict-free ds_read_b64
+// V^T tile in LDS: 64 rows (d) x 128 B, keys PERMUTED inside a row so that the 8 keys a lane feeds into one
+// MFMA k-step -- {4g .. 4g+3} and {16+4g .. 16+4g+3} of the step's 32, the order in which the S^T accumulators
+// hold P -- are 16 contiguous bytes (logical chunk 4 ks + g), and the chunk index XOR-ed with (row >> 1) & 7:
+// ONE conflict-free ds_read_b128 per fragment.  (Before: four 8-byte reads per fragment pair that the compiler
+// merged into ds_read2_b64 -- half the LDS rate, 32-bank mode, 2-way conflicts at the 144-B pitch.  PMC:
+// SQ_LDS_BANK_CONFLICT 1.9e8 cycles per launch, the LDS pipe busier than the matrix pipe.)
+constexpr int VT_LD = 128;
 
 constexpr int ATT_Q = 128;  // queries per workgroup
 
@@ -1099,7 +1105,11 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
   const bf16_t* kp0 = kbase + (size_t)sr0 * ldq + sc * 8;
   const bf16_t* vp0 = vbase + (size_t)sr0 * s_pad + sc * 8;
   const int kdo = sr0 * 128 + ((sc ^ (sr0 & 7)) << 4);
-  const int vdo = sr0 * VT_LD + sc * 16;
+  // this thread's 8 keys 8 sc .. 8 sc + 7 of V^T row sr0: k-step sc >> 2, c = sc & 3 -> half (c >> 1) of the
+  // chunks of lane groups g = 2 (c & 1) (first 4 keys) and g + 1 (last 4 keys)
+  const int vks = sc >> 2, vc = sc & 3, vsw = (sr0 >> 1) & 7;
+  const int vdo0 = sr0 * VT_LD + (((vks * 4 + 2 * (vc & 1)) ^ vsw) << 4) + (vc >> 1) * 8;
+  const int vdo1 = sr0 * VT_LD + (((vks * 4 + 2 * (vc & 1) + 1) ^ vsw) << 4) + (vc >> 1) * 8;
   uint4 kr0, vr0;
 #define ATT_LOAD(kt)                                                                   \
   do {                                                                                 \
@@ -1109,7 +1119,8 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
 #define ATT_STORE(b)                                      \
   do {                                                    \
     *reinterpret_cast<uint4*>(Ksb[b] + kdo) = kr0;        \
-    *reinterpret_cast<uint4*>(Vsb[b] + vdo) = vr0;        \
+    *reinterpret_cast<uint2*>(Vsb[b] + vdo0) = make_uint2(vr0.x, vr0.y); \
+    *reinterpret_cast<uint2*>(Vsb[b] + vdo1) = make_uint2(vr0.z, vr0.w); \
   } while (0)
   ATT_LOAD(0);
   ATT_STORE(0);
@@ -1196,14 +1207,12 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
     // ---- O^T[d][q] += V^T . P^T : A rows = d (16*mt + lc), k slots <-> keys 32*ks + 16*(j>>2) + 4*g + (j&3)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const char* vrow = Vs + (mt * 16 + lc) * VT_LD + g * 8;
-      union { bf16x8 v; uint2 h[2]; } vf0, vf1;
-      vf0.h[0] = *reinterpret_cast<const uint2*>(vrow);
-      vf0.h[1] = *reinterpret_cast<const uint2*>(vrow + 32);
-      vf1.h[0] = *reinterpret_cast<const uint2*>(vrow + 64);
-      vf1.h[1] = *reinterpret_cast<const uint2*>(vrow + 96);
-      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0.v, pf0.v, o[mt], 0, 0, 0);
-      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1.v, pf1.v, o[mt], 0, 0, 0);
+      const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+      const char* vrow = Vs + vr * VT_LD;
+      const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
+      const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf0.v, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf1.v, o[mt], 0, 0, 0);
     }
     __syncthreads();  // tile kt+1 is complete in LDS, everyone is done reading tile kt
   }

@@ -100,14 +100,14 @@ def _cat_image():
     return z, z["image_u8"]
 
 
-def _hip_features(sd, img_u8, boxes):
-    """Product pieces of the driver: normalise, render all views on the device, bf16 HIP ViT."""
+def _hip_features(sd, img_u8, boxes, dtype="bfloat16"):
+    """Product pieces of the driver: normalise, render all views on the device, HIP ViT (bf16 or fp32)."""
     from dvt_amd import views as Vw
     from dvt_amd.vit import HipViT
     x = Vw.normalize_u8(img_u8, MEAN, STD, DEV)
     views = torch.empty((len(boxes), 3, 518, 518), device=DEV)
     Vw.render_views(x, boxes, views)
-    feats = HipViT(sd, 14, 14, (518, 518), DEV).forward_features(views)
+    feats = HipViT(sd, 14, 14, (518, 518), DEV, dtype=dtype).forward_features(views)
     return views, feats
 
 
@@ -134,6 +134,13 @@ def test_end_to_end_chain(built_lib):
         eng.fit(feats_h.reshape(-1, 768), coords.reshape(-1, 2).to(DEV), idx, log_every=0)
         res[mode] = eng.infer(coords[-1].to(DEV)).cpu()
         del eng
+    # `--dtype float32` = the reference's default: fp32 extractor -> fp32-operand fit
+    _, feats_h32 = _hip_features(sd, img_u8, boxes, dtype="float32")
+    cos_vit32 = per_patch_cos(feats_h32.cpu(), feats_o)
+    eng = hip_engine_from(d_o, f_o, n_rows, T, WARM, "float32")
+    eng.fit(feats_h32.reshape(-1, 768), coords.reshape(-1, 2).to(DEV), idx, log_every=0)
+    res["fp32_chain"] = eng.infer(coords[-1].to(DEV)).cpu()
+    del eng
     eng = hip_engine_from(d_o, f_o, n_rows, T, WARM, "float32")  # HIP fit on the ORACLE's features
     eng.fit(feats_o.reshape(-1, 768).to(DEV), coords.reshape(-1, 2).to(DEV), idx, log_every=0)
     fit_only = eng.infer(coords[-1].to(DEV)).cpu()
@@ -145,6 +152,10 @@ def test_end_to_end_chain(built_lib):
     ofit.fit_image(d2, f2, feats_o, coords, idx2, num_iters=T, warmup_iters=WARM)
     floor = per_patch_cos(ofit.final_denoised_feats(d2, f2, feats_o, coords)[0], want)
     c32, c16, cfo = per_patch_cos(res["float32"], want), per_patch_cos(res["bfloat16"], want), per_patch_cos(fit_only, want)
+    cfull = per_patch_cos(res["fp32_chain"], want)
+    print(f"[end-to-end chain, --dtype float32: fp32 ViT -> fp32 fit] raw features cos min {cos_vit32.min():.8f}; "
+          f"denoised_feats vs oracle chain: mean {cfull.mean():.6f} min {cfull.min():.6f}")
+    assert cos_vit32.min() > 0.999999 and cfull.mean() >= 0.9999 and cfull.min() >= 0.999
     print(f"[end-to-end chain, {V + 1} views, {T} steps] raw ViT features HIP bf16 vs fp32 oracle: cos mean "
           f"{cos_vit.mean():.6f} min {cos_vit.min():.6f}; denoised_feats HIP chain vs oracle chain: "
           f"fp32 fit mean {c32.mean():.6f} min {c32.min():.6f}, bf16 fit mean {c16.mean():.6f} min {c16.min():.6f}; "
