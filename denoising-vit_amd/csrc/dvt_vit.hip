@@ -77,6 +77,8 @@ struct GemmBArgs {
   int dim, heads, s_pad, n_tokens;
   int n_prefix, pos_has_cls;  // EPI_EMBED: prefix rows; pos_embed row 0 belongs to cls (else patches only)
   int group;          // N tiles per L2-resident group (set by launch_gemm)
+  int mblock;         // M panels per block of the tile order (1: n fastest)
+  int nt_store;       // bf16 outputs with the non-temporal hint
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
   double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
@@ -117,7 +119,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int row, int chunk)
 struct TileMap {
   int m, n;
 };
-__device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, int group) {
+__device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, int group, int mblock = 1) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
   const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;  // bijective
   const int per_group = group * mt;
@@ -130,8 +132,18 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, in
   }
   const int rem = id - g * per_group;
   TileMap t;
-  t.m = rem / width;
-  t.n = g * group + rem % width;
+  if (mblock <= 1) {
+    t.m = rem / width;
+    t.n = g * group + rem % width;
+  } else {
+    // (m block, n, m in block): the `mblock` tiles that share a W slab are ADJACENT in the order (they start
+    // together and walk k in lock-step), and an A panel is re-touched every `mblock` ids
+    const int per_block = mblock * width;
+    const int mb = rem / per_block, r2 = rem - mb * per_block;
+    const int left = mt - mb * mblock, hb = left < mblock ? left : mblock;
+    t.n = g * group + r2 / hb;
+    t.m = mb * mblock + r2 % hb;
+  }
   return t;
 }
 
@@ -355,7 +367,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
       pk.y = pack2(a.z, a.w);
       pk.z = pack2(b.x, b.y);
       pk.w = pack2(b.z, b.w);
-      *reinterpret_cast<uint4*>(p.out + (size_t)(mb + row) * ldo + nb + c8) = pk;
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out + (size_t)(mb + row) * ldo + nb + c8);
+      const u32x4_t val = {pk.x, pk.y, pk.z, pk.w};
+      if (p.nt_store)
+        __builtin_nontemporal_store(val, dst);  // streamed output: do not displace the operand panels in L2
+      else
+        *dst = val;
     }
   }
 }
@@ -647,7 +665,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / 256, p.N / 256, p.group);
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / 256, p.N / 256, p.group, p.mblock);
   const int m0 = tm.m * 256, n0 = tm.n * 256;
 
   f32x4 acc[8][4];
@@ -775,7 +793,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / 256, p.N / 256, p.group);
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / 256, p.N / 256, p.group, p.mblock);
   const int m0 = tm.m * 256, n0 = tm.n * 256;
 
   f32x4 acc[8][4];
@@ -896,6 +914,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // tiles, fc1: 12): each 393-KB A panel is then fetched once instead of once per group (measured: GEMMs 907 ->
 // 931 TF/s in the extractor; 9600 KiB the same, 1200 KiB 900).
 int g_vit_group_bytes = 4800 * 1024;
+// M panels per block of the tile order, 0 = auto: 4 when a group has >= 6 N tiles (qkv 9, fc1 12), else 1.
+// PMC FETCH_SIZE per launch, 128 views (profiles/r02/pmc_vit/): qkv 1.57 -> 1.10 GB, fc1 1.65 -> 1.39 GB with
+// blocks of 4; the N = 768 GEMMs (3 N tiles) get WORSE with blocks (1.53 -> 1.68 GB) and keep n-fastest.
+// Time moves by +1 % only (919 -> 930 TF/s): the L2 misses are served by the memory-side cache.
+int g_vit_mblock = 0;
+// bf16 output stores with the non-temporal hint: measured no effect on time or FETCH_SIZE (kept as a knob)
+int g_vit_nt_store = 0;
 
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
@@ -922,6 +947,8 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     g = g > nt ? nt : g;
     while (g > 1 && nt % g) --g;
     a.group = g;
+    a.mblock = g_vit_mblock > 0 ? g_vit_mblock : (g >= 6 ? 4 : 1);
+    a.nt_store = g_vit_nt_store;
     if (g_vit_gemm_variant == 4)
       hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     else
@@ -1271,6 +1298,14 @@ int check_vit_cfg(const DvtVitConfig* c) {
 }  // namespace
 
 int dvt_vit_tune(int v) {
+  if (v == -50 || v == -51) {  // non-temporal bf16 output stores off / on
+    g_vit_nt_store = v == -51;
+    return 0;
+  }
+  if (v <= -100) {  // -100 - b: M panels per block of the tile order
+    g_vit_mblock = -100 - v < 0 ? 0 : -100 - v;  // 0 = auto
+    return 0;
+  }
   if (v >= 16) {  // values >= 16: L2 group budget in KiB
     g_vit_group_bytes = v * 1024;
     return 0;

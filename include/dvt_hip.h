@@ -261,7 +261,9 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
  * key 1 = ViT bf16 GEMM schedule (4, default: 256x256 8-phase ring; 0: 256x256 two-stage; 1: always
  *         128x128 two-stage; 2: 256x128 lock-step three-stage; 3: 256x128 ping-pong;
- *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation);
+ *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation;
+ *         -100 - b: b M panels per block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output
+ *         stores off / on).  No value changes results: every schedule and order is bit-identical;
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);
