@@ -200,6 +200,26 @@ struct DvtLinearOp {
   float* dx;
   int m, n, k, relu;
 };
+// General exact-fp32 GEMM (dvt_gemm_f32.hip), the building block of the stage-2 trainer.
+//   layout 0: C[M][N] = A[M][K] . B[N][K]^T   (both k-contiguous: a forward linear layer)
+//   layout 1: C[M][N] = A[M][K] . B[K][N]     (a data gradient; N % 64 == 0)
+//   layout 2: C[M][N] = A[K][M]^T . B[K][N]   (a weight gradient; M % 64 == 0, N % 64 == 0)
+// K % 64 == 0.  `accumulate`: fp32 atomic adds into C (the reduction is split over workgroups);
+// `colsum` (layout 2): colsum[m] += sum_k A[k][m] (bias gradient).  nb0 x nb1 > 1: batched over
+// (b0, b1) with element strides s?0 / s?1, no split.
+struct DvtGemmEx {
+  int layout;
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K, lda, ldb, ldc;
+  const float* bias;
+  float* colsum;
+  int accumulate;
+  int nb0, nb1;
+  long long sA0, sA1, sB0, sB1, sC0, sC1;
+};
+int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s);
 // bf16_operands: round operands to bf16 while staging (autocast semantics), fp32 otherwise
 int dvt_linear_group(const DvtLinearOp* ops, int n_ops, hipStream_t s, int bf16_operands = 0);
 int dvt_fit_prep(const DvtGridTable* tbl, const float* xy, const int32_t* ridx, const float* params,

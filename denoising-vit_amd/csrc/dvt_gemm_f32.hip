@@ -460,12 +460,11 @@ __device__ __forceinline__ void frags_f32(const float* __restrict__ S, int row, 
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_glds_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * G3_STAGE_FLOATS];  // 96 KB, one LDS object
+__device__ __forceinline__ void gemm_f32_glds_body(const GemmArgs& p, int bz, float* __restrict__ smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int kbeg = bz * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   if (kbeg >= kend) return;
   const int nk = (kend - kbeg) / BK;
@@ -526,6 +525,29 @@ __global__ __launch_bounds__(256) void gemm_f32_glds_kernel(GemmArgs p) {
     }
   }
   if (do_colsum && tid < 64 && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_glds_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * G3_STAGE_FLOATS];  // 96 KB, one LDS object
+  gemm_f32_glds_body<A_KC, B_KC>(p, blockIdx.z, smem);
+}
+
+// Batched form (stage-2 attention: one problem per (image, head)): blockIdx.z = b0 * nb1 + b1 selects
+// the operand bases, no k-split.
+struct BatchDims {
+  int nb1;
+  long long sA0, sA1, sB0, sB1, sC0, sC1;
+};
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_glds_batched_kernel(GemmArgs p, BatchDims d) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * G3_STAGE_FLOATS];
+  const int b0 = blockIdx.z / d.nb1, b1 = blockIdx.z - b0 * d.nb1;
+  GemmArgs q = p;
+  q.A = p.A + b0 * d.sA0 + b1 * d.sA1;
+  q.B = p.B + b0 * d.sB0 + b1 * d.sB1;
+  q.C = p.C + b0 * d.sC0 + b1 * d.sC1;
+  gemm_f32_glds_body<A_KC, B_KC>(q, 0, smem);
 }
 
 int g_f32_glds = 1;  // 0: always the register-staged kernel
@@ -719,6 +741,56 @@ extern "C" int dvt_tune_set(int key, int value) {
   if (key == 2) return dvt_grid_tune(value);
   if (key == 3) return dvt_adam_tune(value);
   return DVT_E_BADARG;
+}
+
+// General exact-fp32 GEMM for the stage-2 trainer (dvt_stage2.hip): any of the three operand layouts with
+// explicit leading dimensions, optional (image, head) batching, optional atomic accumulation with a k-split.
+// Always the 3-stage LDS-DMA kernel (there is no extractor to share the CUs with in stage 2), so the shapes
+// must be whole 64-tiles where that kernel needs them (checked).
+int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s) {
+  if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0) return DVT_E_BADARG;
+  GemmArgs a{};
+  a.A = g->A; a.B = g->B; a.C = g->C;
+  a.M = g->M; a.N = g->N; a.K = g->K;
+  a.lda = g->lda; a.ldb = g->ldb; a.ldc = g->ldc;
+  a.bias = g->bias;
+  a.colsum = g->layout == 2 ? g->colsum : nullptr;
+  a.atomic = g->accumulate;
+  if (a.K % BK) return DVT_E_BADARG;
+  const bool a_kc = g->layout != 2, b_kc = g->layout == 0;
+  if ((!a_kc && (a.M % 64)) || (!b_kc && (a.N % 64)) || (a.lda & 3) || (a.ldb & 3)) return DVT_E_BADARG;
+  const int nb = (g->nb0 > 0 ? g->nb0 : 1) * (g->nb1 > 0 ? g->nb1 : 1);
+  int splits = 1;
+  a.kchunk = a.K;
+  if (g->accumulate && nb == 1) {  // split the reduction so that ~1024 workgroups exist (one atomic per split)
+    const int tiles = dvt_cdiv(a.M, 64) * dvt_cdiv(a.N, 64), ktiles = a.K / BK;
+    splits = dvt_cdiv(1024, tiles);
+    if (splits > ktiles / 4) splits = ktiles / 4;
+    if (splits < 1) splits = 1;
+    a.kchunk = dvt_cdiv(ktiles, splits) * BK;
+    splits = dvt_cdiv(a.K, a.kchunk);
+  }
+  if (nb > 65535 || splits > 65535) return DVT_E_BADARG;
+  dim3 grid(dvt_cdiv(a.N, 64), dvt_cdiv(a.M, 64), nb > 1 ? nb : splits);
+  DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K * nb);
+  if (nb > 1) {
+    BatchDims d{g->nb1 > 0 ? g->nb1 : 1, g->sA0, g->sA1, g->sB0, g->sB1, g->sC0, g->sC1};
+    if (g->layout == 0)
+      hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<true, true>), grid, dim3(256), 0, s, a, d);
+    else if (g->layout == 1)
+      hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<true, false>), grid, dim3(256), 0, s, a, d);
+    else
+      hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<false, false>), grid, dim3(256), 0, s, a, d);
+  } else {
+    if (g->layout == 0)
+      hipLaunchKernelGGL((gemm_f32_glds_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else if (g->layout == 1)
+      hipLaunchKernelGGL((gemm_f32_glds_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_f32_glds_kernel<false, false>), grid, dim3(256), 0, s, a);
+  }
+  DVT_CHECK_LAUNCH();
+  return 0;
 }
 
 // Forward linear for LARGE m (the fp32 extractor: m = views x 1408 tokens): always the 3-stage LDS-DMA kernel
