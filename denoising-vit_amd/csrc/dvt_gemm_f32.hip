@@ -459,7 +459,10 @@ __device__ __forceinline__ void frags_f32(const float* __restrict__ S, int row, 
   }
 }
 
-template <bool A_KC, bool B_KC>
+// NS = 3 stages (96 KB, one workgroup per CU, loads two k-tiles ahead) or 2 stages (64 KB, TWO workgroups per CU,
+// loads one k-tile ahead): with one workgroup per CU every k-tile exposes its barrier + fragment-read latency
+// (the MFMA pipe idles ~45 % of the time); a second resident workgroup fills those gaps.
+template <bool A_KC, bool B_KC, int NS = 3>
 __device__ __forceinline__ void gemm_f32_glds_body(const GemmArgs& p, int bz, float* __restrict__ smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -477,21 +480,21 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmArgs& p, int bz, fl
 
 #define G3_ISSUE(kt)                                                                          \
   do {                                                                                        \
-    float* st_ = smem + ((kt) % 3) * G3_STAGE_FLOATS;                                         \
+    float* st_ = smem + ((kt) % NS) * G3_STAGE_FLOATS;                                        \
     stage_f32<A_KC>(p.A, p.lda, m0, p.M, kbeg + (kt) * BK, st_, wave, lane);                  \
     stage_f32<B_KC>(p.B, p.ldb, n0, p.N, kbeg + (kt) * BK, st_ + 64 * BK, wave, lane);        \
   } while (0)
   G3_ISSUE(0);
-  if (nk > 1) G3_ISSUE(1);
+  if (NS == 3 && nk > 1) G3_ISSUE(1);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk)
+    if (NS == 3 && kt + 1 < nk)
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < nk) G3_ISSUE(kt + 2);
-    const float* As = smem + (kt % 3) * G3_STAGE_FLOATS;
+    if (kt + NS - 1 < nk) G3_ISSUE(kt + NS - 1);
+    const float* As = smem + (kt % NS) * G3_STAGE_FLOATS;
     const float* Bs = As + 64 * BK;
     const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
     float fa[BK / 2], fb[BK / 2];
@@ -527,10 +530,10 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmArgs& p, int bz, fl
   if (do_colsum && tid < 64 && m0 + tid < p.M) atomic_add_f32(p.colsum + m0 + tid, csum);
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int NS = 3>
 __global__ __launch_bounds__(256) void gemm_f32_glds_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * G3_STAGE_FLOATS];  // 96 KB, one LDS object
-  gemm_f32_glds_body<A_KC, B_KC>(p, blockIdx.z, smem);
+  __shared__ __attribute__((aligned(16))) float smem[NS * G3_STAGE_FLOATS];  // 96 / 64 KB, one LDS object
+  gemm_f32_glds_body<A_KC, B_KC, NS>(p, blockIdx.z, smem);
 }
 
 // Batched form (stage-2 attention: one problem per (image, head)): blockIdx.z = b0 * nb1 + b1 selects
@@ -539,18 +542,34 @@ struct BatchDims {
   int nb1;
   long long sA0, sA1, sB0, sB1, sC0, sC1;
 };
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int NS = 3>
 __global__ __launch_bounds__(256) void gemm_f32_glds_batched_kernel(GemmArgs p, BatchDims d) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * G3_STAGE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[NS * G3_STAGE_FLOATS];
   const int b0 = blockIdx.z / d.nb1, b1 = blockIdx.z - b0 * d.nb1;
   GemmArgs q = p;
   q.A = p.A + b0 * d.sA0 + b1 * d.sA1;
   q.B = p.B + b0 * d.sB0 + b1 * d.sB1;
   q.C = p.C + b0 * d.sC0 + b1 * d.sC1;
-  gemm_f32_glds_body<A_KC, B_KC>(q, 0, smem);
+  gemm_f32_glds_body<A_KC, B_KC, NS>(q, 0, smem);
+}
+
+// Single-k-tile problems (q k^T and dO v^T of the stage-2 attention: K = 64) gain nothing from the 3-stage ring, and
+// its 96 KB of LDS hold a CU to ONE workgroup whose only tile is pure load -> MFMA -> store latency (measured:
+// 27 TF/s).  The register-staged body needs 35 KB: four workgroups per CU overlap each other's latencies.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_batched_small_k_kernel(GemmArgs p, BatchDims d) {
+  __shared__ __attribute__((aligned(16))) float As[Tile<A_KC, 64, 256, 64>::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[Tile<B_KC, 64, 256, 64>::LDS_FLOATS];
+  const int b0 = blockIdx.z / d.nb1, b1 = blockIdx.z - b0 * d.nb1;
+  GemmArgs q = p;
+  q.A = p.A + b0 * d.sA0 + b1 * d.sA1;
+  q.B = p.B + b0 * d.sB0 + b1 * d.sB1;
+  q.C = p.C + b0 * d.sC0 + b1 * d.sC1;
+  gemm_f32_body<A_KC, B_KC, 2, 2, 64>(q, blockIdx.x, blockIdx.y, 0, As, Bs);
 }
 
 int g_f32_glds = 1;  // 0: always the register-staged kernel
+int g_f32_ex_stages = 2;  // LDS stages of the stage-2 GEMMs (dvt_gemm_f32_ex): 2 or 3
 extern int g_cfg_override;
 
 // eligibility of the LDS-DMA kernel: whole k-tiles, and row-contiguous operands whose 64-wide
@@ -721,7 +740,10 @@ extern "C" int dvt_tune_set(int key, int value) {
     return 0;
   }
   if (key == 4) {
-    g_f32_glds = value;
+    if (value == 2 || value == 3)
+      g_f32_ex_stages = value;  // stage-2 GEMMs: LDS stages
+    else
+      g_f32_glds = value;
     return 0;
   }
   if (key == 5) {
@@ -773,22 +795,32 @@ int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s) {
   if (nb > 65535 || splits > 65535) return DVT_E_BADARG;
   dim3 grid(dvt_cdiv(a.N, 64), dvt_cdiv(a.M, 64), nb > 1 ? nb : splits);
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K * nb);
-  if (nb > 1) {
-    BatchDims d{g->nb1 > 0 ? g->nb1 : 1, g->sA0, g->sA1, g->sB0, g->sB1, g->sC0, g->sC1};
-    if (g->layout == 0)
-      hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<true, true>), grid, dim3(256), 0, s, a, d);
-    else if (g->layout == 1)
-      hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<true, false>), grid, dim3(256), 0, s, a, d);
-    else
-      hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<false, false>), grid, dim3(256), 0, s, a, d);
-  } else {
-    if (g->layout == 0)
-      hipLaunchKernelGGL((gemm_f32_glds_kernel<true, true>), grid, dim3(256), 0, s, a);
-    else if (g->layout == 1)
-      hipLaunchKernelGGL((gemm_f32_glds_kernel<true, false>), grid, dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((gemm_f32_glds_kernel<false, false>), grid, dim3(256), 0, s, a);
-  }
+#define EX_LAUNCH(NS)                                                                                     \
+  do {                                                                                                    \
+    if (nb > 1) {                                                                                         \
+      BatchDims d{g->nb1 > 0 ? g->nb1 : 1, g->sA0, g->sA1, g->sB0, g->sB1, g->sC0, g->sC1};               \
+      if (a.K <= BK && g->layout == 0)                                                                    \
+        hipLaunchKernelGGL((gemm_f32_batched_small_k_kernel<true, true>), grid, dim3(256), 0, s, a, d);   \
+      else if (g->layout == 0)                                                                            \
+        hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<true, true, NS>), grid, dim3(256), 0, s, a, d);  \
+      else if (g->layout == 1)                                                                            \
+        hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<true, false, NS>), grid, dim3(256), 0, s, a, d); \
+      else                                                                                                \
+        hipLaunchKernelGGL((gemm_f32_glds_batched_kernel<false, false, NS>), grid, dim3(256), 0, s, a, d);\
+    } else {                                                                                              \
+      if (g->layout == 0)                                                                                 \
+        hipLaunchKernelGGL((gemm_f32_glds_kernel<true, true, NS>), grid, dim3(256), 0, s, a);             \
+      else if (g->layout == 1)                                                                            \
+        hipLaunchKernelGGL((gemm_f32_glds_kernel<true, false, NS>), grid, dim3(256), 0, s, a);            \
+      else                                                                                                \
+        hipLaunchKernelGGL((gemm_f32_glds_kernel<false, false, NS>), grid, dim3(256), 0, s, a);           \
+    }                                                                                                     \
+  } while (0)
+  if (g_f32_ex_stages == 2)
+    EX_LAUNCH(2);
+  else
+    EX_LAUNCH(3);
+#undef EX_LAUNCH
   DVT_CHECK_LAUNCH();
   return 0;
 }
