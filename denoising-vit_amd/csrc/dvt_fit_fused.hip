@@ -594,7 +594,8 @@ bool dvt_fit_fused_shapes_ok(const DvtFitConfig* c) {
   const int C = c->feat_dim;
   if (C != 384 && C != 768 && C != 1024) return false;
   if (c->hidden != C / 2 || c->res_hidden != C / 4) return false;
-  if (c->batch % 128 || c->batch <= 0) return false;  // whole MFMA k-steps per workgroup pair; 4 k-steps per wgrad quarter
+  // the weight-gradient kernel splits the batch into 4 quarters of whole 4-deep prefetch groups of 32-row k-steps
+  if (c->batch % 512 || c->batch <= 0) return false;
   return c->lattice <= 8192 && c->batch <= 65535;  // G gradient through Adam's row lists
 }
 

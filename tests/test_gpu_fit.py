@@ -283,3 +283,32 @@ def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
     # the bulk must be tight, single elements may differ by a few lr
     assert float(d.mean()) < 2e-5 and float(d.max()) < 0.05
     assert per_patch_cos(o1, o0).min() > 0.9999
+
+
+@pytest.mark.parametrize("B", [256, 384, 512, 1536])
+def test_bf16_fit_any_batch_size(built_lib, B):
+    """The fused row / backward kernels need the batch in whole 512-row groups; every other `--pixel_bsz` must take
+    the layer-by-layer launches instead of failing (the smoke run of round 2 hit DVT_E_BADARG at B = 256)."""
+    from dvt_amd.fit import FitEngine, FitSettings
+    C, V, H = 384, 4, 12
+    feats, xy = synthetic_image(V, H, H, C, seed=B)
+    n_rows, T = V * H * H, 8
+    s = FitSettings(feat_dim=C, noise_map_height=H, noise_map_width=H, num_iters=T, warmup_iters=2, pixel_bsz=B,
+                    mlp_dtype="bfloat16")
+    idx = np.random.RandomState(B).randint(0, n_rows, (T, B)).astype(np.int32)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    outs = []
+    try:
+        for fused in (1, 0):
+            assert built_lib.dvt_tune_set(6, fused) == 0
+            eng = FitEngine(s, n_rows, DEV)
+            eng.reset(torch.Generator(device=DEV).manual_seed(1))
+            eng.fit(f, c, idx, log_every=1)
+            torch.cuda.synchronize()
+            outs.append((eng.loss_log(), eng.infer(xy[-1].to(DEV)).cpu()))
+            del eng
+    finally:
+        built_lib.dvt_tune_set(6, 1)
+    for step in range(T):
+        assert abs(outs[0][0][step]["loss"] - outs[1][0][step]["loss"]) <= 2e-4 * abs(outs[1][0][step]["loss"])
+    assert per_patch_cos(outs[0][1], outs[1][1]).min() > 0.9999
