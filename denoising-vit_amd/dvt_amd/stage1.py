@@ -95,7 +95,7 @@ def work_list(args) -> list[str]:
     return names[args.start_idx: args.start_idx + args.num_imgs]
 
 
-def _cu_masked_stream(device, keep_per_32: int):
+def _cu_masked_stream(device, keep_per_32: int, first: int = 0):
     """A HIP stream whose kernels may only run on `keep_per_32` of every 32 CUs
     (hipExtStreamCreateWithCUMask), wrapped for torch.  Leaves a few CUs permanently free of the
     extractor's long-running workgroups so that the fit's short dependent launches start at once."""
@@ -103,7 +103,7 @@ def _cu_masked_stream(device, keep_per_32: int):
     hip = ctypes.CDLL("libamdhip64.so")
     n_cu = torch.cuda.get_device_properties(device).multi_processor_count
     words = (n_cu + 31) // 32
-    mask = (ctypes.c_uint32 * words)(*([(1 << keep_per_32) - 1] * words))
+    mask = (ctypes.c_uint32 * words)(*([(((1 << keep_per_32) - 1) << first) & 0xFFFFFFFF] * words))
     stream = ctypes.c_void_p()
     with torch.cuda.device(device):
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(words), mask)
@@ -169,9 +169,14 @@ class Stage1:
         self.engine = self.engines[0]
         self.gen = torch.Generator(device=dev).manual_seed(args.seed)
         if depth > 1:
-            self.s_vit = (torch.cuda.Stream(device=dev) if vit_cus_per_32 >= 32
+            # Neither stream is favoured by the queue arbiter.  Measured (profiles/r02/r02h_*): fit favoured 2.28 images/s
+            # (extractor GEMMs 866 us), extractor favoured 2.15 (GEMMs 629 us, but the fit starves), neither 2.31.
+            prio = os.environ.get("DVT_STREAM_PRIO", "none")
+            self.s_vit = (torch.cuda.Stream(device=dev, priority=-1 if prio == "vit" else 0) if vit_cus_per_32 >= 32
                           else _cu_masked_stream(dev, vit_cus_per_32))
-            self.s_fit = torch.cuda.Stream(device=dev, priority=-1)
+            fit_cus = int(os.environ.get("DVT_FIT_CUS", "32"))  # experiment: confine the fit to the LAST n of every 32 CUs
+            self.s_fit = (torch.cuda.Stream(device=dev, priority=-1 if prio == "fit" else 0) if fit_cus >= 32
+                          else _cu_masked_stream(dev, fit_cus, 32 - fit_cus))
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
         self.extract_bsz = max(1, int(getattr(args, "extract_bsz", 128) or 128))
