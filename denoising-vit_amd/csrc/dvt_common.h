@@ -115,6 +115,9 @@ struct DvtFusedFit {  // per fit: inputs, arena, shadow weights and what the row
   const int32_t* g_offs;   // this step's row lists of the G gradient (DvtAdamRowGather), phase 1 only
   const uint16_t* g_perm;
   uint32_t* touched;       // bitmap of grid entries with a gradient (grid backward -> Adam)
+  const uint32_t* gs_keys; // this step's sorted grid-corner lists (dvt_grid_dev.h: GridSortedPtrs), or nullptr
+  const uint16_t* gs_pay;
+  const float* gs_w;
 };
 #if defined(__HIPCC__)
 typedef __bf16 dvt_hwbf16x2 __attribute__((ext_vector_type(2)));

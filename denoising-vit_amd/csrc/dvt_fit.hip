@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include "dvt_common.h"
+#include "dvt_grid_dev.h"
 
 int g_adam_pingpong = 1;  // dvt_tune_set(8, 0): always sweep forward (A/B timing)
 
@@ -28,7 +29,12 @@ struct Work {
   uint16_t* g_perm;  // [num_iters, batch]
   uint16_t* shadow;  // bf16 shadow copies of the MLP weights for the fused row kernel (nullptr: shapes not eligible)
   uint16_t* T;       // transposed bf16 operand copies for the weight-gradient kernel (with `shadow`)
+  // sorted grid-corner lists of the current chunk of GS_CHUNK steps (dvt_grid_dev.h; nullptr: atomics path)
+  uint32_t* gs_keys;
+  uint16_t* gs_pay;
+  float* gs_w;
 };
+constexpr int GS_CHUNK = 128;  // steps per sort launch: 168 MB of lists per fit at batch 2048, 16 levels
 
 bool row_lists_ok(const DvtFitConfig* c) { return c->lattice <= 8192 && c->batch <= 65535; }
 
@@ -64,14 +70,25 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
   }
   t.shadow = nullptr;
   t.T = nullptr;
+  bool fused_bufs = false;  // (pointers are all null in the size query: never test them here)
   if (dvt_fit_fused_shapes_ok(c)) {
     DvtShadowLayout L;
     if (dvt_shadow_layout(c, &L) == 0) {
+      fused_bufs = true;
       t.shadow = reinterpret_cast<uint16_t*>(take((L.total + 1) / 2));
       DvtTLayout TL;
       dvt_t_layout(c, &TL);
       t.T = reinterpret_cast<uint16_t*>(take((TL.total + 1) / 2));
     }
+  }
+  t.gs_keys = nullptr;
+  t.gs_pay = nullptr;
+  t.gs_w = nullptr;
+  if (fused_bufs && dvt_grid_sorted_ok(&c->grid, c->batch)) {
+    const int64_t per_step = (int64_t)c->grid.n_levels * 4 * B;
+    t.gs_keys = reinterpret_cast<uint32_t*>(take(per_step * GS_CHUNK));
+    t.gs_w = take(per_step * GS_CHUNK);
+    t.gs_pay = reinterpret_cast<uint16_t*>(take((per_step * GS_CHUNK + 1) / 2));
   }
   if (w) *w = t;
   return o;
@@ -160,7 +177,7 @@ int check_bufs(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin, in
 // launch covers all k fits (blockIdx.y = fit; the grouped GEMM launch simply carries k x the
 // problems).  k = 1 is the reference's per-image loop.
 int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const Work* ws, int step,
-             hipStream_t s) {
+             int gs_local, hipStream_t s) {  // gs_local: index of `step` inside the current chunk of sorted grid lists, or -1
   const int B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
   const int E = c->grid.n_levels * c->grid.n_features;
   const bool phase2 = step > c->switch_step;
@@ -222,8 +239,11 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     for (int f = 0; f < k; ++f) {
       const Work& w = ws[f];
       shadow[f] = w.shadow;
+      const size_t gso = (size_t)gs_local * c->grid.n_levels * 4 * B;
+      const bool gs = w.gs_keys != nullptr && gs_local >= 0;
       ff[f] = DvtFusedFit{xy[f], ridx[f], feat[f], P[f], w.shadow, w.T, w.F, w.Hres, w.dF, w.denc, w.rows, Gd[f],
-                          w.g_offs + (size_t)step * (c->lattice + 1), w.g_perm + (size_t)step * B, touched[f]};
+                          w.g_offs + (size_t)step * (c->lattice + 1), w.g_perm + (size_t)step * B, touched[f],
+                          gs ? w.gs_keys + gso : nullptr, gs ? w.gs_pay + gso : nullptr, gs ? w.gs_w + gso : nullptr};
     }
     DVT_TRY(dvt_fit_rows_k(c, &shl, k, ff, use_res, s));
   } else {
@@ -399,8 +419,31 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
     rc = dvt_shadow_build_k(&L, k, pp, ss, 0, c->arena_floats, (hipStream_t)stream);
     if (rc) return rc;
   }
+  const bool sorted_lists = dvt_fit_fused_ok(c) && w[0].shadow != nullptr && w[0].g_offs != nullptr &&
+                            w[0].gs_keys != nullptr;
   for (int step = step_begin; step < step_end; ++step) {
-    int rc = fit_step(c, k, bufs, w, step, (hipStream_t)stream);
+    int gs_local = -1;
+    if (sorted_lists) {
+      gs_local = (step - step_begin) % GS_CHUNK;
+      if (gs_local == 0) {  // sorted grid-corner lists of the next GS_CHUNK steps, from the resident index stream
+        const int steps = step_end - step < GS_CHUNK ? step_end - step : GS_CHUNK;
+        const float* xy[DVT_FIT_BATCH_MAX];
+        const int32_t* ridx[DVT_FIT_BATCH_MAX];
+        uint32_t* keys[DVT_FIT_BATCH_MAX];
+        uint16_t* pay[DVT_FIT_BATCH_MAX];
+        float* ww[DVT_FIT_BATCH_MAX];
+        for (int j = 0; j < k; ++j) {
+          xy[j] = bufs[j]->xy;
+          ridx[j] = bufs[j]->idx + (size_t)step * c->batch;
+          keys[j] = w[j].gs_keys;
+          pay[j] = w[j].gs_pay;
+          ww[j] = w[j].gs_w;
+        }
+        int rc = dvt_grid_sort_k(&c->grid, k, xy, ridx, c->batch, steps, keys, pay, ww, (hipStream_t)stream);
+        if (rc) return rc;
+      }
+    }
+    int rc = fit_step(c, k, bufs, w, step, gs_local, (hipStream_t)stream);
     if (rc) return rc;
   }
   return 0;

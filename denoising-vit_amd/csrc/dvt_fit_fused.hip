@@ -507,6 +507,7 @@ struct BackwardArgs {
   DvtGridTable T;
   GridBwdPlan plan;
   GridBwdPtrs gp;
+  GridSortedPtrs gs;  // gs.nt > 0: gather from the sorted lists instead of scattering with atomics
   int n, grid_blocks_per_fit, k, wg_blocks;
   WgradArgs w;
 };
@@ -516,8 +517,13 @@ __global__ __launch_bounds__(1024) void fit_backward_kernel(BackwardArgs a) {
   // it the other half would only start when it drains (measured: the sum of the two, not the maximum)
   if ((int)blockIdx.x >= a.wg_blocks) {
     const int b = (int)blockIdx.x - a.wg_blocks;
-    grid_bwd_body<256>(a.T, a.plan, a.gp, a.n, b % a.grid_blocks_per_fit, b / a.grid_blocks_per_fit, smem,
-                       reinterpret_cast<uint32_t*>(smem + 256 * 8));
+    const int fy = b / a.grid_blocks_per_fit, bx = b - fy * a.grid_blocks_per_fit;
+    if (a.gs.nt > 0) {
+      const int parts = a.gs.nt >> 10;
+      grid_gather_body(a.T, a.gs, fy, bx / parts, bx % parts, a.gp.d_enc[fy], a.gp.d_params[fy], a.gp.touched[fy]);
+      return;
+    }
+    grid_bwd_body<256>(a.T, a.plan, a.gp, a.n, bx, fy, smem, reinterpret_cast<uint32_t*>(smem + 256 * 8));
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -584,6 +590,8 @@ int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* para
 }
 
 int g_fit_fused_enable = 1;  // dvt_tune_set(6, 0): the unfused launch sequence (same results, A/B timing + parity)
+int g_fit_sorted_grid = 1;  // 0: the fused step scatters the grid gradient with atomics (round-2a path)
+
 bool dvt_fit_fused_ok(const DvtFitConfig* c) {
   return g_fit_fused_enable && c && c->mlp_bf16 && dvt_fit_fused_shapes_ok(c);
 }
@@ -696,6 +704,17 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
   g_grid_lds_chunk = saved_chunk;
   const long long direct_threads = (long long)c->batch * (c->grid.n_levels - ba.plan.first_direct_level) * 8;
   ba.grid_blocks_per_fit = ba.plan.n_lds_blocks + dvt_cdiv(direct_threads, 1024);
+  bool sorted = g_fit_sorted_grid && dvt_grid_sorted_ok(&c->grid, c->batch);
+  for (int f = 0; f < k; ++f) sorted = sorted && fits[f].gs_keys && fits[f].gs_pay && fits[f].gs_w;
+  if (sorted) {
+    ba.gs.nt = 4 * c->batch;
+    ba.grid_blocks_per_fit = c->grid.n_levels * (ba.gs.nt / 1024);
+    for (int f = 0; f < k; ++f) {
+      ba.gs.keys[f] = fits[f].gs_keys;
+      ba.gs.pay[f] = fits[f].gs_pay;
+      ba.gs.w[f] = fits[f].gs_w;
+    }
+  }
   for (int f = 0; f < k; ++f) {
     ba.gp.xy[f] = reinterpret_cast<const float2*>(fits[f].xy);
     ba.gp.ridx[f] = fits[f].ridx;

@@ -732,6 +732,7 @@ namespace {
 extern int g_cfg_override;
 }
 extern int g_fit_fused_enable;
+extern int g_fit_sorted_grid;
 extern int g_adam_pingpong;
 
 extern "C" int dvt_tune_set(int key, int value) {
@@ -757,6 +758,10 @@ extern "C" int dvt_tune_set(int key, int value) {
   }
   if (key == 6) {
     g_fit_fused_enable = value != 0;
+    return 0;
+  }
+  if (key == 7) {
+    g_fit_sorted_grid = value != 0;
     return 0;
   }
   if (key == 1) return dvt_vit_tune(value);

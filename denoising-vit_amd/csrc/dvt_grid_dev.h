@@ -153,5 +153,71 @@ __device__ __forceinline__ void grid_bwd_body(const DvtGridTable& T, const GridB
 }
 
 
+// ---- sorted-list backward (fused fit step) ----------------------------------------------------------------
+// The coordinates and the whole index stream of a fit are resident before its first step, so WHICH grid entries
+// step t touches -- and with which interpolation weights -- is known in advance.  grid_sort_kernel (dvt_grid.hip)
+// writes, per (step, level), the 4 * batch (sample, corner) pairs sorted by entry index: keys / pay / w
+// [step][level][4 * batch].  The backward pass then needs no scatter: thread i takes sorted pair i, forms
+// w_i * d_enc[sample_i][level] (8 features), a segmented scan over equal keys inside the wave sums each entry's
+// contributions, and the LAST lane of a segment stores the 32-byte gradient -- a plain store when the segment lies
+// inside one wave (always, on the fine levels), fp32 atomics only for the few segments a wave boundary cuts.
+// Replaces ~1 M memory-side atomics per step (global_atomic_add_f32 / ds_add_f32) by ~60 k 32-byte stores.
+struct GridSortedPtrs {
+  const uint32_t* keys[DVT_FIT_BATCH_MAX];  // this step: [level][nt] entry index inside the level, ascending
+  const uint16_t* pay[DVT_FIT_BATCH_MAX];   //            (sample << 2) | corner
+  const float* w[DVT_FIT_BATCH_MAX];        //            bilinear weight of that corner
+  int nt;                                   // 4 * batch
+};
+
+// One 1024-thread block = 1024 consecutive sorted pairs of level `l` of fit `fy` (part `part` of nt / 1024).
+__device__ __forceinline__ void grid_gather_body(const DvtGridTable& T, const GridSortedPtrs& q, int fy, int l, int part,
+                                                 const float* __restrict__ d_enc, float* __restrict__ d_params,
+                                                 uint32_t* __restrict__ touched) {
+  const int lane = threadIdx.x & 63;
+  const int u = part * 1024 + threadIdx.x;
+  const size_t base = (size_t)l * q.nt;
+  const uint32_t* __restrict__ keys = q.keys[fy] + base;
+  const uint32_t key = keys[u];
+  const uint32_t prev = u > 0 ? keys[u - 1] : 0xffffffffu;
+  const uint32_t next = u + 1 < q.nt ? keys[u + 1] : 0xffffffffu;
+  const uint32_t pay = q.pay[fy][base + u];
+  const float wgt = q.w[fy][base + u];
+  const float4* gp = reinterpret_cast<const float4*>(d_enc + ((size_t)(pay >> 2) * T.n_levels + l) * 8);
+  const float4 g0 = gp[0], g1 = gp[1];
+  float c[8] = {wgt * g0.x, wgt * g0.y, wgt * g0.z, wgt * g0.w, wgt * g1.x, wgt * g1.y, wgt * g1.z, wgt * g1.w};
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t ok = __shfl_up(key, d, 64);
+    const bool take = lane >= d && ok == key;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const float o = __shfl_up(c[f], d, 64);
+      if (take) c[f] += o;
+    }
+  }
+  // all 64 lanes are still active here (nt % 1024 == 0): lane 0's key and predecessor tell whether the wave's first
+  // segment began in the previous wave
+  const uint32_t first_key = __builtin_amdgcn_readfirstlane(key), first_prev = __builtin_amdgcn_readfirstlane(prev);
+  const bool ends = key != next;
+  if (!(ends || lane == 63)) return;
+  const bool began_before = key == first_key && first_prev == first_key;
+  const uint32_t a = T.offset[l] + key;
+  float* dst = d_params + (size_t)a * 8;
+  if (ends && !began_before) {
+    reinterpret_cast<float4*>(dst)[0] = make_float4(c[0], c[1], c[2], c[3]);
+    reinterpret_cast<float4*>(dst)[1] = make_float4(c[4], c[5], c[6], c[7]);
+  } else {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) atomic_add_f32(dst + f, c[f]);
+  }
+  if (ends && touched != nullptr)
+    __hip_atomic_fetch_or(touched + (a >> 5), 1u << (a & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+bool dvt_grid_sorted_ok(const DvtGridTable* T, int n);
+// lists of `steps` consecutive steps of k fits: ridx[f] points at the first of those steps' index rows ([steps][n])
+int dvt_grid_sort_k(const DvtGridTable* T, int k, const float* const* xy, const int32_t* const* ridx, int n, int steps,
+                    uint32_t* const* keys, uint16_t* const* pay, float* const* w, hipStream_t s);
+
 void dvt_grid_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan);
 extern int g_grid_lds_chunk;
