@@ -138,6 +138,93 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
   }
 }
 
+// ==========================================================================================================
+// Lazy-exact Adam for the fine hash-grid levels.
+//
+// 98 % of the arena are grid entries of the levels with >= 64 k entries, and a step touches at most 4 * batch of
+// them: an entry of the finest levels is sampled once in ~128 steps.  The reference nevertheless steps EVERY
+// parameter EVERY iteration (dense Adam with coupled weight decay: g = wd * p even where the data gradient is
+// zero, quirk Q2) -- 515 MB of HBM traffic per step, 55 % of the fit.  But an untouched entry's update depends on
+// nothing except its own (p, m, v) and the step's learning rate, so it can be applied LATER, as long as it is
+// applied before anyone reads p: per entry a 16-bit `done` counter says how many steps are in; the gradient a
+// step wrote stays in the gradient arena as that entry's PENDING step.  Before the row kernel of step t the
+// catch-up kernel visits exactly the entries step t will read (their sorted list is known in advance,
+// dvt_grid_dev.h): apply the pending step `done` with its gradient, then steps done+1 .. t-1 with g = 0 -- the
+// same arithmetic in the same order as the dense sweep -- store, clear the gradient, done = t.  At the end of a
+// dvt_fit_run call one sweep brings every entry to the last step, so the arena is exact at every call boundary.
+// Work is conserved (every entry-step is still executed once), HBM traffic is not: ~12 MB instead of ~470 MB per
+// step; the kernel is VALU-bound.  v_rcp_f32 / v_sqrt_f32 (1 ulp) replace the IEEE division / square root of the
+// dense kernel in the replay loop: 2 instead of ~25 instructions per element-step.
+// 8 lanes per entry (one feature each): the lanes of an entry share the trip count.
+// ==========================================================================================================
+constexpr int LAZY_TAB = 2048;  // most recent steps whose (neg_step, 1 / bc2s) sit in LDS; older ones come from L2
+struct LazyArgs {
+  float* P[DVT_FIT_BATCH_MAX];
+  float* M[DVT_FIT_BATCH_MAX];
+  float* V[DVT_FIT_BATCH_MAX];
+  float* G[DVT_FIT_BATCH_MAX];
+  uint16_t* done[DVT_FIT_BATCH_MAX];       // [n_entries - e0], steps already applied (relative to the call's first step)
+  const uint32_t* ukeys[DVT_FIT_BATCH_MAX];  // catch-up: this step's distinct entries [L][nt] (absolute, ascending)
+  const int32_t* ucount[DVT_FIT_BATCH_MAX];  //           [L]
+  const float* neg_step;   // [steps of the call]  -(lr / bias_correction1)
+  const float* inv_bc2s;   //                      1 / sqrt(bias_correction2)
+  uint32_t e0, n_entries;  // lazy entries: [e0, n_entries)
+  int nt, l0;              // catch-up: list pitch, first level that has lazy entries
+  int target;              // bring entries to `target` applied steps
+  float one_m_b1, beta2, one_m_b2, eps, wd;
+};
+
+__device__ __forceinline__ void lazy_replay(const LazyArgs& a, const float* tab_ns, const float* tab_ib, int tab0,
+                                            float& p, float& m, float& v, float g, int from, int to) {
+  for (int s = from; s < to; ++s) {
+    const float ns = s >= tab0 ? tab_ns[s - tab0] : a.neg_step[s];
+    const float ib = s >= tab0 ? tab_ib[s - tab0] : a.inv_bc2s[s];
+    const float gg = g + a.wd * p;
+    m = m + (gg - m) * a.one_m_b1;
+    v = v * a.beta2 + (a.one_m_b2 * gg) * gg;
+    const float den = __builtin_amdgcn_sqrtf(v) * ib + a.eps;
+    p = p + (ns * m) * __builtin_amdgcn_rcpf(den);
+    g = 0.f;
+  }
+}
+
+// FINAL = false: grid (nt * 8 / 1024, lazy levels, fits), one entry of this step's list per 8 lanes.
+// FINAL = true:  grid (ceil((n_entries - e0) * 8 / 1024), 1, fits), every lazy entry.
+template <bool FINAL>
+__global__ __launch_bounds__(1024) void adam_lazy_kernel(LazyArgs a) {
+  __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
+  const int fit = blockIdx.z;
+  const int tab0 = a.target > LAZY_TAB ? a.target - LAZY_TAB : 0;
+  for (int i = threadIdx.x; i < a.target - tab0; i += 1024) {
+    tab_ns[i] = a.neg_step[tab0 + i];
+    tab_ib[i] = a.inv_bc2s[tab0 + i];
+  }
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  const int f = (int)(i & 7);
+  uint32_t e;
+  if (FINAL) {
+    if (i >> 3 >= (long long)(a.n_entries - a.e0)) return;
+    e = a.e0 + (uint32_t)(i >> 3);
+  } else {
+    const int l = a.l0 + blockIdx.y;
+    if ((i >> 3) >= a.ucount[fit][l]) return;
+    e = a.ukeys[fit][(size_t)l * a.nt + (i >> 3)];
+    if (e < a.e0) return;
+  }
+  const int from = a.done[fit][e - a.e0];
+  if (from >= a.target) return;
+  const size_t q = (size_t)e * 8 + f;
+  float p = a.P[fit][q], m = a.M[fit][q], v = a.V[fit][q];
+  const float g = a.G[fit][q];
+  lazy_replay(a, tab_ns, tab_ib, tab0, p, m, v, g, from, a.target);
+  a.P[fit][q] = p;
+  a.M[fit][q] = m;
+  a.V[fit][q] = v;
+  if (g != 0.f) a.G[fit][q] = 0.f;
+  if (f == 0) a.done[fit][e - a.e0] = (uint16_t)a.target;
+}
+
 }  // namespace
 
 int dvt_adam_tune(int zero_all) {
@@ -227,6 +314,81 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
       hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
     else
       hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
+    DVT_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ---- lazy-exact Adam: host side (see the kernel comment above) ----------------------------------------------
+int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, const uint32_t* const* ukeys,
+                    const int32_t* const* ucount, hipStream_t s) {
+  if (!z || k < 1 || k > DVT_FIT_BATCH_MAX || target < 1 || target > 65535 || z->n_entries <= z->e0) return DVT_E_BADARG;
+  LazyArgs a{};
+  for (int f = 0; f < k; ++f) {
+    a.P[f] = z->p[f];
+    a.M[f] = z->m[f];
+    a.V[f] = z->v[f];
+    a.G[f] = z->g[f];
+    a.done[f] = z->done[f];
+    if (!a.P[f] || !a.M[f] || !a.V[f] || !a.G[f] || !a.done[f]) return DVT_E_BADARG;
+    if (!final_sweep) {
+      if (!ukeys || !ucount || !ukeys[f] || !ucount[f]) return DVT_E_BADARG;
+      a.ukeys[f] = ukeys[f];
+      a.ucount[f] = ucount[f];
+    }
+  }
+  a.neg_step = z->neg_step;
+  a.inv_bc2s = z->inv_bc2s;
+  a.e0 = z->e0;
+  a.n_entries = z->n_entries;
+  a.nt = z->nt;
+  a.l0 = z->l0;
+  a.target = target;
+  a.one_m_b1 = (float)(1.0 - z->beta1);
+  a.beta2 = (float)z->beta2;
+  a.one_m_b2 = (float)(1.0 - z->beta2);
+  a.eps = (float)z->eps;
+  a.wd = (float)z->weight_decay;
+  if (final_sweep) {
+    const long long lanes = (long long)(z->n_entries - z->e0) * 8;
+    hipLaunchKernelGGL(adam_lazy_kernel<true>, dim3((unsigned)dvt_cdiv(lanes, 1024), 1, k), dim3(1024), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(adam_lazy_kernel<false>, dim3((unsigned)dvt_cdiv((long long)z->nt * 8, 1024), z->n_levels - z->l0, k),
+                       dim3(1024), 0, s, a);
+  }
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Device tables of the per-step scalars of the lazy kernels, written from kernel arguments (stream-ordered, no
+// host buffer has to outlive the call): relative step i of the call <-> Adam step count t0 + i + 1.
+namespace {
+struct TabChunk {
+  int n, off;
+  float ns[448], ib[448];
+};
+__global__ void lazy_tab_kernel(TabChunk c, float* neg_step, float* inv_bc2s) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < c.n) {
+    neg_step[c.off + i] = c.ns[i];
+    inv_bc2s[c.off + i] = c.ib[i];
+  }
+}
+}  // namespace
+
+int dvt_adam_lazy_tables(const double* h_lr, int step_begin, int step_end, double beta1, double beta2, float* neg_step,
+                         float* inv_bc2s, hipStream_t s) {
+  if (!h_lr || !neg_step || !inv_bc2s || step_end <= step_begin) return DVT_E_BADARG;
+  for (int o = step_begin; o < step_end; o += 448) {
+    TabChunk c{};
+    c.off = o - step_begin;
+    c.n = step_end - o < 448 ? step_end - o : 448;
+    for (int i = 0; i < c.n; ++i) {
+      const double t = (double)(o + i + 1);
+      c.ns[i] = (float)(-(h_lr[o + i] / (1.0 - pow(beta1, t))));
+      c.ib[i] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
+    }
+    hipLaunchKernelGGL(lazy_tab_kernel, dim3(7), dim3(64), 0, s, c, neg_step, inv_bc2s);
     DVT_CHECK_LAUNCH();
   }
   return 0;

@@ -35,6 +35,29 @@ int dvt_loss_launch(const float* F, const float* G, const int32_t* g_idx, int la
                     const float* Hres, const float* raw_rows, float* d_pred, float* d_hres,
                     float* d_G, float* row_sums, int n, int c, float grad_scale, hipStream_t s);
 
+// Lazy-exact Adam over the fine hash-grid levels (dvt_adam.hip).  Entries [e0, n_entries) are stepped on demand:
+// `done[e - e0]` steps (relative to the first step of the dvt_fit_run call) are applied, the gradient arena holds
+// the pending step's gradient.  neg_step / inv_bc2s: device tables indexed by relative step.
+struct DvtAdamLazy {
+  float* p[DVT_FIT_BATCH_MAX];
+  float* m[DVT_FIT_BATCH_MAX];
+  float* v[DVT_FIT_BATCH_MAX];
+  float* g[DVT_FIT_BATCH_MAX];
+  uint16_t* done[DVT_FIT_BATCH_MAX];
+  const float* neg_step;
+  const float* inv_bc2s;
+  uint32_t e0, n_entries;
+  int nt, l0, n_levels;
+  double beta1, beta2, eps, weight_decay;
+};
+// final_sweep: every lazy entry is brought to `target` applied steps; otherwise only the distinct entries listed
+// in ukeys / ucount (this step's lists, [L][nt] / [L]).
+int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, const uint32_t* const* ukeys,
+                    const int32_t* const* ucount, hipStream_t s);
+
+int dvt_adam_lazy_tables(const double* h_lr, int step_begin, int step_end, double beta1, double beta2, float* neg_step,
+                         float* inv_bc2s, hipStream_t s);
+
 // ---- batched fits: k images advanced by the SAME launches (blockIdx.y = fit) ----
 // The per-image fit is a chain of ~10 small dependent launches per Adam step; each launch pays a
 // fixed dependent-launch latency (and, next to the extractor, a wait for free CU slots) that does
@@ -118,6 +141,7 @@ struct DvtFusedFit {  // per fit: inputs, arena, shadow weights and what the row
   const uint32_t* gs_keys; // this step's sorted grid-corner lists (dvt_grid_dev.h: GridSortedPtrs), or nullptr
   const uint16_t* gs_pay;
   const float* gs_w;
+  uint32_t gs_bitmap_end;  // grid entries >= this get no `touched` bit (lazy Adam owns them); 0xffffffff: all do
 };
 #if defined(__HIPCC__)
 typedef __bf16 dvt_hwbf16x2 __attribute__((ext_vector_type(2)));

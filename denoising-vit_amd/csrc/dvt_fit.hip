@@ -17,6 +17,10 @@
 #include "dvt_common.h"
 #include "dvt_grid_dev.h"
 
+extern int g_fit_sorted_grid;
+int g_fit_lazy_adam = 1;  // dvt_tune_set(9, 0): dense Adam over the whole arena
+int g_fit_lazy_refresh = 32;  // dvt_tune_set(9, n >= 2): steps between full sweeps of the lazy region
+
 int g_adam_pingpong = 1;  // dvt_tune_set(8, 0): always sweep forward (A/B timing)
 
 namespace {
@@ -33,10 +37,31 @@ struct Work {
   uint32_t* gs_keys;
   uint16_t* gs_pay;
   float* gs_w;
+  // lazy-exact Adam over the fine grid levels (dvt_adam.hip): distinct-entry lists of the chunk, per-entry step
+  // counters, per-step scalar tables (nullptr: dense Adam everywhere)
+  uint32_t* gs_ukeys;
+  int32_t* gs_ucount;
+  uint16_t* lazy_done;
+  float *lazy_ns, *lazy_ib;
 };
 constexpr int GS_CHUNK = 128;  // steps per sort launch: 168 MB of lists per fit at batch 2048, 16 levels
 
 bool row_lists_ok(const DvtFitConfig* c) { return c->lattice <= 8192 && c->batch <= 65535; }
+
+// Grid entries [e0, n_entries_total) are stepped lazily: everything from the first level with >= 64 k entries on
+// (a step touches <= 4 * batch = 8 k of them), e0 rounded up to a whole `touched` word / Adam chunk.
+bool lazy_range(const DvtFitConfig* c, uint32_t* e0, int* l0) {
+  if (c->num_iters > 65535) return false;  // 16-bit step counters
+  for (int l = 0; l < c->grid.n_levels; ++l)
+    if (c->grid.entries[l] >= 65536u) {
+      const uint32_t e = (c->grid.offset[l] + 31u) & ~31u;
+      if (e >= c->grid.n_entries_total) return false;
+      *e0 = e;
+      *l0 = l;
+      return true;
+    }
+  return false;
+}
 
 int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
   const int64_t B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
@@ -70,7 +95,7 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
   }
   t.shadow = nullptr;
   t.T = nullptr;
-  bool fused_bufs = false;  // (pointers are all null in the size query: never test them here)
+  bool fused_bufs = false, lazy_bufs = false;  // (pointers are all null in the size query: never test them here)
   if (dvt_fit_fused_shapes_ok(c)) {
     DvtShadowLayout L;
     if (dvt_shadow_layout(c, &L) == 0) {
@@ -89,6 +114,22 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
     t.gs_keys = reinterpret_cast<uint32_t*>(take(per_step * GS_CHUNK));
     t.gs_w = take(per_step * GS_CHUNK);
     t.gs_pay = reinterpret_cast<uint16_t*>(take((per_step * GS_CHUNK + 1) / 2));
+    uint32_t e0;
+    int l0;
+    if (lazy_range(c, &e0, &l0)) {
+      t.gs_ukeys = reinterpret_cast<uint32_t*>(take(per_step * GS_CHUNK));
+      t.gs_ucount = reinterpret_cast<int32_t*>(take((int64_t)c->grid.n_levels * GS_CHUNK));
+      t.lazy_done = reinterpret_cast<uint16_t*>(take(((int64_t)(c->grid.n_entries_total - e0) + 1) / 2));
+      t.lazy_ns = take(c->num_iters);
+      t.lazy_ib = take(c->num_iters);
+      lazy_bufs = true;
+    }
+  }
+  if (!lazy_bufs) {
+    t.gs_ukeys = nullptr;
+    t.gs_ucount = nullptr;
+    t.lazy_done = nullptr;
+    t.lazy_ns = t.lazy_ib = nullptr;
   }
   if (w) *w = t;
   return o;
@@ -177,7 +218,9 @@ int check_bufs(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin, in
 // launch covers all k fits (blockIdx.y = fit; the grouped GEMM launch simply carries k x the
 // problems).  k = 1 is the reference's per-image loop.
 int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const Work* ws, int step,
-             int gs_local, hipStream_t s) {  // gs_local: index of `step` inside the current chunk of sorted grid lists, or -1
+             int gs_local, uint32_t lazy_e0, hipStream_t s) {
+  // gs_local: index of `step` inside the current chunk of sorted grid lists, or -1;  lazy_e0: first grid entry the lazy
+  // Adam kernels own (0xffffffff: none, dense Adam steps everything)
   const int B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
   const int E = c->grid.n_levels * c->grid.n_features;
   const bool phase2 = step > c->switch_step;
@@ -243,7 +286,8 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
       const bool gs = w.gs_keys != nullptr && gs_local >= 0;
       ff[f] = DvtFusedFit{xy[f], ridx[f], feat[f], P[f], w.shadow, w.T, w.F, w.Hres, w.dF, w.denc, w.rows, Gd[f],
                           w.g_offs + (size_t)step * (c->lattice + 1), w.g_perm + (size_t)step * B, touched[f],
-                          gs ? w.gs_keys + gso : nullptr, gs ? w.gs_pay + gso : nullptr, gs ? w.gs_w + gso : nullptr};
+                          gs ? w.gs_keys + gso : nullptr, gs ? w.gs_pay + gso : nullptr, gs ? w.gs_w + gso : nullptr,
+                          lazy_e0};
     }
     DVT_TRY(dvt_fit_rows_k(c, &shl, k, ff, use_res, s));
   } else {
@@ -346,10 +390,16 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
     sg.active = 1;
     a.segs[a.n_segs++] = sg;
   };
+  const bool lazy = lazy_e0 != 0xffffffffu;
+  const int64_t dense_grid_end = lazy ? (int64_t)lazy_e0 * 8 : c->off_w1;  // the lazy kernels own [lazy_e0 * 8, off_w1)
+  if (lazy) {
+    a.sparse_end = dense_grid_end;
+    seg(c->off_grid, dense_grid_end, step + 1);  // coarse grid levels
+  }
   if (!phase2) {
-    seg(c->off_grid, c->off_wh1, step + 1);  // grid + field MLP + G
+    seg(lazy ? c->off_w1 : c->off_grid, c->off_wh1, step + 1);  // (grid +) field MLP + G
   } else {
-    seg(c->off_grid, c->off_G, step + 1);  // grid + field MLP (G frozen: grad None)
+    seg(lazy ? c->off_w1 : c->off_grid, c->off_G, step + 1);  // (grid +) field MLP (G frozen: grad None)
     if (use_res) seg(c->off_wh1, c->arena_floats, step - c->switch_step);  // h: own step count
   }
   DvtAdamRowGather gather{};
@@ -420,7 +470,40 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
     if (rc) return rc;
   }
   const bool sorted_lists = dvt_fit_fused_ok(c) && w[0].shadow != nullptr && w[0].g_offs != nullptr &&
-                            w[0].gs_keys != nullptr;
+                            w[0].gs_keys != nullptr && g_fit_sorted_grid;
+  uint32_t lazy_e0 = 0xffffffffu;
+  int lazy_l0 = 0;
+  DvtAdamLazy lz{};
+  const int n_call = step_end - step_begin;
+  const bool lazy = sorted_lists && g_fit_lazy_adam && w[0].lazy_done != nullptr && n_call >= 1 && n_call <= 65535 &&
+                    lazy_range(c, &lazy_e0, &lazy_l0);
+  if (!lazy) lazy_e0 = 0xffffffffu;
+  if (lazy) {
+    lz.e0 = lazy_e0;
+    lz.n_entries = c->grid.n_entries_total;
+    lz.nt = 4 * c->batch;
+    lz.l0 = lazy_l0;
+    lz.n_levels = c->grid.n_levels;
+    lz.beta1 = c->beta1;
+    lz.beta2 = c->beta2;
+    lz.eps = c->eps;
+    lz.weight_decay = c->weight_decay;
+    lz.neg_step = w[0].lazy_ns;
+    lz.inv_bc2s = w[0].lazy_ib;
+    int rc = dvt_adam_lazy_tables(bufs[0]->h_lr, step_begin, step_end, c->beta1, c->beta2, w[0].lazy_ns, w[0].lazy_ib,
+                                  (hipStream_t)stream);
+    if (rc) return rc;
+    for (int j = 0; j < k; ++j) {
+      lz.p[j] = bufs[j]->params;
+      lz.m[j] = bufs[j]->adam_m;
+      lz.v[j] = bufs[j]->adam_v;
+      lz.g[j] = bufs[j]->grads;
+      lz.done[j] = w[j].lazy_done;
+      const hipError_t e = hipMemsetAsync(w[j].lazy_done, 0, (size_t)(lz.n_entries - lz.e0) * sizeof(uint16_t),
+                                          (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
   for (int step = step_begin; step < step_end; ++step) {
     int gs_local = -1;
     if (sorted_lists) {
@@ -432,18 +515,45 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
         uint32_t* keys[DVT_FIT_BATCH_MAX];
         uint16_t* pay[DVT_FIT_BATCH_MAX];
         float* ww[DVT_FIT_BATCH_MAX];
+        uint32_t* uk[DVT_FIT_BATCH_MAX];
+        int32_t* uc[DVT_FIT_BATCH_MAX];
         for (int j = 0; j < k; ++j) {
           xy[j] = bufs[j]->xy;
           ridx[j] = bufs[j]->idx + (size_t)step * c->batch;
           keys[j] = w[j].gs_keys;
           pay[j] = w[j].gs_pay;
           ww[j] = w[j].gs_w;
+          uk[j] = w[j].gs_ukeys;
+          uc[j] = w[j].gs_ucount;
         }
-        int rc = dvt_grid_sort_k(&c->grid, k, xy, ridx, c->batch, steps, keys, pay, ww, (hipStream_t)stream);
+        int rc = dvt_grid_sort_k(&c->grid, k, xy, ridx, c->batch, steps, keys, pay, ww, (hipStream_t)stream,
+                                 lazy ? uk : nullptr, lazy ? uc : nullptr);
         if (rc) return rc;
       }
     }
-    int rc = fit_step(c, k, bufs, w, step, gs_local, (hipStream_t)stream);
+    if (lazy && step > step_begin && (step - step_begin) % g_fit_lazy_refresh == 0) {
+      // REFRESH every g_fit_lazy_refresh steps: all lazy entries through step - 1.  A replay is a sequential recurrence
+      // (~70 cycles per step), and without a bound the longest gap of a step's entries (~128 ln 8192 steps on the
+      // finest level) made the catch-up kernel 74 us long whatever the throughput; with the refresh no chain exceeds
+      // GS_CHUNK steps, and the sweep itself runs at full lane utilisation (nearly every lane replays the same
+      // GS_CHUNK steps) -- work is only moved, not added.
+      int rc = dvt_adam_lazy_k(&lz, k, true, step - step_begin, nullptr, nullptr, (hipStream_t)stream);
+      if (rc) return rc;
+    } else if (lazy && step > step_begin) {  // bring the entries this step reads up to date (steps < step applied)
+      const uint32_t* uk[DVT_FIT_BATCH_MAX];
+      const int32_t* uc[DVT_FIT_BATCH_MAX];
+      for (int j = 0; j < k; ++j) {
+        uk[j] = w[j].gs_ukeys + (size_t)gs_local * c->grid.n_levels * 4 * c->batch;
+        uc[j] = w[j].gs_ucount + (size_t)gs_local * c->grid.n_levels;
+      }
+      int rc = dvt_adam_lazy_k(&lz, k, false, step - step_begin, uk, uc, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+    int rc = fit_step(c, k, bufs, w, step, gs_local, lazy_e0, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  if (lazy) {  // the arena is exact at every call boundary: every lazy entry through the last step of this call
+    int rc = dvt_adam_lazy_k(&lz, k, true, n_call, nullptr, nullptr, (hipStream_t)stream);
     if (rc) return rc;
   }
   return 0;

@@ -708,6 +708,7 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
   for (int f = 0; f < k; ++f) sorted = sorted && fits[f].gs_keys && fits[f].gs_pay && fits[f].gs_w;
   if (sorted) {
     ba.gs.nt = 4 * c->batch;
+    ba.gs.bitmap_end = fits[0].gs_bitmap_end;
     ba.grid_blocks_per_fit = c->grid.n_levels * (ba.gs.nt / 1024);
     for (int f = 0; f < k; ++f) {
       ba.gs.keys[f] = fits[f].gs_keys;

@@ -733,6 +733,8 @@ extern int g_cfg_override;
 }
 extern int g_fit_fused_enable;
 extern int g_fit_sorted_grid;
+extern int g_fit_lazy_adam;
+extern int g_fit_lazy_refresh;
 extern int g_adam_pingpong;
 
 extern "C" int dvt_tune_set(int key, int value) {
@@ -762,6 +764,11 @@ extern "C" int dvt_tune_set(int key, int value) {
   }
   if (key == 7) {
     g_fit_sorted_grid = value != 0;
+    return 0;
+  }
+  if (key == 9) {
+    g_fit_lazy_adam = value != 0;
+    if (value >= 2) g_fit_lazy_refresh = value;
     return 0;
   }
   if (key == 1) return dvt_vit_tune(value);

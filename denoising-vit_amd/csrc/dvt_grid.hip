@@ -151,6 +151,8 @@ struct GridSortArgs {
   uint32_t* keys[DVT_FIT_BATCH_MAX];
   uint16_t* pay[DVT_FIT_BATCH_MAX];
   float* w[DVT_FIT_BATCH_MAX];
+  uint32_t* ukeys[DVT_FIT_BATCH_MAX];  // optional: [steps][L][nt] ABSOLUTE indices of the distinct entries, ascending
+  int32_t* ucount[DVT_FIT_BATCH_MAX];  //           [steps][L] how many
   int n;
 };
 
@@ -192,18 +194,58 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(GridSortArgs a) {
       __syncthreads();
     }
   }
+  // thread tid owns the sorted positions [8 tid, 8 tid + 8)
   const size_t base = ((size_t)t * L + l) * nt;
-  for (int u = tid; u < nt; u += 1024) {
-    const unsigned long long e = sk[u];
-    const uint32_t pu = (uint32_t)(e & 8191u);
-    const float2 p = xy[ridx[pu >> 2]];
-    uint32_t idx[4];
-    float w[4];
-    corners2d(a.T, l, p.x, p.y, idx, w);
-    a.keys[f][base + u] = (uint32_t)(e >> 13);
-    a.pay[f][base + u] = (uint16_t)pu;
-    a.w[f][base + u] = w[pu & 3];
+  unsigned long long e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = sk[8 * tid + j];
+  const unsigned long long before = tid > 0 ? sk[8 * tid - 1] : ~0ull;
+  __syncthreads();  // sk is free from here on
+  int heads = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int u = 8 * tid + j;
+    if (u < nt) {
+      const uint32_t pu = (uint32_t)(e[j] & 8191u);
+      const float2 p = xy[ridx[pu >> 2]];
+      uint32_t idx[4];
+      float w[4];
+      corners2d(a.T, l, p.x, p.y, idx, w);
+      a.keys[f][base + u] = (uint32_t)(e[j] >> 13);
+      a.pay[f][base + u] = (uint16_t)pu;
+      a.w[f][base + u] = w[pu & 3];
+      const unsigned long long pk = (j ? e[j - 1] : before) >> 13;
+      heads += (u == 0 || pk != (e[j] >> 13)) ? 1 : 0;
+    }
   }
+  if (a.ukeys[f] == nullptr) return;
+  // exclusive scan of the per-thread head counts (1024 threads): wave scan + 16 wave totals through LDS
+  int* scan = reinterpret_cast<int*>(sk);
+  const int lane = tid & 63, wave = tid >> 6;
+  int incl = heads;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) scan[wave] = incl;
+  __syncthreads();
+  int wave_base = 0, total = 0;
+  for (int wv = 0; wv < 16; ++wv) {
+    const int c = scan[wv];
+    if (wv < wave) wave_base += c;
+    total += c;
+  }
+  int pos = wave_base + incl - heads;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int u = 8 * tid + j;
+    if (u < nt) {
+      const unsigned long long pk = (j ? e[j - 1] : before) >> 13;
+      if (u == 0 || pk != (e[j] >> 13)) a.ukeys[f][base + pos++] = off + (uint32_t)(e[j] >> 13);
+    }
+  }
+  if (tid == 0) a.ucount[f][(size_t)t * L + l] = total;
 }
 }  // namespace
 
@@ -216,7 +258,8 @@ bool dvt_grid_sorted_ok(const DvtGridTable* T, int n) {
 }
 
 int dvt_grid_sort_k(const DvtGridTable* T, int k, const float* const* xy, const int32_t* const* ridx, int n, int steps,
-                    uint32_t* const* keys, uint16_t* const* pay, float* const* w, hipStream_t s) {
+                    uint32_t* const* keys, uint16_t* const* pay, float* const* w, hipStream_t s,
+                    uint32_t* const* ukeys, int32_t* const* ucount) {
   if (!dvt_grid_sorted_ok(T, n) || k < 1 || k > DVT_FIT_BATCH_MAX || steps < 1 || steps > 65535) return DVT_E_BADARG;
   GridSortArgs a{};
   a.T = *T;
@@ -228,6 +271,9 @@ int dvt_grid_sort_k(const DvtGridTable* T, int k, const float* const* xy, const 
     a.keys[f] = keys[f];
     a.pay[f] = pay[f];
     a.w[f] = w[f];
+    a.ukeys[f] = ukeys ? ukeys[f] : nullptr;
+    a.ucount[f] = ucount ? ucount[f] : nullptr;
+    if ((a.ukeys[f] == nullptr) != (a.ucount[f] == nullptr)) return DVT_E_BADARG;
   }
   hipLaunchKernelGGL(grid_sort_kernel, dim3(T->n_levels, steps, k), dim3(1024), 0, s, a);
   DVT_CHECK_LAUNCH();

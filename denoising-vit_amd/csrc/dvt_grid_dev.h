@@ -167,6 +167,7 @@ struct GridSortedPtrs {
   const uint16_t* pay[DVT_FIT_BATCH_MAX];   //            (sample << 2) | corner
   const float* w[DVT_FIT_BATCH_MAX];        //            bilinear weight of that corner
   int nt;                                   // 4 * batch
+  uint32_t bitmap_end;                      // entries >= this are stepped lazily (dvt_adam.hip): no `touched` bit
 };
 
 // One 1024-thread block = 1024 consecutive sorted pairs of level `l` of fit `fy` (part `part` of nt / 1024).
@@ -210,14 +211,15 @@ __device__ __forceinline__ void grid_gather_body(const DvtGridTable& T, const Gr
 #pragma unroll
     for (int f = 0; f < 8; ++f) atomic_add_f32(dst + f, c[f]);
   }
-  if (ends && touched != nullptr)
+  if (ends && touched != nullptr && a < q.bitmap_end)
     __hip_atomic_fetch_or(touched + (a >> 5), 1u << (a & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 bool dvt_grid_sorted_ok(const DvtGridTable* T, int n);
 // lists of `steps` consecutive steps of k fits: ridx[f] points at the first of those steps' index rows ([steps][n])
 int dvt_grid_sort_k(const DvtGridTable* T, int k, const float* const* xy, const int32_t* const* ridx, int n, int steps,
-                    uint32_t* const* keys, uint16_t* const* pay, float* const* w, hipStream_t s);
+                    uint32_t* const* keys, uint16_t* const* pay, float* const* w, hipStream_t s,
+                    uint32_t* const* ukeys = nullptr, int32_t* const* ucount = nullptr);
 
 void dvt_grid_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan);
 extern int g_grid_lds_chunk;
