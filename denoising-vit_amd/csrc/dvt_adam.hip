@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
 // dense kernel in the replay loop: 2 instead of ~25 instructions per element-step.
 // 8 lanes per entry (one feature each): the lanes of an entry share the trip count.
 // ==========================================================================================================
-constexpr int LAZY_TAB = 2048;  // most recent steps whose (neg_step, 1 / bc2s) sit in LDS; older ones come from L2
+constexpr int LAZY_TAB = 256;  // most recent steps whose (neg_step, 1 / bc2s) sit in LDS (2 KB); older ones come from L2
+                               // (never needed while the refresh interval is <= LAZY_TAB)
+constexpr int LAZY_BLOCK = 256;  // one wave per SIMD, < 48 VGPRs, 2 KB of LDS: like the dense Adam kernel a lazy block
+                                 // fits beside the extractor's 8-phase GEMM workgroups (456 of 512 VGPRs, 136 of 160 KB)
 struct LazyArgs {
   float* P[DVT_FIT_BATCH_MAX];
   float* M[DVT_FIT_BATCH_MAX];
@@ -188,19 +191,19 @@ __device__ __forceinline__ void lazy_replay(const LazyArgs& a, const float* tab_
   }
 }
 
-// FINAL = false: grid (nt * 8 / 1024, lazy levels, fits), one entry of this step's list per 8 lanes.
-// FINAL = true:  grid (ceil((n_entries - e0) * 8 / 1024), 1, fits), every lazy entry.
+// FINAL = false: grid (nt * 8 / LAZY_BLOCK, lazy levels, fits), one entry of this step's list per 8 lanes.
+// FINAL = true:  grid (ceil((n_entries - e0) * 8 / LAZY_BLOCK), 1, fits), every lazy entry.
 template <bool FINAL>
-__global__ __launch_bounds__(1024) void adam_lazy_kernel(LazyArgs a) {
+__global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
   __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
   const int fit = blockIdx.z;
   const int tab0 = a.target > LAZY_TAB ? a.target - LAZY_TAB : 0;
-  for (int i = threadIdx.x; i < a.target - tab0; i += 1024) {
+  for (int i = threadIdx.x; i < a.target - tab0; i += LAZY_BLOCK) {
     tab_ns[i] = a.neg_step[tab0 + i];
     tab_ib[i] = a.inv_bc2s[tab0 + i];
   }
   __syncthreads();
-  const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  const long long i = (long long)blockIdx.x * LAZY_BLOCK + threadIdx.x;
   const int f = (int)(i & 7);
   uint32_t e;
   if (FINAL) {
@@ -351,10 +354,10 @@ int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, c
   a.wd = (float)z->weight_decay;
   if (final_sweep) {
     const long long lanes = (long long)(z->n_entries - z->e0) * 8;
-    hipLaunchKernelGGL(adam_lazy_kernel<true>, dim3((unsigned)dvt_cdiv(lanes, 1024), 1, k), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(adam_lazy_kernel<true>, dim3((unsigned)dvt_cdiv(lanes, LAZY_BLOCK), 1, k), dim3(LAZY_BLOCK), 0, s, a);
   } else {
-    hipLaunchKernelGGL(adam_lazy_kernel<false>, dim3((unsigned)dvt_cdiv((long long)z->nt * 8, 1024), z->n_levels - z->l0, k),
-                       dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(adam_lazy_kernel<false>, dim3((unsigned)dvt_cdiv((long long)z->nt * 8, LAZY_BLOCK), z->n_levels - z->l0, k),
+                       dim3(LAZY_BLOCK), 0, s, a);
   }
   DVT_CHECK_LAUNCH();
   return 0;
