@@ -33,13 +33,14 @@ for _p in (ROOT, os.path.join(ROOT, "denoising-vit_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# HBM bytes per launch from PMC counters, collected in separate rocprofv3 --pmc passes
-# (profiles/r0*_pmc/{fetch,write}.txt; tools/gpu_pmc.sh on a 128-view batch + 60 fit steps):
+# HBM-side bytes per launch from PMC counters, collected in separate rocprofv3 --pmc passes
+# (profiles/r02/pmc_final/{fetch,write}.txt; tools/gpu_r3c.sh on a 128-view batch + 60 fit steps):
 # (FETCH_SIZE x 2 [gfx950 wide-load correction, MI355X_MICROARCH.md HBM section] + WRITE_SIZE)
-# x 1024 B / launches.  Calibration: layernorm reads 830.6 MB/launch = its algorithmic 830 MB.
-# vit_gemm = launch-weighted mean of the qkv, proj / fc2 and fc1 GEMMs.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {"vit_gemm": 2121.0e6, "vit_attn": 1108.3e6, "adam": 517.3e6,
-                                "fit_gemm": 48.4e6, "grid": None}
+# x 1024 B / launches.  Calibration: layernorm reads + writes 830.6 MB/launch = its algorithmic 830 MB.
+# vit_gemm = launch-weighted mean of the qkv (1932 MB), proj / fc2 (2081 MB) and fc1 (2494 MB) GEMMs;
+# adam = the dense part only (coarse grid levels + MLPs + G; the fine levels are stepped lazily).
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"vit_gemm": 2146.6e6, "vit_attn": 1107.6e6, "adam": 53.7e6,
+                                "fit_gemm": 66.4e6, "fit_rows": 94.4e6, "grid": None}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA
