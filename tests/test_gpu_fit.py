@@ -312,3 +312,131 @@ def test_bf16_fit_any_batch_size(built_lib, B):
     for step in range(T):
         assert abs(outs[0][0][step]["loss"] - outs[1][0][step]["loss"]) <= 2e-4 * abs(outs[1][0][step]["loss"])
     assert per_patch_cos(outs[0][1], outs[1][1]).min() > 0.9999
+
+
+def _bf16_run(built_lib, feats, xy, idx, T, knobs=(), splits=None, C=768, seed=1, warmup=None):
+    from dvt_amd.fit import FitEngine, FitSettings
+    n_rows = feats.shape[0]
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=T // 10 if warmup is None else warmup, mlp_dtype="bfloat16")
+    try:
+        for k, v in knobs:
+            assert built_lib.dvt_tune_set(k, v) == 0
+        eng = FitEngine(s, n_rows, DEV)
+        eng.reset(torch.Generator(device=DEV).manual_seed(seed))
+        for lo, hi in (splits or [(0, T)]):
+            eng.fit(feats, xy, idx, log_every=1, step_begin=lo, step_end=hi)
+        torch.cuda.synchronize()
+    finally:
+        built_lib.dvt_tune_set(9, 32)
+        built_lib.dvt_tune_set(7, 1)
+    return eng
+
+
+def _never_touched_mask(built_lib, eng, xy_rows, idx):
+    """bool [n_entries]: grid entries no sampled row of the whole index stream has a corner on."""
+    import ctypes as C
+    tbl = eng.cfg.grid
+    rows = torch.from_numpy(np.unique(idx.reshape(-1))).to(DEV).long()
+    pts = xy_rows[rows].contiguous()
+    n = pts.shape[0]
+    ci = torch.empty((n, tbl.n_levels, 4), device=DEV, dtype=torch.int32)
+    cw = torch.empty((n, tbl.n_levels, 4), device=DEV, dtype=torch.float32)
+    assert built_lib.dvt_grid_corners(C.byref(tbl), pts.data_ptr(), ci.data_ptr(), cw.data_ptr(), n,
+                                      torch.cuda.current_stream().cuda_stream) == 0
+    mask = torch.ones(int(tbl.n_entries_total), dtype=torch.bool, device=DEV)
+    mask[ci.reshape(-1).long()] = False
+    return mask
+
+
+def _arena_agreement(a, b, mask, what, rtol=2e-5):
+    """(p, m, v) of the never-touched entries follow a recurrence that depends on nothing but their own start value
+    and the learning-rate schedule: the two runs must agree to rounding there, however long the run."""
+    n8 = mask.numel() * 8
+    for name in ("params", "adam_m", "adam_v"):
+        x, y = getattr(a, name)[:n8].view(-1, 8)[mask], getattr(b, name)[:n8].view(-1, 8)[mask]
+        scale = float(y.abs().max())
+        worst = float((x - y).abs().max())
+        print(f"{what}, {name}, {int(mask.sum())} never-touched entries: max |diff| {worst:.3e} (scale {scale:.3e})")
+        assert worst <= rtol * scale, (what, name, worst, scale)
+
+
+def test_lazy_adam_equals_dense_adam(built_lib):
+    """The lazy-exact Adam of the fine hash-grid levels (per-entry step counters, pending gradients, catch-up before
+    every row kernel, refresh every 32 steps, final sweep) against the dense sweep (dvt_tune_set(9, 0)) on the same
+    fused bf16-mode fit.
+    * 2 steps with lr(0) = 0 (one warm-up step), so that both runs see identical gradients in both steps: every code
+      path has run once (pending gradient consumed by the catch-up of step 1 and by the final sweep) and the arenas
+      agree to the 1-ulp rcp / sqrt of the replay loop.  (With feedback, the TRAINING DYNAMICS amplify any rounding
+      difference within a few steps -- a flipped bf16 rounding changes a gradient by 1e-3, Adam turns the sign of a
+      near-zero gradient into +-lr -- equally in the dense levels and the MLP weights both runs step identically.)
+    * 150 steps (phase switch, four refreshes, a chunk boundary of the sorted lists): the never-touched entries agree
+      to rounding in p, m AND v; losses and the saved tensor agree like two runs of the same path do."""
+    V, H, C = 6, 37, 768
+    feats, xy = synthetic_image(V, H, H, C, seed=5)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    idx2 = np.random.RandomState(4).randint(0, f.shape[0], (2, 2048)).astype(np.int32)
+    lazy = _bf16_run(built_lib, f, c, idx2, 2, warmup=1)
+    dense = _bf16_run(built_lib, f, c, idx2, 2, knobs=[(9, 0)], warmup=1)
+    for name in ("params", "adam_m", "adam_v"):
+        a, b = getattr(lazy, name), getattr(dense, name)
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name
+    T = 150
+    idx = np.random.RandomState(5).randint(0, f.shape[0], (T, 2048)).astype(np.int32)
+    lazy = _bf16_run(built_lib, f, c, idx, T)
+    dense = _bf16_run(built_lib, f, c, idx, T, knobs=[(9, 0)])
+    # (150 steps of 1-ulp rcp / sqrt differences in a recurrence that contracts p to ~4e-7: 1.4e-4 relative, 6e-11 absolute)
+    _arena_agreement(lazy, dense, _never_touched_mask(built_lib, lazy, c, idx), "lazy vs dense Adam", rtol=2e-3)
+    assert float(lazy.grads.abs().max()) == 0.0 and int(lazy.touched.abs().max()) == 0
+    la, ld = lazy.loss_log(), dense.loss_log()
+    worst = max(abs(la[s]["loss"] - ld[s]["loss"]) / abs(ld[s]["loss"]) for s in range(T))
+    cos = per_patch_cos(lazy.infer(xy[-1].to(DEV)).cpu(), dense.infer(xy[-1].to(DEV)).cpu())
+    print(f"lazy vs dense Adam, 150 steps: worst per-step loss rel diff {worst:.2e}, saved tensor cosine min {cos.min():.6f}")
+    assert worst < 5e-3 and cos.min() > 0.999
+
+
+def test_lazy_adam_is_exact_at_call_boundaries(built_lib):
+    """Chunked runs (the driver's resume / logging granularity): [0, 45) + [45, 46) + [46, 150) against one call --
+    every call ends with a sweep that brings all lazy entries to its last step -- and a refresh interval that divides
+    nothing (7): never-touched entries agree to rounding, the rest like two runs of one path."""
+    V, H, C, T = 5, 37, 768, 150
+    feats, xy = synthetic_image(V, H, H, C, seed=6)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    idx = np.random.RandomState(6).randint(0, f.shape[0], (T, 2048)).astype(np.int32)
+    one = _bf16_run(built_lib, f, c, idx, T)
+    parts = _bf16_run(built_lib, f, c, idx, T, splits=[(0, 45), (45, 46), (46, T)])
+    odd = _bf16_run(built_lib, f, c, idx, T, knobs=[(9, 7)])
+    mask = _never_touched_mask(built_lib, one, c, idx)
+    ref = one.infer(xy[-1].to(DEV)).cpu()
+    for other, what in ((parts, "3 calls vs 1"), (odd, "refresh 7 vs 32")):
+        _arena_agreement(other, one, mask, what)
+        assert float(other.grads.abs().max()) == 0.0
+        assert per_patch_cos(other.infer(xy[-1].to(DEV)).cpu(), ref).min() > 0.999
+
+
+def test_batched_fused_fits_equal_separate_fits(built_lib):
+    """dvt_fit_run_batched on the fused bf16 path (sorted lists, lazy Adam, all per fit) against separate runs."""
+    from dvt_amd.fit import FitEngine, FitSettings, fit_many
+    V, H, C, T, k = 4, 37, 768, 70, 2
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=7, mlp_dtype="bfloat16")
+    data = [synthetic_image(V, H, H, C, seed=20 + j) for j in range(k)]
+    fs = [d[0].reshape(-1, C).to(DEV) for d in data]
+    cs = [d[1].reshape(-1, 2).to(DEV) for d in data]
+    n_rows = fs[0].shape[0]
+    idxs = [np.random.RandomState(30 + j).randint(0, n_rows, (T, 2048)).astype(np.int32) for j in range(k)]
+    solo, batched = [], []
+    for j in range(k):
+        e = FitEngine(s, n_rows, DEV)
+        e.reset(torch.Generator(device=DEV).manual_seed(j))
+        e.fit(fs[j], cs[j], idxs[j], log_every=0)
+        solo.append(e)
+        b = FitEngine(s, n_rows, DEV)
+        b.reset(torch.Generator(device=DEV).manual_seed(j))
+        batched.append(b)
+    fit_many(batched, fs, cs, idxs, log_every=0)
+    torch.cuda.synchronize()
+    for j in range(k):
+        d = (solo[j].params - batched[j].params).abs()
+        assert float(d.mean()) < 2e-5 and float(d.max()) < 0.1, (j, float(d.mean()), float(d.max()))
+        a, b = solo[j].infer(data[j][1][-1].to(DEV)), batched[j].infer(data[j][1][-1].to(DEV))
+        assert per_patch_cos(a.cpu(), b.cpu()).min() > 0.9999
+        assert float(batched[j].grads.abs().max()) == 0.0
