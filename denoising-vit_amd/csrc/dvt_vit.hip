@@ -79,6 +79,12 @@ struct GemmBArgs {
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int mblock;         // M panels per block of the tile order (1: n fastest)
   int nt_store;       // bf16 outputs with the non-temporal hint
+  // LayerNorm folded into the GEMMs (see ln_fold): consumer side (EPI_QKV / EPI_GELU) ...
+  const float2* ln_stats;  // [M] (mean, rstd) of the fp32 residual rows; A is then bf16(x), W is bf16(gamma (.) W)
+  const float* ln_cs;      // [N] column sums of the folded weights
+  // ... producer side (EPI_RESID): besides x, emit bf16(x) and the per-row partial sums of this 64-column block
+  bf16_t* xb;              // [M, N]
+  float2* st_part;         // [N / 64][M] (sum, sum of squares)
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
   double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
@@ -286,25 +292,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBArgs p) {
 constexpr int EP_LD = 68;                      // floats per row of a wave's LDS block
 constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;  // 17408 B x 8 waves = 136 KB <= 144 KB
 
+template <int NI>
+__device__ __forceinline__ void ln_fold(const GemmBArgs& p, f32x4 (&acc)[NI][4], int mrow0, int ncol0, int lane);
+
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&acc)[4][4], int m0,
                                                   int n0, int wm, int wn, int wave, int lane,
                                                   char* smem) {
   const int g = lane >> 4, lc = lane & 15;
+  // LayerNorm folded into this GEMM (see ln_fold): the accumulators are x . W'^T of the UN-normalised rows
+  const bool ln = (EPI == EPI_QKV || EPI == EPI_GELU) && p.ln_stats != nullptr;
   if (EPI == EPI_QKV && n0 >= 2 * p.dim) {  // V tiles keep the direct transposed store
+    if (ln) ln_fold<4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
     gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
     return;
   }
   float* blk = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
   const int nb = n0 + wn * 64;
+  // (mean, rstd) of the block's 64 rows: ONE coalesced load per lane, requested now and parked in the padding
+  // columns of the LDS block with the accumulators (as 32 loads per lane at the top of the epilogue they cost a full
+  // memory latency per tile)
+  float2 st_row = make_float2(0.f, 0.f);
+  if (ln) st_row = p.ln_stats[m0 + wm * 64 + lane];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float bias = p.bias != nullptr ? p.bias[nb + j * 16 + lc] : 0.f;
+    const float bias = (p.bias != nullptr && !ln) ? p.bias[nb + j * 16 + lc] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) blk[(i * 16 + 4 * g + r) * EP_LD + j * 16 + lc] = acc[i][j][r] + bias;
   }
+  if (ln) *reinterpret_cast<float2*>(blk + lane * EP_LD + 64) = st_row;
   // each wave only re-reads its own block: no workgroup barrier needed, only LDS completion
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int mb = m0 + wm * 64;
@@ -347,11 +365,30 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     const int c8 = (lane & 7) * 8;  // 8 lanes x 8 columns = one row; 8 rows per pass
     // (GELU: one row at a time -- four rows of erf polynomials in flight took the fc1 kernel to 254 VGPRs,
     // and at 2 x 256 registers per SIMD no wave of the fit's streaming kernels can share the CU)
+    float4 cs0, cs1, bf0, bf1;
+    if (ln) {
+      cs0 = *reinterpret_cast<const float4*>(p.ln_cs + nb + c8);
+      cs1 = *reinterpret_cast<const float4*>(p.ln_cs + nb + c8 + 4);
+      bf0 = *reinterpret_cast<const float4*>(p.bias + nb + c8);
+      bf1 = *reinterpret_cast<const float4*>(p.bias + nb + c8 + 4);
+    }
 #pragma unroll(EPI == EPI_GELU ? 1 : 4)
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3);
       float4 a = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8);
       float4 b = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8 + 4);
+      if (ln) {  // rstd * (acc - mean * cs) + b'
+        const float2 stv = *reinterpret_cast<const float2*>(blk + row * EP_LD + 64);
+        const float mu = stv.x, rs = stv.y;
+        a.x = fmaf(rs, a.x - mu * cs0.x, bf0.x);
+        a.y = fmaf(rs, a.y - mu * cs0.y, bf0.y);
+        a.z = fmaf(rs, a.z - mu * cs0.z, bf0.z);
+        a.w = fmaf(rs, a.w - mu * cs0.w, bf0.w);
+        b.x = fmaf(rs, b.x - mu * cs1.x, bf1.x);
+        b.y = fmaf(rs, b.y - mu * cs1.y, bf1.y);
+        b.z = fmaf(rs, b.z - mu * cs1.z, bf1.z);
+        b.w = fmaf(rs, b.w - mu * cs1.w, bf1.w);
+      }
       if (EPI == EPI_GELU) {
         a.x = gelu_erf(a.x);
         a.y = gelu_erf(a.y);
@@ -378,6 +415,89 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   }
 }
 
+// ---- LayerNorm folded into the neighbouring GEMMs ------------------------------------------------------------
+// xn = (x - mu) * rstd * gamma + beta, then xn . W^T + b, is   rstd * (x . W'^T - mu * cs) + b'   with
+// W' = gamma (.) W, cs[n] = sum_k W'[n][k], b' = b + W beta.  So the consumer GEMM (qkv, fc1) reads bf16(x)
+// itself and fixes its accumulators up with the row's (mu, rstd); the producer (the residual epilogue of proj /
+// fc2) writes bf16(x) and per-row partial (sum, sum of squares) next to the fp32 x it writes anyway.  The
+// LayerNorm kernel between them -- 553 MB read + 277 MB written per call, 168 calls per image -- disappears.
+template <int NI>
+__device__ __forceinline__ void ln_fold(const GemmBArgs& p, f32x4 (&acc)[NI][4], int mrow0, int ncol0, int lane) {
+  const int g = lane >> 4, lc = lane & 15;
+  float cs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cs[j] = p.ln_cs[ncol0 + j * 16 + lc];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float2 st = p.ln_stats[mrow0 + i * 16 + 4 * g + r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j][r] = st.y * (acc[i][j][r] - st.x * cs[j]);
+    }
+}
+
+// (mu, rstd) of every row from the P column-block partials written by the residual epilogue (fixed order: the
+// result does not depend on scheduling)
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float2* __restrict__ part, int P, int M, float inv_n,
+                                                                float eps, float2* __restrict__ stats) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int q = 0; q < P; ++q) {
+    const float2 v = part[(size_t)q * M + m];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mu = s1 * inv_n;
+  const float var = fmaxf(s2 * inv_n - mu * mu, 0.f);
+  stats[m] = make_float2(mu, rsqrtf(var + eps));
+}
+
+// After the patch embedding (whose epilogue is not a residual epilogue): bf16(x) and exact two-pass (mu, rstd)
+__global__ __launch_bounds__(256) void ln_cast_stats_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb,
+                                                            float2* __restrict__ stats, int rows, int dim, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * dim);
+  const int nq = dim >> 2;
+  float4 v[4];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      v[i] = xr[q];
+      sum += v[i].x + v[i].y + v[i].z + v[i].w;
+      uint2 pk;
+      pk.x = pack2(v[i].x, v[i].y);
+      pk.y = pack2(v[i].z, v[i].w);
+      reinterpret_cast<uint2*>(xb + (size_t)row * dim)[q] = pk;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)dim;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q < nq) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      var += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(var) / (float)dim + eps);
+  if (lane == 0) stats[row] = make_float2(mean, rstd);
+}
+
+// sum over the 16 lanes of a DPP row (rotations inside the row: v_add_f32 with a row_ror modifier, no LDS traffic)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
 // EPI_RESID epilogue of the 256x256 kernels: x[m, n] += gamma[n] * (acc + bias[n]) on a wave's
 // 128 x 64 block.  The fp32 residual stream is a read-modify-write of 8 B per element (1.1 GB per
 // launch); with the loads issued four at a time inside the row loop a tile's epilogue took 4 x 2
@@ -400,6 +520,21 @@ __device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4
 // compiler assumes there is no ">64-bit store data overwritten by the next VALU" hazard and emits
 // no wait state, but gfx950 showed exactly that corruption (lanes 12-15 of each 16, one dword).
 #define RS_ST(it, v) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), xr, loff + (it) * rstep, 0, 0)
+// LayerNorm producer side: bf16 copy of the new row piece (16 lanes x 8 B = 128 B per row) and the row's partial
+// (sum, sum of squares) over this wave's 64 columns: xor-reduce over the 16 lanes that hold the row
+#define RS_LN(it, o)                                                                                    \
+  do {                                                                                                  \
+    const int row_ = mb + (it) * 4 + g;                                                                 \
+    uint2 pk_;                                                                                          \
+    pk_.x = pack2((o).x, (o).y);                                                                        \
+    pk_.y = pack2((o).z, (o).w);                                                                        \
+    *reinterpret_cast<uint2*>(p.xb + (size_t)row_ * p.N + nb + c4) = pk_;                               \
+    float s1_ = ((o).x + (o).y) + ((o).z + (o).w);                                                      \
+    float s2_ = ((o).x * (o).x + (o).y * (o).y) + ((o).z * (o).z + (o).w * (o).w);                      \
+    s1_ = row16_sum(s1_);                                                                               \
+    s2_ = row16_sum(s2_);                                                                               \
+    if (lc == 0) p.st_part[(size_t)(nb >> 6) * p.M + row_] = make_float2(s1_, s2_);                     \
+  } while (0)
   float4 xl[16], xh[16];
 #pragma unroll
   for (int it = 0; it < 16; ++it) xl[it] = RS_LD(it);
@@ -425,6 +560,7 @@ __device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4
     o.z += gm.z * v.z;
     o.w += gm.w * v.w;
     RS_ST(it, o);
+    if (p.xb != nullptr) RS_LN(it, o);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own reads of the block are complete
 #pragma unroll
@@ -443,9 +579,11 @@ __device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4
     o.z += gm.z * v.z;
     o.w += gm.w * v.w;
     RS_ST(16 + it, o);
+    if (p.xb != nullptr) RS_LN(16 + it, o);
   }
 #undef RS_LD
 #undef RS_ST
+#undef RS_LN
 }
 
 // ---- 256x128x64 tile, 8 waves (4 x 2, 64x64 each), 3 LDS stages, counted vmcnt -------------
@@ -921,6 +1059,8 @@ int g_vit_group_bytes = 4800 * 1024;
 int g_vit_mblock = 0;
 // bf16 output stores with the non-temporal hint: measured no effect on time or FETCH_SIZE (kept as a knob)
 int g_vit_nt_store = 0;
+// LayerNorm folded into the qkv / fc1 GEMMs and the proj / fc2 residual epilogues (ln_fold)
+int g_vit_fuse_ln = 1;
 
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
@@ -975,12 +1115,12 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
 // im2col for the patch embedding (Conv2d 3 -> dim, kernel = patch, stride)
 // ======================================================================================
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img,
-                                                     bf16_t* __restrict__ col, DvtVitConfig c) {
-  const int t = blockIdx.x;  // token row in [0, batch*s_pad)
+                                                     bf16_t* __restrict__ col, DvtVitConfig c, int real_rows) {
+  const int t = blockIdx.x;  // token row in [0, batch*s_pad), then the phantom rows up to a whole 256-row tile
   const int b = t / c.s_pad, s = t - b * c.s_pad;
   bf16_t* dst = col + (size_t)t * c.k_patch;
   const int pp = c.patch * c.patch;
-  if (s < c.n_prefix || s >= c.n_tokens) {
+  if (t >= real_rows || s < c.n_prefix || s >= c.n_tokens) {
     for (int k = threadIdx.x; k < c.k_patch; k += 256) dst[k] = 0;
     return;
   }
@@ -1265,10 +1405,15 @@ inline int64_t up256b(int64_t x) { return (x + 255) / 256 * 256; }
 struct VitWork {
   float* x;
   bf16_t *xn, *qk, *vt, *hid, *col;
+  bf16_t* xb;       // bf16(x) for the LayerNorm-folded GEMMs
+  float2* st_part;  // [dim / 64][T] partial row sums from the residual epilogues
+  float2* stats;    // [T] (mean, rstd)
 };
 
 int64_t vit_carve(const DvtVitConfig* c, int batch, char* base, VitWork* w) {
-  const int64_t T = (int64_t)batch * c->s_pad;
+  // rows: whole 256-row GEMM tiles -- an odd batch (s_pad = 1408 = 5.5 tiles) gets 128 phantom rows, computed and
+  // never read, so that every batch takes the same kernels (results must not depend on how views are batched)
+  const int64_t T = ((int64_t)batch * c->s_pad + 255) / 256 * 256;
   int64_t o = 0;
   auto take = [&](int64_t bytes) {
     char* p = base ? base + o : nullptr;
@@ -1279,9 +1424,12 @@ int64_t vit_carve(const DvtVitConfig* c, int batch, char* base, VitWork* w) {
   t.x = (float*)take(T * c->dim * 4);
   t.xn = (bf16_t*)take(T * c->dim * 2);
   t.qk = (bf16_t*)take(T * 2 * c->dim * 2);
-  t.vt = (bf16_t*)take(T * c->dim * 2);
+  t.vt = (bf16_t*)take(((int64_t)batch + 1) * c->s_pad * c->dim * 2);  // the phantom rows' V^T lands in image `batch`
   t.hid = (bf16_t*)take(T * c->mlp_dim * 2);
   t.col = (bf16_t*)take(T * c->k_patch * 2);
+  t.xb = (bf16_t*)take(T * c->dim * 2);
+  t.st_part = (float2*)take((int64_t)(c->dim / 64) * T * 8);
+  t.stats = (float2*)take(T * 8);
   if (w) *w = t;
   return o;
 }
@@ -1298,6 +1446,10 @@ int check_vit_cfg(const DvtVitConfig* c) {
 }  // namespace
 
 int dvt_vit_tune(int v) {
+  if (v == -60 || v == -61) {  // LayerNorm kernels (-60) / folded into the GEMMs (-61, default)
+    g_vit_fuse_ln = v == -61;
+    return 0;
+  }
   if (v == -50 || v == -51) {  // non-temporal bf16 output stores off / on
     g_vit_nt_store = v == -51;
     return 0;
@@ -1408,7 +1560,7 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
   hipStream_t s = (hipStream_t)stream;
   VitWork k;
   vit_carve(c, batch, (char*)workspace, &k);
-  const int T = batch * c->s_pad, D = c->dim;
+  const int T = (batch * c->s_pad + 255) / 256 * 256, D = c->dim;  // incl. phantom rows (vit_carve)
   // algorithmic GEMM rows: the real tokens, not the rows padded to a multiple of 128
   const double rows = (double)batch * c->n_tokens;
 
@@ -1419,7 +1571,7 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
   } while (0)
 
   // patch embedding: im2col -> GEMM with the (+bias, +pos_embed, cls) epilogue
-  hipLaunchKernelGGL(im2col_kernel, dim3(T), dim3(256), 0, s, img, k.col, *c);
+  hipLaunchKernelGGL(im2col_kernel, dim3(T), dim3(256), 0, s, img, k.col, *c, batch * c->s_pad);
   DVT_CHECK_LAUNCH();
   {
     GemmBArgs a{};
@@ -1430,13 +1582,32 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
     a.work = 2.0 * (double)batch * c->grid_h * c->grid_w * D * (3.0 * c->patch * c->patch);
     DVT_TRY(launch_gemm<EPI_EMBED>(a, s));
   }
+  // LayerNorm folded into the GEMMs (ln_fold): needs the folded weights, the 8-phase kernel on every GEMM of the
+  // block (whole 256-row / 256-column tiles) and is switched by dvt_vit_tune; otherwise the LayerNorm kernels run.
+  bool fuse_ln = g_vit_fuse_ln && g_vit_gemm_variant == 4 && T % 256 == 0 && D % 256 == 0 && c->mlp_dim % 256 == 0 &&
+                 n_blocks > 0;
   for (int l = 0; l < n_blocks; ++l) {
     const DvtVitBlockWeights& bw = w->blocks[l];
-    DVT_TRY(dvt_vit_layernorm(k.x, bw.norm1_w, bw.norm1_b, k.xn, T, D, c->ln_eps, s));
+    fuse_ln = fuse_ln && bw.qkv_wf && bw.qkv_cs && bw.qkv_bf && bw.fc1_wf && bw.fc1_cs && bw.fc1_bf;
+  }
+  const int n_part = D / 64;
+  auto finalize_stats = [&]() {
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(dvt_cdiv(T, 256)), dim3(256), 0, s, (const float2*)k.st_part,
+                       n_part, T, 1.0f / (float)D, c->ln_eps, k.stats);
+  };
+  if (fuse_ln) {
+    hipLaunchKernelGGL(ln_cast_stats_kernel, dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, (const float*)k.x, k.xb, k.stats, T, D,
+                       c->ln_eps);
+    DVT_CHECK_LAUNCH();
+  }
+  for (int l = 0; l < n_blocks; ++l) {
+    const DvtVitBlockWeights& bw = w->blocks[l];
+    if (!fuse_ln) DVT_TRY(dvt_vit_layernorm(k.x, bw.norm1_w, bw.norm1_b, k.xn, T, D, c->ln_eps, s));
     {
       GemmBArgs a{};
-      a.A = k.xn; a.W = (const bf16_t*)bw.qkv_w; a.M = T; a.N = 3 * D; a.K = D;
-      a.bias = bw.qkv_b; a.out = k.qk; a.vt = k.vt;
+      a.A = fuse_ln ? k.xb : k.xn; a.W = (const bf16_t*)(fuse_ln ? bw.qkv_wf : bw.qkv_w); a.M = T; a.N = 3 * D; a.K = D;
+      a.bias = fuse_ln ? bw.qkv_bf : bw.qkv_b; a.out = k.qk; a.vt = k.vt;
+      if (fuse_ln) { a.ln_stats = k.stats; a.ln_cs = bw.qkv_cs; }
       a.dim = D; a.heads = c->heads; a.s_pad = c->s_pad; a.n_tokens = c->n_tokens;
       a.work = 2.0 * rows * 3.0 * D * D;
       DVT_TRY(launch_gemm<EPI_QKV>(a, s));
@@ -1446,14 +1617,21 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
       GemmBArgs a{};
       a.A = k.xn; a.W = (const bf16_t*)bw.proj_w; a.M = T; a.N = D; a.K = D;
       a.bias = bw.proj_b; a.x = k.x; a.gamma = bw.ls1;
+      if (fuse_ln) { a.xb = k.xb; a.st_part = k.st_part; }
       a.work = 2.0 * rows * D * D;
       DVT_TRY(launch_gemm<EPI_RESID>(a, s));
     }
-    DVT_TRY(dvt_vit_layernorm(k.x, bw.norm2_w, bw.norm2_b, k.xn, T, D, c->ln_eps, s));
+    if (fuse_ln) {
+      finalize_stats();
+      DVT_CHECK_LAUNCH();
+    } else {
+      DVT_TRY(dvt_vit_layernorm(k.x, bw.norm2_w, bw.norm2_b, k.xn, T, D, c->ln_eps, s));
+    }
     {
       GemmBArgs a{};
-      a.A = k.xn; a.W = (const bf16_t*)bw.fc1_w; a.M = T; a.N = c->mlp_dim; a.K = D;
-      a.bias = bw.fc1_b; a.out = k.hid;
+      a.A = fuse_ln ? k.xb : k.xn; a.W = (const bf16_t*)(fuse_ln ? bw.fc1_wf : bw.fc1_w); a.M = T; a.N = c->mlp_dim; a.K = D;
+      a.bias = fuse_ln ? bw.fc1_bf : bw.fc1_b; a.out = k.hid;
+      if (fuse_ln) { a.ln_stats = k.stats; a.ln_cs = bw.fc1_cs; }
       a.work = 2.0 * rows * (double)c->mlp_dim * D;
       DVT_TRY(launch_gemm<EPI_GELU>(a, s));
     }
@@ -1461,8 +1639,13 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
       GemmBArgs a{};
       a.A = k.hid; a.W = (const bf16_t*)bw.fc2_w; a.M = T; a.N = D; a.K = c->mlp_dim;
       a.bias = bw.fc2_b; a.x = k.x; a.gamma = bw.ls2;
+      if (fuse_ln && l + 1 < n_blocks) { a.xb = k.xb; a.st_part = k.st_part; }
       a.work = 2.0 * rows * (double)c->mlp_dim * D;
       DVT_TRY(launch_gemm<EPI_RESID>(a, s));
+    }
+    if (fuse_ln && l + 1 < n_blocks) {
+      finalize_stats();
+      DVT_CHECK_LAUNCH();
     }
   }
 #undef DVT_TRY

@@ -29,7 +29,7 @@ class VitConfig(C.Structure):
 class VitBlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "norm2_w", "norm2_b",
-        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_wf", "qkv_cs", "qkv_bf", "fc1_wf", "fc1_cs", "fc1_bf")]
 
 
 class VitWeights(C.Structure):
@@ -204,6 +204,16 @@ class HipViT:
             b.fc1_w, b.fc1_b = bf16(sd[p + "mlp.fc1.weight"]), f32(sd[p + "mlp.fc1.bias"])
             b.fc2_w, b.fc2_b = bf16(sd[p + "mlp.fc2.weight"]), f32(sd[p + "mlp.fc2.bias"])
             b.ls2 = f32(sd.get(p + "ls2.gamma", torch.ones(dim)))
+            if dtype == "bfloat16":
+                # LayerNorm folded into the consuming GEMM (include/dvt_vit.h): W' = bf16(gamma (.) W), its fp32 column
+                # sums, and b' = b + W beta -- computed once, in fp32, from the checkpoint tensors
+                for norm, lin, dst in (("norm1", "attn.qkv", "qkv"), ("norm2", "mlp.fc1", "fc1")):
+                    W = sd[p + lin + ".weight"].float()
+                    gamma, beta = sd[p + norm + ".weight"].float(), sd[p + norm + ".bias"].float()
+                    Wf = (W * gamma[None, :]).to(torch.bfloat16)
+                    setattr(b, dst + "_wf", bf16(Wf))
+                    setattr(b, dst + "_cs", f32(Wf.float().sum(1)))
+                    setattr(b, dst + "_bf", f32(sd[p + lin + ".bias"].float() + W @ beta))
         self.weights = w
         self._ws = None
         self._ws_batch = 0

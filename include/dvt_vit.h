@@ -55,6 +55,11 @@ typedef struct DvtVitBlockWeights {
   const void* fc1_w;  const float* fc1_b;   /* [mlp_dim, dim] */
   const void* fc2_w;  const float* fc2_b;   /* [dim, mlp_dim] */
   const float* ls2;
+  /* Optional (bf16 path; all six or none): LayerNorm folded into the GEMMs.  With W' = bf16(norm.weight (.) W)
+   * [out, in], cs[n] = sum_k W'[n][k] (fp32) and b' = b + W norm.bias, the qkv / fc1 GEMMs read bf16(x) directly and
+   * correct their accumulators with the row's (mean, rstd); the LayerNorm kernels of the block are not launched. */
+  const void* qkv_wf; const float* qkv_cs; const float* qkv_bf;   /* folded with norm1 */
+  const void* fc1_wf; const float* fc1_cs; const float* fc1_bf;   /* folded with norm2 */
 } DvtVitBlockWeights;
 
 typedef struct DvtVitWeights {

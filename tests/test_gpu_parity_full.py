@@ -222,7 +222,18 @@ def test_vit_outlier_stress(built_lib):
     x = torch.randn(2, 3, 518, 518, generator=g)
     want = ovit.forward_features(sd, x, 14, 14)
     # the residual stream really is heavy-tailed in the oracle
-    got = HipViT(sd, 14, 14, (518, 518), DEV).forward_features(x.to(DEV)).cpu()
+    vit = HipViT(sd, 14, 14, (518, 518), DEV)
+    got = vit.forward_features(x.to(DEV)).cpu()  # batch 2 -> whole 256-row tiles: LayerNorm folded into the GEMMs
+    try:
+        assert built_lib.dvt_tune_set(1, -60) == 0
+        got_ln = vit.forward_features(x.to(DEV)).cpu()  # the same weights through the LayerNorm kernels
+    finally:
+        built_lib.dvt_tune_set(1, -61)
+    assert not torch.equal(got, got_ln), "the folded path did not run"
+    cos_ln = per_patch_cos(got_ln, want)
+    print(f"[ViT outlier stress] LayerNorm kernels instead of folded GEMMs: cosine mean {cos_ln.mean():.6f} min "
+          f"{cos_ln.min():.6f}; rel-L2 {float((got_ln - want).norm() / want.norm()):.4f}; folded vs kernels rel-L2 "
+          f"{float((got - got_ln).norm() / got_ln.norm()):.4f}")
     cos = per_patch_cos(got, want)
     err = float((got - want).norm() / want.norm())
     # the hot channels dominate every token's norm after the final LayerNorm, so the full cosine is

@@ -243,3 +243,39 @@ def test_vit_forward_f32_vs_oracle(L, dim, depth, img, stride, n_reg):
           f"cos min {cos.min():.8f}")
     assert err < 2e-5 and cos.min() > 0.999999
     assert err < 0.02 * err_bf
+
+
+@pytest.mark.parametrize("depth,batch", [(3, 2), (12, 4)])
+def test_layernorm_folded_into_gemms(L, depth, batch):
+    """LayerNorm folded into the qkv / fc1 GEMMs and the proj / fc2 residual epilogues (dvt_vit.hip: ln_fold) against
+    the LayerNorm kernels (dvt_tune_set(1, -60)) and the fp32 oracle, ViT-B/14 geometry, random LayerNorm affine
+    parameters (so that gamma / beta folding is exercised), even batch = whole 256-row tiles."""
+    from dvt_amd.vit import HipViT, random_state_dict
+    sd = random_state_dict(768, depth, 14, 1370, seed=depth, well_conditioned=True)
+    g = torch.Generator().manual_seed(depth)
+    for k in list(sd):
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+            sd[k] = sd[k] * (1.0 + 0.3 * torch.randn(sd[k].shape, generator=g))
+        if k.endswith("norm1.bias") or k.endswith("norm2.bias"):
+            sd[k] = sd[k] + 0.2 * torch.randn(sd[k].shape, generator=g)
+    x = torch.randn(batch, 3, 518, 518, generator=g)
+    want = ovit.forward_features(sd, x[:2], 14, 14)
+    vit = HipViT(sd, 14, 14, (518, 518), DEV)
+    folded = vit.forward_features(x.to(DEV)).cpu()
+    try:
+        assert L.dvt_tune_set(1, -60) == 0
+        plain = vit.forward_features(x.to(DEV)).cpu()
+    finally:
+        L.dvt_tune_set(1, -61)
+    assert not torch.equal(folded, plain), "the folded path did not run"
+    cf = torch.nn.functional.cosine_similarity(folded[:2].reshape(-1, 768), want.reshape(-1, 768), dim=-1)
+    cp = torch.nn.functional.cosine_similarity(plain[:2].reshape(-1, 768), want.reshape(-1, 768), dim=-1)
+    rel = float((folded - plain).norm() / plain.norm())
+    print(f"LN folded (depth {depth}): vs oracle cos mean {cf.mean():.6f} min {cf.min():.6f} (LN kernels: {cp.mean():.6f} / "
+          f"{cp.min():.6f}); folded vs kernels rel-L2 {rel:.4f}")
+    assert cf.min() > cp.min() - 2e-4 and cf.mean() > cp.mean() - 1e-4 and cf.min() > 0.999
+    # an odd batch gets phantom rows up to a whole 256-row tile and takes the same kernels: batching changes nothing
+    one = vit.forward_features(x[:1].to(DEV)).cpu()
+    assert torch.equal(one, folded[:1])
+    three = vit.forward_features(x[:3].to(DEV), max_batch=3).cpu()
+    assert torch.equal(three, folded[:3])
