@@ -171,29 +171,37 @@ struct LazyArgs {
   const int32_t* ucount[DVT_FIT_BATCH_MAX];  //           [L]
   const float* neg_step;   // [steps of the call]  -(lr / bias_correction1)
   const float* inv_bc2s;   //                      1 / sqrt(bias_correction2)
+  const float* bc2s;       //                      sqrt(bias_correction2) (exact mode)
   uint32_t e0, n_entries;  // lazy entries: [e0, n_entries)
   int nt, l0;              // catch-up: list pitch, first level that has lazy entries
   int target;              // bring entries to `target` applied steps
   float one_m_b1, beta2, one_m_b2, eps, wd;
 };
 
+// EXACT: the dense kernel's own adam1() (IEEE division and square root): bit-identical to the dense sweep, ~3x the
+// instructions.  Default: v_rcp_f32 / v_sqrt_f32 (1 ulp each).
+template <bool EXACT>
 __device__ __forceinline__ void lazy_replay(const LazyArgs& a, const float* tab_ns, const float* tab_ib, int tab0,
                                             float& p, float& m, float& v, float g, int from, int to) {
   for (int s = from; s < to; ++s) {
     const float ns = s >= tab0 ? tab_ns[s - tab0] : a.neg_step[s];
-    const float ib = s >= tab0 ? tab_ib[s - tab0] : a.inv_bc2s[s];
-    const float gg = g + a.wd * p;
-    m = m + (gg - m) * a.one_m_b1;
-    v = v * a.beta2 + (a.one_m_b2 * gg) * gg;
-    const float den = __builtin_amdgcn_sqrtf(v) * ib + a.eps;
-    p = p + (ns * m) * __builtin_amdgcn_rcpf(den);
+    if (EXACT) {
+      adam1(p, m, v, g, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, a.bc2s[s], a.eps, ns);
+    } else {
+      const float ib = s >= tab0 ? tab_ib[s - tab0] : a.inv_bc2s[s];
+      const float gg = g + a.wd * p;
+      m = m + (gg - m) * a.one_m_b1;
+      v = v * a.beta2 + (a.one_m_b2 * gg) * gg;
+      const float den = __builtin_amdgcn_sqrtf(v) * ib + a.eps;
+      p = p + (ns * m) * __builtin_amdgcn_rcpf(den);
+    }
     g = 0.f;
   }
 }
 
 // FINAL = false: grid (nt * 8 / LAZY_BLOCK, lazy levels, fits), one entry of this step's list per 8 lanes.
 // FINAL = true:  grid (ceil((n_entries - e0) * 8 / LAZY_BLOCK), 1, fits), every lazy entry.
-template <bool FINAL>
+template <bool FINAL, bool EXACT>
 __global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
   __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
   const int fit = blockIdx.z;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
   const size_t q = (size_t)e * 8 + f;
   float p = a.P[fit][q], m = a.M[fit][q], v = a.V[fit][q];
   const float g = a.G[fit][q];
-  lazy_replay(a, tab_ns, tab_ib, tab0, p, m, v, g, from, a.target);
+  lazy_replay<EXACT>(a, tab_ns, tab_ib, tab0, p, m, v, g, from, a.target);
   a.P[fit][q] = p;
   a.M[fit][q] = m;
   a.V[fit][q] = v;
@@ -342,6 +350,7 @@ int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, c
   }
   a.neg_step = z->neg_step;
   a.inv_bc2s = z->inv_bc2s;
+  a.bc2s = z->bc2s;
   a.e0 = z->e0;
   a.n_entries = z->n_entries;
   a.nt = z->nt;
@@ -352,12 +361,19 @@ int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, c
   a.one_m_b2 = (float)(1.0 - z->beta2);
   a.eps = (float)z->eps;
   a.wd = (float)z->weight_decay;
+  const dim3 blk(LAZY_BLOCK);
   if (final_sweep) {
-    const long long lanes = (long long)(z->n_entries - z->e0) * 8;
-    hipLaunchKernelGGL(adam_lazy_kernel<true>, dim3((unsigned)dvt_cdiv(lanes, LAZY_BLOCK), 1, k), dim3(LAZY_BLOCK), 0, s, a);
+    const dim3 grid((unsigned)dvt_cdiv((long long)(z->n_entries - z->e0) * 8, LAZY_BLOCK), 1, k);
+    if (z->exact)
+      hipLaunchKernelGGL((adam_lazy_kernel<true, true>), grid, blk, 0, s, a);
+    else
+      hipLaunchKernelGGL((adam_lazy_kernel<true, false>), grid, blk, 0, s, a);
   } else {
-    hipLaunchKernelGGL(adam_lazy_kernel<false>, dim3((unsigned)dvt_cdiv((long long)z->nt * 8, LAZY_BLOCK), z->n_levels - z->l0, k),
-                       dim3(LAZY_BLOCK), 0, s, a);
+    const dim3 grid((unsigned)dvt_cdiv((long long)z->nt * 8, LAZY_BLOCK), z->n_levels - z->l0, k);
+    if (z->exact)
+      hipLaunchKernelGGL((adam_lazy_kernel<false, true>), grid, blk, 0, s, a);
+    else
+      hipLaunchKernelGGL((adam_lazy_kernel<false, false>), grid, blk, 0, s, a);
   }
   DVT_CHECK_LAUNCH();
   return 0;
@@ -368,30 +384,32 @@ int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, c
 namespace {
 struct TabChunk {
   int n, off;
-  float ns[448], ib[448];
+  float ns[320], ib[320], bc[320];
 };
-__global__ void lazy_tab_kernel(TabChunk c, float* neg_step, float* inv_bc2s) {
+__global__ void lazy_tab_kernel(TabChunk c, float* neg_step, float* inv_bc2s, float* bc2s) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i < c.n) {
     neg_step[c.off + i] = c.ns[i];
     inv_bc2s[c.off + i] = c.ib[i];
+    bc2s[c.off + i] = c.bc[i];
   }
 }
 }  // namespace
 
 int dvt_adam_lazy_tables(const double* h_lr, int step_begin, int step_end, double beta1, double beta2, float* neg_step,
-                         float* inv_bc2s, hipStream_t s) {
-  if (!h_lr || !neg_step || !inv_bc2s || step_end <= step_begin) return DVT_E_BADARG;
-  for (int o = step_begin; o < step_end; o += 448) {
+                         float* inv_bc2s, float* bc2s, hipStream_t s) {
+  if (!h_lr || !neg_step || !inv_bc2s || !bc2s || step_end <= step_begin) return DVT_E_BADARG;
+  for (int o = step_begin; o < step_end; o += 320) {
     TabChunk c{};
     c.off = o - step_begin;
-    c.n = step_end - o < 448 ? step_end - o : 448;
+    c.n = step_end - o < 320 ? step_end - o : 320;
     for (int i = 0; i < c.n; ++i) {
       const double t = (double)(o + i + 1);
       c.ns[i] = (float)(-(h_lr[o + i] / (1.0 - pow(beta1, t))));
       c.ib[i] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
+      c.bc[i] = (float)sqrt(1.0 - pow(beta2, t));
     }
-    hipLaunchKernelGGL(lazy_tab_kernel, dim3(7), dim3(64), 0, s, c, neg_step, inv_bc2s);
+    hipLaunchKernelGGL(lazy_tab_kernel, dim3(5), dim3(64), 0, s, c, neg_step, inv_bc2s, bc2s);
     DVT_CHECK_LAUNCH();
   }
   return 0;

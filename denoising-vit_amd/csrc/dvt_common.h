@@ -46,6 +46,8 @@ struct DvtAdamLazy {
   uint16_t* done[DVT_FIT_BATCH_MAX];
   const float* neg_step;
   const float* inv_bc2s;
+  const float* bc2s;
+  int exact;  // replay with the dense kernel's IEEE division / square root (bit-identical to the dense sweep)
   uint32_t e0, n_entries;
   int nt, l0, n_levels;
   double beta1, beta2, eps, weight_decay;
@@ -56,7 +58,7 @@ int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, c
                     const int32_t* const* ucount, hipStream_t s);
 
 int dvt_adam_lazy_tables(const double* h_lr, int step_begin, int step_end, double beta1, double beta2, float* neg_step,
-                         float* inv_bc2s, hipStream_t s);
+                         float* inv_bc2s, float* bc2s, hipStream_t s);
 
 // ---- batched fits: k images advanced by the SAME launches (blockIdx.y = fit) ----
 // The per-image fit is a chain of ~10 small dependent launches per Adam step; each launch pays a

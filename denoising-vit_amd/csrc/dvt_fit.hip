@@ -19,6 +19,7 @@
 
 extern int g_fit_sorted_grid;
 int g_fit_lazy_adam = 1;  // dvt_tune_set(9, 0): dense Adam over the whole arena
+int g_fit_lazy_exact = 0;  // dvt_tune_set(10, 1): replay with IEEE division / sqrt (bit-identical to the dense sweep)
 int g_fit_lazy_refresh = 32;  // dvt_tune_set(9, n >= 2): steps between full sweeps of the lazy region
 
 int g_adam_pingpong = 1;  // dvt_tune_set(8, 0): always sweep forward (A/B timing)
@@ -42,7 +43,7 @@ struct Work {
   uint32_t* gs_ukeys;
   int32_t* gs_ucount;
   uint16_t* lazy_done;
-  float *lazy_ns, *lazy_ib;
+  float *lazy_ns, *lazy_ib, *lazy_bc;
 };
 constexpr int GS_CHUNK = 128;  // steps per sort launch: 168 MB of lists per fit at batch 2048, 16 levels
 
@@ -122,6 +123,7 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
       t.lazy_done = reinterpret_cast<uint16_t*>(take(((int64_t)(c->grid.n_entries_total - e0) + 1) / 2));
       t.lazy_ns = take(c->num_iters);
       t.lazy_ib = take(c->num_iters);
+      t.lazy_bc = take(c->num_iters);
       lazy_bufs = true;
     }
   }
@@ -129,7 +131,7 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
     t.gs_ukeys = nullptr;
     t.gs_ucount = nullptr;
     t.lazy_done = nullptr;
-    t.lazy_ns = t.lazy_ib = nullptr;
+    t.lazy_ns = t.lazy_ib = t.lazy_bc = nullptr;
   }
   if (w) *w = t;
   return o;
@@ -490,8 +492,10 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
     lz.weight_decay = c->weight_decay;
     lz.neg_step = w[0].lazy_ns;
     lz.inv_bc2s = w[0].lazy_ib;
+    lz.bc2s = w[0].lazy_bc;
+    lz.exact = g_fit_lazy_exact;
     int rc = dvt_adam_lazy_tables(bufs[0]->h_lr, step_begin, step_end, c->beta1, c->beta2, w[0].lazy_ns, w[0].lazy_ib,
-                                  (hipStream_t)stream);
+                                  w[0].lazy_bc, (hipStream_t)stream);
     if (rc) return rc;
     for (int j = 0; j < k; ++j) {
       lz.p[j] = bufs[j]->params;

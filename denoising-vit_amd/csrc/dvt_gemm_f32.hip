@@ -735,6 +735,7 @@ extern int g_fit_fused_enable;
 extern int g_fit_sorted_grid;
 extern int g_fit_lazy_adam;
 extern int g_fit_lazy_refresh;
+extern int g_fit_lazy_exact;
 extern int g_adam_pingpong;
 
 extern "C" int dvt_tune_set(int key, int value) {
@@ -764,6 +765,10 @@ extern "C" int dvt_tune_set(int key, int value) {
   }
   if (key == 7) {
     g_fit_sorted_grid = value != 0;
+    return 0;
+  }
+  if (key == 10) {
+    g_fit_lazy_exact = value != 0;
     return 0;
   }
   if (key == 9) {

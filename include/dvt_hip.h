@@ -271,7 +271,10 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         2 / 3 = LDS stages of the stage-2 GEMMs (2, default: two workgroups per CU);
  * key 6 = bf16-mode fit step: 1 (default) the fused row kernel (dvt_fit_fused.hip), 0 = one launch per layer;
  * key 7 = fused step: 1 (default) hash-grid gradient gathered from per-step sorted corner lists, 0 = scattered with atomics;
- * key 9 = fused step: 1 (default) lazy-exact Adam over the fine hash-grid levels, 0 = dense Adam over the whole arena;
+ * key 9 = fused step: 1 (default) lazy Adam over the fine hash-grid levels, 0 = dense Adam over the whole arena,
+ *         n >= 2 = lazy with a full refresh every n steps (default 32);
+ * key 10 = lazy Adam replays with IEEE division / square root (1: bit-identical to the dense sweep, slower; default 0:
+ *         v_rcp_f32 / v_sqrt_f32, 1 ulp each);
  * key 8 = Adam sweeps the arena in alternating directions on consecutive steps (1, default) or always forward (0);
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);

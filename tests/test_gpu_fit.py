@@ -440,3 +440,40 @@ def test_batched_fused_fits_equal_separate_fits(built_lib):
         a, b = solo[j].infer(data[j][1][-1].to(DEV)), batched[j].infer(data[j][1][-1].to(DEV))
         assert per_patch_cos(a.cpu(), b.cpu()).min() > 0.9999
         assert float(batched[j].grads.abs().max()) == 0.0
+
+
+def test_long_run_many_list_chunks(built_lib):
+    """2500 steps = 20 chunks of sorted lists, 78 refreshes, replay tables longer than their LDS window.
+    * exact replay mode (dvt_tune_set(10, 1): IEEE division / sqrt, the dense kernel's own update function): every
+      never-touched entry ends BIT-IDENTICAL to the dense sweep in p, m and v -- step counters, pending gradients,
+      per-step scalar tables, refresh and chunk bookkeeping cannot be off by anything;
+    * default mode (1-ulp rcp / sqrt): the same entries' weight-decay jitter (|p| ~ 2e-4, never read by anything)
+      decorrelates over thousands of steps like any two runs would; what is read -- losses, the saved tensor -- agrees."""
+    V, H, C, T = 4, 37, 768, 2500
+    feats, xy = synthetic_image(V, H, H, C, seed=7)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    idx = np.random.RandomState(7).randint(0, f.shape[0], (T, 2048)).astype(np.int32)
+    dense = _bf16_run(built_lib, f, c, idx, T, knobs=[(9, 0)])
+    try:
+        exact = _bf16_run(built_lib, f, c, idx, T, knobs=[(10, 1)])
+    finally:
+        built_lib.dvt_tune_set(10, 0)
+    lazy = _bf16_run(built_lib, f, c, idx, T)
+    mask = _never_touched_mask(built_lib, lazy, c, idx)
+    assert int(mask.sum()) > 1000
+    n8 = mask.numel() * 8
+    for name in ("params", "adam_m", "adam_v"):
+        x, y = getattr(exact, name)[:n8].view(-1, 8)[mask], getattr(dense, name)[:n8].view(-1, 8)[mask]
+        assert torch.equal(x, y), f"exact lazy replay differs from the dense sweep in {name}"
+    jitter = float(dense.params[:n8].view(-1, 8)[mask].abs().max())
+    drift = float((lazy.params[:n8].view(-1, 8)[mask] - dense.params[:n8].view(-1, 8)[mask]).abs().max())
+    print(f"2500 steps: exact replay bit-identical on {int(mask.sum())} never-touched entries; fast replay: their jitter "
+          f"|p| <= {jitter:.2e}, max drift vs dense {drift:.2e}")
+    assert drift <= 4 * jitter
+    ref = dense.infer(xy[-1].to(DEV)).cpu()
+    ld = dense.loss_log()
+    for other in (exact, lazy):
+        assert float(other.grads.abs().max()) == 0.0 and int(other.touched.abs().max()) == 0
+        lo = other.loss_log()
+        assert abs(lo[T - 1]["loss"] - ld[T - 1]["loss"]) < 2e-2 * abs(ld[T - 1]["loss"])
+        assert per_patch_cos(other.infer(xy[-1].to(DEV)).cpu(), ref).min() > 0.995

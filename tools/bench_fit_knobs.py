@@ -19,8 +19,8 @@ xy = torch.rand(n_rows, 2, device=dev, generator=g)
 idx = torch.from_numpy(np.random.RandomState(0).randint(0, n_rows, (1000, 2048)).astype(np.int32)).to(dev)
 eng = FitEngine(FitSettings(num_iters=1000, warmup_iters=100, mlp_dtype="bfloat16"), n_rows, dev)
 L = _lib.lib()
-for name, knobs in (("default (lazy Adam, refresh 32)", {}), ("refresh 16", {9: 16}), ("refresh 64", {9: 64}), ("refresh 128", {9: 128}), ("refresh 24", {9: 24}), ("dense Adam, sorted grid", {9: 0})):
-    for k, v in {7: 1, 8: 1, 9: 32, **knobs}.items():
+for name, knobs in (("default (lazy Adam, refresh 32)", {}), ("exact replay (IEEE div/sqrt)", {10: 1}), ("exact replay, refresh 16", {10: 1, 9: 16}), ("dense Adam, sorted grid", {9: 0})):
+    for k, v in {7: 1, 8: 1, 9: 32, 10: 0, **knobs}.items():
         _lib.check(L.dvt_tune_set(k, v))
     for rep in range(2):
         eng.reset(g)
@@ -34,4 +34,5 @@ for name, knobs in (("default (lazy Adam, refresh 32)", {}), ("refresh 16", {9: 
     print(f"{name:32s}: phase 1 {ts[0]:7.1f} us/step, phase 2 {ts[1]:7.1f} us/step", flush=True)
 L.dvt_tune_set(7, 1)
 L.dvt_tune_set(9, 32)
+L.dvt_tune_set(10, 0)
 L.dvt_tune_set(8, 1)
