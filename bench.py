@@ -270,6 +270,11 @@ def main():
                                   f"fit MLP GEMMs {a.fit_dtype} operands / fp32 accumulate + outputs; hash grid, "
                                   "losses, Adam: fp32.  The reference's DEFAULT is --dtype float32 (see value_fp32_fit)",
                 "fit_dtype": a.fit_dtype,
+                "fit_step": ("bfloat16: fused row kernel, hash-grid gradient gathered from per-step sorted lists, dense Adam "
+                             "for coarse grid levels + MLPs + G, lazy Adam (same recurrence applied on demand, refresh every 32 "
+                             "steps, v_rcp / v_sqrt 1-ulp replay) for the fine grid levels; float32: layer-by-layer kernels, "
+                             "dense Adam"),
+                "extractor": "LayerNorm folded into the qkv / fc1 GEMMs (bf16 path); LayerNorm kernels in the fp32 path",
                 "weights": "random init (no network for checkpoints)",
                 "t_extract_s_serial": split["t_extract"], "t_fit_s_serial": split["t_fit"],
                 "pipeline_depth": a.pipeline_depth, "fit_batch": a.fit_batch,
