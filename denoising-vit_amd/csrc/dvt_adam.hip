@@ -78,15 +78,16 @@ struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
 // HBM-bound update overlaps the MFMA-bound GEMM instead of time-slicing whole CUs (at 52 registers, with the
 // gather path compiled in, nothing fitted and the pipelined image time was t_extract + 0.96 t_fit).
 template <bool GATHER>
-__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, AdamGather gr) {
-  float4* __restrict__ P = q.P[blockIdx.y];
-  float4* __restrict__ M = q.M[blockIdx.y];
-  float4* __restrict__ V = q.V[blockIdx.y];
-  float4* __restrict__ G = q.G[blockIdx.y];
-  uint32_t* __restrict__ touched = q.touched[blockIdx.y];
+__device__ __forceinline__ void adam_dense_body(const AdamKArgs& a, const AdamPtrs& q, const AdamGather& gr, int bx,
+                                                int nbx, int fit) {
+  float4* __restrict__ P = q.P[fit];
+  float4* __restrict__ M = q.M[fit];
+  float4* __restrict__ V = q.V[fit];
+  float4* __restrict__ G = q.G[fit];
+  uint32_t* __restrict__ touched = q.touched[fit];
   const int lane = threadIdx.x & 63;
-  const long long wave_global = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long wave_stride = (long long)gridDim.x * 4;
+  const long long wave_global = (long long)bx * 4 + (threadIdx.x >> 6);
+  const long long wave_stride = (long long)nbx * 4;
   const float one_m_b1 = a.one_m_b1, one_m_b2 = a.one_m_b2;
   const long long n_chunks = a.chunk0[a.n_active];
   for (long long ci = wave_global; ci < n_chunks; ci += wave_stride) {
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
     if (GATHER && gathered) {
       // dG[row] = sum of the d_pred rows of this step's samples on lattice row `row`
       const int e = (int)(q - gr.q_begin) * 4, row = e / gr.c, col4 = (e - row * gr.c) >> 2;
-      const int32_t* offs = gr.offs[blockIdx.y];
-      const uint16_t* perm = gr.perm[blockIdx.y];
-      const float4* rows = gr.rows[blockIdx.y];
+      const int32_t* offs = gr.offs[fit];
+      const uint16_t* perm = gr.perm[fit];
+      const float4* rows = gr.rows[fit];
       const int cq = gr.c >> 2;
       const bool real = row < gr.lattice;  // alignment padding behind the last row has no gradient
       for (int o = real ? offs[row] : 0, oe = real ? offs[row + 1] : 0; o < oe; ++o) {
@@ -138,6 +139,11 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, Adam
     if (has || (sparse && a.zero_all)) G[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero_grad
     if (sparse && word != 0u && lane == 0) touched[q0 >> 6] = 0u;
   }
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void adam_kernel(AdamKArgs a, AdamPtrs q, AdamGather gr) {
+  adam_dense_body<GATHER>(a, q, gr, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // ==========================================================================================================
@@ -216,23 +222,21 @@ __device__ __forceinline__ void lazy_replay(const LazyArgs& a, const float* tab_
 // FINAL = false: grid (nt * 4 / LAZY_BLOCK, lazy levels, fits), one entry of this step's list per 4 lanes.
 // FINAL = true:  grid (ceil((n_entries - e0) * 4 / LAZY_BLOCK), 1, fits), every lazy entry.
 template <bool FINAL, bool EXACT>
-__global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
-  __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
-  const int fit = blockIdx.z;
+__device__ __forceinline__ void adam_lazy_body(const LazyArgs& a, int bx, int by, int fit, float* tab_ns, float* tab_ib) {
   const int tab0 = a.target > LAZY_TAB ? a.target - LAZY_TAB : 0;
   for (int i = threadIdx.x; i < a.target - tab0; i += LAZY_BLOCK) {
     tab_ns[i] = a.neg_step[tab0 + i];
     tab_ib[i] = a.inv_bc2s[tab0 + i];
   }
   __syncthreads();
-  const long long i = (long long)blockIdx.x * LAZY_BLOCK + threadIdx.x;
+  const long long i = (long long)bx * LAZY_BLOCK + threadIdx.x;
   const int f = (int)(i & 3);  // feature pair
   uint32_t e;
   if (FINAL) {
     if (i >> 2 >= (long long)(a.n_entries - a.e0)) return;
     e = a.e0 + (uint32_t)(i >> 2);
   } else {
-    const int l = a.l0 + blockIdx.y;
+    const int l = a.l0 + by;
     if ((i >> 2) >= a.ucount[fit][l]) return;
     e = a.ukeys[fit][(size_t)l * a.nt + (i >> 2)];
     if (e < a.e0) return;
@@ -254,6 +258,32 @@ __global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
   if (f == 0) a.done[fit][e - a.e0] = (uint16_t)a.target;
 }
 
+template <bool FINAL, bool EXACT>
+__global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
+  __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
+  adam_lazy_body<FINAL, EXACT>(a, blockIdx.x, blockIdx.y, blockIdx.z, tab_ns, tab_ib);
+}
+
+// ONE launch for the step's dense Adam (HBM-bound) and the catch-up of the NEXT step's entries (VALU-bound): they touch
+// disjoint parameters, both depend only on the backward pass that just finished, and side by side they take the longer
+// of the two instead of the sum.  The first blocks are the (level, list chunk) blocks of the catch-up, the last
+// dense_blocks sweep the dense segments.
+template <bool EXACT>
+__global__ __launch_bounds__(256) void adam_dense_lazy_kernel(AdamKArgs a, AdamPtrs q, LazyArgs z, int dense_blocks,
+                                                              int lazy_bx) {
+  __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
+  // catch-up blocks FIRST: their replay chains are the long pole, the streaming blocks fill in around them
+  const int lazy_blocks = (int)gridDim.x - dense_blocks;
+  if ((int)blockIdx.x >= lazy_blocks) {
+    AdamGather none{};
+    none.q_begin = none.q_end = -1;
+    adam_dense_body<false>(a, q, none, (int)blockIdx.x - lazy_blocks, dense_blocks, blockIdx.y);
+    return;
+  }
+  const int b = (int)blockIdx.x;
+  adam_lazy_body<false, EXACT>(z, b % lazy_bx, b / lazy_bx, blockIdx.y, tab_ns, tab_ib);
+}
+
 }  // namespace
 
 int dvt_adam_tune(int zero_all) {
@@ -266,9 +296,15 @@ extern "C" int dvt_adam_step(const DvtAdamArgs* h, float* p, float* m, float* v,
   return dvt_adam_step_k(h, 1, &p, &m, &v, &g, &touched, (hipStream_t)stream);
 }
 
+namespace {
+int make_lazy_args(const DvtAdamLazy* z, int k, bool final_sweep, int target, const uint32_t* const* ukeys,
+                   const int32_t* const* ucount, LazyArgs* out);
+}
+
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
-                    const DvtAdamRowGather* gather, int reverse) {
+                    const DvtAdamRowGather* gather, int reverse, const DvtAdamLazy* lazy_next, int lazy_target,
+                    const uint32_t* const* lazy_ukeys, const int32_t* const* lazy_ucount) {
   if (!h || k < 1 || k > DVT_FIT_BATCH_MAX || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
     return DVT_E_BADARG;
   if (h->sparse_end & 255) return DVT_E_BADARG;
@@ -339,7 +375,17 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
   if (blocks > 256 * 16) blocks = 256 * 16;
   {
     DvtProbeScope probe(DVT_PROBE_ADAM, stream, work * k);
-    if (gr.q_end > gr.q_begin)
+    if (lazy_next != nullptr && gr.q_end <= gr.q_begin) {  // + the catch-up of the next step's entries, same launch
+      LazyArgs z{};
+      const int rc = make_lazy_args(lazy_next, k, false, lazy_target, lazy_ukeys, lazy_ucount, &z);
+      if (rc) return rc;
+      const int lazy_bx = dvt_cdiv((long long)lazy_next->nt * 4, LAZY_BLOCK);
+      const unsigned total = (unsigned)blocks + (unsigned)(lazy_bx * (lazy_next->n_levels - lazy_next->l0));
+      if (lazy_next->exact)
+        hipLaunchKernelGGL(adam_dense_lazy_kernel<true>, dim3(total, k), dim3(256), 0, stream, a, q, z, (int)blocks, lazy_bx);
+      else
+        hipLaunchKernelGGL(adam_dense_lazy_kernel<false>, dim3(total, k), dim3(256), 0, stream, a, q, z, (int)blocks, lazy_bx);
+    } else if (gr.q_end > gr.q_begin)
       hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
     else
       hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
@@ -349,8 +395,9 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
 }
 
 // ---- lazy-exact Adam: host side (see the kernel comment above) ----------------------------------------------
-int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, const uint32_t* const* ukeys,
-                    const int32_t* const* ucount, hipStream_t s) {
+namespace {
+int make_lazy_args(const DvtAdamLazy* z, int k, bool final_sweep, int target, const uint32_t* const* ukeys,
+                   const int32_t* const* ucount, LazyArgs* out) {
   if (!z || k < 1 || k > DVT_FIT_BATCH_MAX || target < 1 || target > 65535 || z->n_entries <= z->e0) return DVT_E_BADARG;
   LazyArgs a{};
   for (int f = 0; f < k; ++f) {
@@ -379,6 +426,18 @@ int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, c
   a.one_m_b2 = (float)(1.0 - z->beta2);
   a.eps = (float)z->eps;
   a.wd = (float)z->weight_decay;
+  *out = a;
+  return 0;
+}
+}  // namespace
+
+int dvt_adam_lazy_k(const DvtAdamLazy* z, int k, bool final_sweep, int target, const uint32_t* const* ukeys,
+                    const int32_t* const* ucount, hipStream_t s) {
+  LazyArgs a{};
+  {
+    const int rc = make_lazy_args(z, k, final_sweep, target, ukeys, ucount, &a);
+    if (rc) return rc;
+  }
   const dim3 blk(LAZY_BLOCK);
   if (final_sweep) {
     const dim3 grid((unsigned)dvt_cdiv((long long)(z->n_entries - z->e0) * 4, LAZY_BLOCK), 1, k);

@@ -85,9 +85,14 @@ struct DvtAdamRowGather {
   const uint16_t* perm[DVT_FIT_BATCH_MAX];  // [batch] of this step, per fit
   const float* rows[DVT_FIT_BATCH_MAX];     // d_pred [batch, c], per fit
 };
+// lazy_next != nullptr: the same launch also runs the lazy-Adam catch-up of the NEXT step's distinct entries
+// (dvt_adam_lazy_k(lazy_next, k, false, lazy_target, lazy_ukeys, lazy_ucount) side by side with the dense sweep)
+struct DvtAdamLazy;
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
-                    const DvtAdamRowGather* gather = nullptr, int reverse = 0);
+                    const DvtAdamRowGather* gather = nullptr, int reverse = 0, const DvtAdamLazy* lazy_next = nullptr,
+                    int lazy_target = 0, const uint32_t* const* lazy_ukeys = nullptr,
+                    const int32_t* const* lazy_ucount = nullptr);
 // offs [steps, lattice + 1] / perm [steps, batch] for steps [0, steps) of idx [steps, batch]; lattice <= 8192,
 // batch <= 65535
 int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,

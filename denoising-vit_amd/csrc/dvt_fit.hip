@@ -19,6 +19,7 @@
 
 extern int g_fit_sorted_grid;
 int g_fit_lazy_adam = 1;  // dvt_tune_set(9, 0): dense Adam over the whole arena
+int g_fit_lazy_merge = 1;  // dvt_tune_set(11, 0): catch-up as its own launch
 int g_fit_lazy_exact = 0;  // dvt_tune_set(10, 1): replay with IEEE division / sqrt (bit-identical to the dense sweep)
 int g_fit_lazy_refresh = 32;  // dvt_tune_set(9, n >= 2): steps between full sweeps of the lazy region
 
@@ -220,9 +221,10 @@ int check_bufs(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin, in
 // launch covers all k fits (blockIdx.y = fit; the grouped GEMM launch simply carries k x the
 // problems).  k = 1 is the reference's per-image loop.
 int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const Work* ws, int step,
-             int gs_local, uint32_t lazy_e0, hipStream_t s) {
+             int gs_local, uint32_t lazy_e0, const DvtAdamLazy* lazy_next, int lazy_target, hipStream_t s) {
   // gs_local: index of `step` inside the current chunk of sorted grid lists, or -1;  lazy_e0: first grid entry the lazy
-  // Adam kernels own (0xffffffff: none, dense Adam steps everything)
+  // Adam kernels own (0xffffffff: none, dense Adam steps everything);  lazy_next: run the catch-up of step + 1 (same
+  // chunk of lists, relative step count lazy_target) inside this step's Adam launch
   const int B = c->batch, C = c->feat_dim, H = c->hidden, R = c->res_hidden;
   const int E = c->grid.n_levels * c->grid.n_features;
   const bool phase2 = step > c->switch_step;
@@ -416,7 +418,17 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
       gather.rows[f] = ws[f].dF;
     }
   }
-  DVT_TRY(dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather, g_adam_pingpong ? (step & 1) : 0));
+  {
+    const uint32_t* uk[KM];
+    const int32_t* uc[KM];
+    if (lazy_next != nullptr)
+      for (int f = 0; f < k; ++f) {
+        uk[f] = ws[f].gs_ukeys + (size_t)(gs_local + 1) * c->grid.n_levels * 4 * B;
+        uc[f] = ws[f].gs_ucount + (size_t)(gs_local + 1) * c->grid.n_levels;
+      }
+    DVT_TRY(dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather, g_adam_pingpong ? (step & 1) : 0, lazy_next,
+                            lazy_target, uk, uc));
+  }
   if (fused) {  // bf16 shadow copies of the weights Adam just stepped, for the next step's row kernel
     const float* pp[KM];
     for (int f = 0; f < k; ++f) pp[f] = P[f];
@@ -508,6 +520,7 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
       if (e != hipSuccess) return (int)e;
     }
   }
+  bool merged_catchup = false;  // the previous step's Adam launch already brought this step's entries up to date
   for (int step = step_begin; step < step_end; ++step) {
     int gs_local = -1;
     if (sorted_lists) {
@@ -543,7 +556,7 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
       // GS_CHUNK steps) -- work is only moved, not added.
       int rc = dvt_adam_lazy_k(&lz, k, true, step - step_begin, nullptr, nullptr, (hipStream_t)stream);
       if (rc) return rc;
-    } else if (lazy && step > step_begin) {  // bring the entries this step reads up to date (steps < step applied)
+    } else if (lazy && step > step_begin && !merged_catchup) {  // bring the entries this step reads up to date
       const uint32_t* uk[DVT_FIT_BATCH_MAX];
       const int32_t* uc[DVT_FIT_BATCH_MAX];
       for (int j = 0; j < k; ++j) {
@@ -553,7 +566,12 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
       int rc = dvt_adam_lazy_k(&lz, k, false, step - step_begin, uk, uc, (hipStream_t)stream);
       if (rc) return rc;
     }
-    int rc = fit_step(c, k, bufs, w, step, gs_local, lazy_e0, (hipStream_t)stream);
+    // the catch-up of step + 1 rides in this step's Adam launch when its lists exist already (same chunk) and step + 1
+    // is not a refresh step
+    const int rel_next = step + 1 - step_begin;
+    merged_catchup = lazy && g_fit_lazy_merge && step + 1 < step_end && gs_local + 1 < GS_CHUNK &&
+                     rel_next % g_fit_lazy_refresh != 0;
+    int rc = fit_step(c, k, bufs, w, step, gs_local, lazy_e0, merged_catchup ? &lz : nullptr, rel_next, (hipStream_t)stream);
     if (rc) return rc;
   }
   if (lazy) {  // the arena is exact at every call boundary: every lazy entry through the last step of this call
