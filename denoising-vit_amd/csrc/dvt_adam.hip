@@ -77,9 +77,14 @@ struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
 // (two 232-register waves per SIMD) leaves free -- one Adam wave per SIMD then shares the CU with it and the
 // HBM-bound update overlaps the MFMA-bound GEMM instead of time-slicing whole CUs (at 52 registers, with the
 // gather path compiled in, nothing fitted and the pipelined image time was t_extract + 0.96 t_fit).
-template <bool GATHER>
+struct AdamShadow {  // bf16 shadow copies of the MLP weights, maintained by the dense sweep itself (SHADOW = true)
+  DvtShadowLayout L;
+  uint16_t* sh[DVT_FIT_BATCH_MAX];
+};
+
+template <bool GATHER, bool SHADOW = false>
 __device__ __forceinline__ void adam_dense_body(const AdamKArgs& a, const AdamPtrs& q, const AdamGather& gr, int bx,
-                                                int nbx, int fit) {
+                                                int nbx, int fit, const AdamShadow* shw = nullptr) {
   float4* __restrict__ P = q.P[fit];
   float4* __restrict__ M = q.M[fit];
   float4* __restrict__ V = q.V[fit];
@@ -136,6 +141,9 @@ __device__ __forceinline__ void adam_dense_body(const AdamKArgs& a, const AdamPt
     P[q] = p;
     M[q] = m;
     V[q] = v;
+    if constexpr (SHADOW) {  // wave-uniform: the chunk lies inside the shadowed matrices or not
+      if (q0 * 4 >= shw->L.lo && q0 * 4 < shw->L.hi) dvt_shadow_store(shw->L, shw->sh[fit], q * 4, p);
+    }
     if (has || (sparse && a.zero_all)) G[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero_grad
     if (sparse && word != 0u && lane == 0) touched[q0 >> 6] = 0u;
   }
@@ -268,11 +276,27 @@ __global__ __launch_bounds__(LAZY_BLOCK) void adam_lazy_kernel(LazyArgs a) {
 // disjoint parameters, both depend only on the backward pass that just finished, and side by side they take the longer
 // of the two instead of the sum.  The first blocks are the (level, list chunk) blocks of the catch-up, the last
 // dense_blocks sweep the dense segments.
+template <bool EXACT, bool SHADOW>
+__device__ __forceinline__ void adam_dense_lazy_body(const AdamKArgs& a, const AdamPtrs& q, const LazyArgs& z, int dense_blocks,
+                                                     int lazy_bx, const AdamShadow* shw, float* tab_ns, float* tab_ib) {
+  // catch-up blocks FIRST: their replay chains are the long pole, the streaming blocks fill in around them
+  const int lazy_blocks = (int)gridDim.x - dense_blocks;
+  if ((int)blockIdx.x >= lazy_blocks) {
+    AdamGather none{};
+    none.q_begin = none.q_end = -1;
+    adam_dense_body<false, SHADOW>(a, q, none, (int)blockIdx.x - lazy_blocks, dense_blocks, blockIdx.y, shw);
+    return;
+  }
+  const int b = (int)blockIdx.x;
+  adam_lazy_body<false, EXACT>(z, b % lazy_bx, b / lazy_bx, blockIdx.y, tab_ns, tab_ib);
+}
+
+// (two kernels, not one with a flag: the shadow layout among the arguments costs registers, and the plain variant must
+// stay at 48 VGPRs -- what the extractor's GEMM waves leave free on a SIMD)
 template <bool EXACT>
 __global__ __launch_bounds__(256) void adam_dense_lazy_kernel(AdamKArgs a, AdamPtrs q, LazyArgs z, int dense_blocks,
                                                               int lazy_bx) {
   __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
-  // catch-up blocks FIRST: their replay chains are the long pole, the streaming blocks fill in around them
   const int lazy_blocks = (int)gridDim.x - dense_blocks;
   if ((int)blockIdx.x >= lazy_blocks) {
     AdamGather none{};
@@ -282,6 +306,12 @@ __global__ __launch_bounds__(256) void adam_dense_lazy_kernel(AdamKArgs a, AdamP
   }
   const int b = (int)blockIdx.x;
   adam_lazy_body<false, EXACT>(z, b % lazy_bx, b / lazy_bx, blockIdx.y, tab_ns, tab_ib);
+}
+template <bool EXACT>
+__global__ __launch_bounds__(256) void adam_dense_lazy_shadow_kernel(AdamKArgs a, AdamPtrs q, LazyArgs z, int dense_blocks,
+                                                                     int lazy_bx, AdamShadow shw) {
+  __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
+  adam_dense_lazy_body<EXACT, true>(a, q, z, dense_blocks, lazy_bx, &shw, tab_ns, tab_ib);
 }
 
 }  // namespace
@@ -304,7 +334,8 @@ int make_lazy_args(const DvtAdamLazy* z, int k, bool final_sweep, int target, co
 int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* m, float* const* v,
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
                     const DvtAdamRowGather* gather, int reverse, const DvtAdamLazy* lazy_next, int lazy_target,
-                    const uint32_t* const* lazy_ukeys, const int32_t* const* lazy_ucount) {
+                    const uint32_t* const* lazy_ukeys, const int32_t* const* lazy_ucount, const DvtShadowLayout* shadow_L,
+                    uint16_t* const* shadow) {
   if (!h || k < 1 || k > DVT_FIT_BATCH_MAX || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
     return DVT_E_BADARG;
   if (h->sparse_end & 255) return DVT_E_BADARG;
@@ -381,10 +412,21 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
       if (rc) return rc;
       const int lazy_bx = dvt_cdiv((long long)lazy_next->nt * 4, LAZY_BLOCK);
       const unsigned total = (unsigned)blocks + (unsigned)(lazy_bx * (lazy_next->n_levels - lazy_next->l0));
-      if (lazy_next->exact)
-        hipLaunchKernelGGL(adam_dense_lazy_kernel<true>, dim3(total, k), dim3(256), 0, stream, a, q, z, (int)blocks, lazy_bx);
+      AdamShadow shw{};
+      const bool with_shadow = shadow_L != nullptr && shadow != nullptr;
+      if (with_shadow) {
+        shw.L = *shadow_L;
+        for (int f = 0; f < k; ++f) shw.sh[f] = shadow[f];
+      }
+      const dim3 grid(total, k), blk(256);
+      if (lazy_next->exact && with_shadow)
+        hipLaunchKernelGGL((adam_dense_lazy_shadow_kernel<true>), grid, blk, 0, stream, a, q, z, (int)blocks, lazy_bx, shw);
+      else if (lazy_next->exact)
+        hipLaunchKernelGGL((adam_dense_lazy_kernel<true>), grid, blk, 0, stream, a, q, z, (int)blocks, lazy_bx);
+      else if (with_shadow)
+        hipLaunchKernelGGL((adam_dense_lazy_shadow_kernel<false>), grid, blk, 0, stream, a, q, z, (int)blocks, lazy_bx, shw);
       else
-        hipLaunchKernelGGL(adam_dense_lazy_kernel<false>, dim3(total, k), dim3(256), 0, stream, a, q, z, (int)blocks, lazy_bx);
+        hipLaunchKernelGGL((adam_dense_lazy_kernel<false>), grid, blk, 0, stream, a, q, z, (int)blocks, lazy_bx);
     } else if (gr.q_end > gr.q_begin)
       hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks, k), dim3(256), 0, stream, a, q, gr);
     else

@@ -92,7 +92,8 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
                     const DvtAdamRowGather* gather = nullptr, int reverse = 0, const DvtAdamLazy* lazy_next = nullptr,
                     int lazy_target = 0, const uint32_t* const* lazy_ukeys = nullptr,
-                    const int32_t* const* lazy_ucount = nullptr);
+                    const int32_t* const* lazy_ucount = nullptr, const struct DvtShadowLayout* shadow_L = nullptr,
+                    uint16_t* const* shadow = nullptr);  // + (with lazy_next) the bf16 weight shadow stored by the sweep
 // offs [steps, lattice + 1] / perm [steps, batch] for steps [0, steps) of idx [steps, batch]; lattice <= 8192,
 // batch <= 65535
 int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,

@@ -19,6 +19,7 @@
 
 extern int g_fit_sorted_grid;
 int g_fit_lazy_adam = 1;  // dvt_tune_set(9, 0): dense Adam over the whole arena
+int g_fit_shadow_in_adam = 1;  // dvt_tune_set(12, 0): shadow_build_kernel after every Adam launch
 int g_fit_lazy_merge = 1;  // dvt_tune_set(11, 0): catch-up as its own launch
 int g_fit_lazy_exact = 0;  // dvt_tune_set(10, 1): replay with IEEE division / sqrt (bit-identical to the dense sweep)
 int g_fit_lazy_refresh = 32;  // dvt_tune_set(9, n >= 2): steps between full sweeps of the lazy region
@@ -426,8 +427,10 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
         uk[f] = ws[f].gs_ukeys + (size_t)(gs_local + 1) * c->grid.n_levels * 4 * B;
         uc[f] = ws[f].gs_ucount + (size_t)(gs_local + 1) * c->grid.n_levels;
       }
+    const bool shadow_in_adam = fused && lazy_next != nullptr && g_fit_shadow_in_adam;
     DVT_TRY(dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather, g_adam_pingpong ? (step & 1) : 0, lazy_next,
-                            lazy_target, uk, uc));
+                            lazy_target, uk, uc, shadow_in_adam ? &shl : nullptr, shadow_in_adam ? shadow : nullptr));
+    if (shadow_in_adam) return 0;
   }
   if (fused) {  // bf16 shadow copies of the weights Adam just stepped, for the next step's row kernel
     const float* pp[KM];

@@ -737,6 +737,7 @@ extern int g_fit_lazy_adam;
 extern int g_fit_lazy_refresh;
 extern int g_fit_lazy_exact;
 extern int g_fit_lazy_merge;
+extern int g_fit_shadow_in_adam;
 extern int g_adam_pingpong;
 
 extern "C" int dvt_tune_set(int key, int value) {
@@ -774,6 +775,10 @@ extern "C" int dvt_tune_set(int key, int value) {
   }
   if (key == 11) {
     g_fit_lazy_merge = value != 0;
+    return 0;
+  }
+  if (key == 12) {
+    g_fit_shadow_in_adam = value != 0;
     return 0;
   }
   if (key == 9) {

@@ -273,6 +273,7 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * key 7 = fused step: 1 (default) hash-grid gradient gathered from per-step sorted corner lists, 0 = scattered with atomics;
  * key 9 = fused step: 1 (default) lazy Adam over the fine hash-grid levels, 0 = dense Adam over the whole arena,
  *         n >= 2 = lazy with a full refresh every n steps (default 32);
+ * key 12 = the merged Adam launch also stores the bf16 weight shadow (1, default) or shadow_build_kernel runs (0);
  * key 11 = the lazy catch-up of the next step shares the Adam launch (1, default) or is its own launch (0);
  * key 10 = lazy Adam replays with IEEE division / square root (1: bit-identical to the dense sweep, slower; default 0:
  *         v_rcp_f32 / v_sqrt_f32, 1 ulp each);

@@ -19,8 +19,8 @@ xy = torch.rand(n_rows, 2, device=dev, generator=g)
 idx = torch.from_numpy(np.random.RandomState(0).randint(0, n_rows, (1000, 2048)).astype(np.int32)).to(dev)
 eng = FitEngine(FitSettings(num_iters=1000, warmup_iters=100, mlp_dtype="bfloat16"), n_rows, dev)
 L = _lib.lib()
-for name, knobs in (("default (merged catch-up)", {}), ("catch-up as its own launch", {11: 0}), ("default again", {}), ("exact replay", {10: 1})):
-    for k, v in {7: 1, 8: 1, 9: 32, 10: 0, 11: 1, **knobs}.items():
+for name, knobs in (("default (shadow in Adam)", {}), ("shadow_build_kernel", {12: 0}), ("default again", {}), ("separate catch-up + shadow", {11: 0})):
+    for k, v in {7: 1, 8: 1, 9: 32, 10: 0, 11: 1, 12: 1, **knobs}.items():
         _lib.check(L.dvt_tune_set(k, v))
     for rep in range(2):
         eng.reset(g)
@@ -36,4 +36,5 @@ L.dvt_tune_set(7, 1)
 L.dvt_tune_set(9, 32)
 L.dvt_tune_set(10, 0)
 L.dvt_tune_set(11, 1)
+L.dvt_tune_set(12, 1)
 L.dvt_tune_set(8, 1)
