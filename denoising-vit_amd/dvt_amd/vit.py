@@ -244,6 +244,10 @@ class HipViT:
             raise _lib.DvtError("out must be a contiguous [B, grid_h, grid_w, dim] fp32 tensor")
         if self.dtype == "float32":
             max_batch = min(max_batch, 32)  # fp32 activations: 32 views keep the scratch at ~1.3 GB
+        # equal-sized launches: 769 views at max_batch 128 would be 6 x 128 + ONE view whose GEMMs fill 6 of 256 CUs;
+        # 7 x 110 (109) keeps every launch full.  (Results do not depend on the batching: tests/test_gpu_vit.py.)
+        n_launch = -(-B // max(1, max_batch))
+        max_batch = -(-B // n_launch)
         ws = self._workspace(min(B, max_batch))
         L = _lib.lib()
         fwd = L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward
