@@ -9,6 +9,7 @@ There is no network here, so checkpoints come from a local file or are randomly 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 
@@ -245,9 +246,11 @@ class HipViT:
         if self.dtype == "float32":
             max_batch = min(max_batch, 32)  # fp32 activations: 32 views keep the scratch at ~1.3 GB
         # equal-sized launches: 769 views at max_batch 128 would be 6 x 128 + ONE view whose GEMMs fill 6 of 256 CUs;
-        # 7 x 110 (109) keeps every launch full.  (Results do not depend on the batching: tests/test_gpu_vit.py.)
-        n_launch = -(-B // max(1, max_batch))
-        max_batch = -(-B // n_launch)
+        # 7 x 110 (109) keeps every launch full (measured: within noise, 2.718 vs 2.712 images/s on one box).  Results do
+        # not depend on the batching (tests/test_gpu_vit.py).
+        if os.environ.get("DVT_VIT_BALANCE", "1") != "0":  # (0: the reference's plain chunks of max_batch, for A/B timing)
+            n_launch = -(-B // max(1, max_batch))
+            max_batch = -(-B // n_launch)
         ws = self._workspace(min(B, max_batch))
         L = _lib.lib()
         fwd = L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward
