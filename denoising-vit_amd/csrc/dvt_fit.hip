@@ -21,7 +21,7 @@ extern int g_fit_sorted_grid;
 int g_fit_lazy_adam = 1;  // dvt_tune_set(9, 0): dense Adam over the whole arena
 int g_fit_shadow_in_adam = 1;  // dvt_tune_set(12, 0): shadow_build_kernel after every Adam launch
 int g_fit_lazy_merge = 1;  // dvt_tune_set(11, 0): catch-up as its own launch
-int g_fit_lazy_exact = 0;  // dvt_tune_set(10, 1): replay with IEEE division / sqrt (bit-identical to the dense sweep)
+int g_fit_lazy_exact = 1;  // default: replay with IEEE division / sqrt (bit-identical to the dense sweep); dvt_tune_set(10, 0): v_rcp / v_sqrt
 int g_fit_lazy_refresh = 32;  // dvt_tune_set(9, n >= 2): steps between full sweeps of the lazy region
 
 int g_adam_pingpong = 1;  // dvt_tune_set(8, 0): always sweep forward (A/B timing)

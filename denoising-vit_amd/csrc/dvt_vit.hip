@@ -78,6 +78,7 @@ struct GemmBArgs {
   int n_prefix, pos_has_cls;  // EPI_EMBED: prefix rows; pos_embed row 0 belongs to cls (else patches only)
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int mblock;         // M panels per block of the tile order (1: n fastest)
+  int tpw;            // 8q kernel: consecutive tiles of the order per workgroup
   int nt_store;       // bf16 outputs with the non-temporal hint
   // LayerNorm folded into the GEMMs (see ln_fold): consumer side (EPI_QKV / EPI_GELU) ...
   const float2* ln_stats;  // [M] (mean, rstd) of the fp32 residual rows; A is then bf16(x), W is bf16(gamma (.) W)
@@ -1048,6 +1049,449 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
 }
 
+// ---- 256x256x64, 8-phase ring, "8q": register epilogue + several tiles per workgroup ---------
+// Round 3.  Two measured costs of the 8p kernel sit outside its k-loop: at K = 768 a tile takes 25.9 us
+// of which 6.9 us are FIXED (prologue latency, drain, LDS round trip of the epilogue), and
+// the epilogue's parameter loads are serialised behind `s_waitcnt vmcnt(0)` one after the other.
+//   (1) Swapped MFMA operands.  acc = mfma(W fragment, A fragment) leaves C^T in the accumulators: a lane
+//       holds ONE output row (token lc of the 16-row block) and 4 consecutive columns per 16-column block.
+//       The W rows of a wave's 32-row half-tile block are permuted at the DMA SOURCE (LDS row 16 jj + lc
+//       holds W row 8 (lc >> 2) + 4 jj + (lc & 3)), so the two 16-column blocks of a half give each lane 8
+//       CONSECUTIVE columns: 16-B bf16 stores / 2 x float4 fp32 accesses straight from registers, no LDS
+//       round trip (64 ds_write_b32 + 32 ds_read_b128 per wave and tile in 8p), no barrier before it.
+//       V tiles of the qkv GEMM keep the un-swapped order (their store is token-contiguous, vt[b][h][d][s]).
+//   (2) Tile loop with the ring running THROUGH the tile boundary.  The LDS ring is free again as soon as
+//       the last phase has read it (the epilogue does not need LDS any more), so the last two k-tiles of
+//       tile i issue the first six half-tiles of tile i+1 in exactly the steady-state order; the next tile
+//       starts in steady state.  Operand staging goes through buffer descriptors (`buffer_load ... lds`):
+//       the per-lane part of a source address is 4 VGPRs for the whole kernel and a tile switch is SGPR-only.
+//       vmcnt is in issue order over loads AND stores on gfx9, so the first k-tile after an epilogue waits
+//       with `vmcnt(8 + S)`, S = a LOWER bound of the store instructions the epilogue issued after the DMAs.
+//   Workgroups keep living ~2-3 tiles (K = 768), not the whole launch: the fit's kernels on the other stream
+//   start only where a GEMM workgroup exits.
+template <int EPI>
+struct P8QStores {  // lower bound of VMEM store instructions per wave in the epilogue
+  static constexpr int n = (EPI == EPI_RESID) ? 24 : 16;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm_q() {
+  static_assert(N <= 63, "vmcnt has 6 bits");
+  if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct QSrc {  // one tile's operands: descriptors based at its first A / W row
+  __amdgpu_buffer_rsrc_t a, b;
+};
+
+// one k-tile = 4 phases.  STG: 0 steady (this tile's k-tiles t+1, t+2); 1 / 2 the last two k-tiles of the
+// workgroup's LAST tile (nothing left to stage); 3 / 4 the last two k-tiles when another tile follows (stage the
+// next tile's k-tiles 0 and 1 where the steady state would stage t+1 / t+2).
+template <bool SWAP, int STG, int W1, int W2, int W4>
+__device__ __forceinline__ void q_ktile(f32x4 (&acc)[8][4], char* smem, char* ldsw, const QSrc& cur, const QSrc& nxt,
+                                        int t, int nk, const int (&voA)[2], const int (&voB)[2], int hA, int hB,
+                                        int oa0, int oa1, int ob0, int ob1) {
+  constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
+  const int bo_ = (t & 1) * BUF, bn_ = bo_ ^ BUF;
+  const char* base_ = smem + bo_;
+  // k-tile index (inside its tile) staged by P1/P2 and by P3/P4
+  const int k1 = (STG == 4) ? 0 : t + 1;
+  const int k2 = (STG == 3) ? 0 : (STG == 4) ? 1 : t + 2;
+  const QSrc& s1 = (STG == 4) ? nxt : cur;
+  const QSrc& s2 = (STG >= 3) ? nxt : cur;
+  constexpr bool ST12 = (STG == 0 || STG == 1 || STG == 3 || STG == 4);
+  constexpr bool ST34 = (STG == 0 || STG == 3 || STG == 4);
+  bf16x8 a[4][2], b0[2][2], b1[2][2];
+#define Q_RD(p_, off) (*reinterpret_cast<const bf16x8*>((p_) + (off)))
+#define Q_STAGE(RS, VO, soff, off)                                                                               \
+  do {                                                                                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, VO[0], soff, 0, 0);              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, VO[1], soff, 0, 0);       \
+  } while (0)
+#define Q_MFMA(IB, JB, AF, BF)                                                                       \
+  do {                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+        acc[IB + i][JB + j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], AF[i][ks],   \
+                                                                             acc[IB + i][JB + j], 0, 0, 0) \
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][ks], BF[j][ks],   \
+                                                                             acc[IB + i][JB + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+  /* P1 */
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    b0[j][0] = Q_RD(base_ + OFF_B0 + j * 2048, ob0);
+    b0[j][1] = Q_RD(base_ + OFF_B0 + j * 2048, ob1);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i][0] = Q_RD(base_ + OFF_A0 + i * 2048, oa0);
+    a[i][1] = Q_RD(base_ + OFF_A0 + i * 2048, oa1);
+  }
+  if constexpr (ST12) Q_STAGE(s1.b, voB, hB + k1 * 128, bn_ + OFF_B1);
+  wait_vm_q<W1>();
+  P8_BAR();
+  P8_LGKM0();
+  Q_MFMA(0, 0, a, b0);
+  P8_BAR();
+  /* P2 */
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    b1[j][0] = Q_RD(base_ + OFF_B1 + j * 2048, ob0);
+    b1[j][1] = Q_RD(base_ + OFF_B1 + j * 2048, ob1);
+  }
+  if constexpr (ST12) Q_STAGE(s1.a, voA, hA + k1 * 128, bn_ + OFF_A1);
+  wait_vm_q<W2>();
+  P8_BAR();
+  P8_LGKM0();
+  Q_MFMA(0, 2, a, b1);
+  P8_BAR();
+  /* P3 */
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i][0] = Q_RD(base_ + OFF_A1 + i * 2048, oa0);
+    a[i][1] = Q_RD(base_ + OFF_A1 + i * 2048, oa1);
+  }
+  if constexpr (ST34) Q_STAGE(s2.a, voA, k2 * 128, bo_ + OFF_A0);
+  P8_BAR();
+  P8_LGKM0();
+  Q_MFMA(4, 2, a, b1);
+  P8_BAR();
+  /* P4 */
+  if constexpr (ST34) Q_STAGE(s2.b, voB, k2 * 128, bo_ + OFF_B0);
+  wait_vm_q<W4>();
+  P8_BAR();
+  Q_MFMA(4, 0, a, b0);
+  P8_BAR();
+#undef Q_RD
+#undef Q_STAGE
+#undef Q_MFMA
+}
+
+// What an epilogue needs of the launch arguments.  Read from the kernarg segment (scalar loads) per tile, behind an
+// opaque copy of the segment pointer, instead of living in ~40 SGPRs across the k-loop (the 8q kernel sat at the
+// 102-SGPR limit and spilled scalars into VGPR lanes inside the loop).
+struct EpiArgs {
+  const float* bias;
+  bf16_t* out;
+  bf16_t* vt;
+  float* x;
+  const float* gamma;
+  const float2* ln_stats;
+  const float* ln_cs;
+  bf16_t* xb;
+  float2* st_part;
+  int M, N, dim, heads, s_pad, nt_store;
+};
+typedef const __attribute__((address_space(4))) GemmBArgs* kernarg_ptr_t;
+__device__ __forceinline__ EpiArgs load_epi_args(kernarg_ptr_t k) {
+  EpiArgs e;
+  e.bias = k->bias; e.out = k->out; e.vt = k->vt; e.x = k->x; e.gamma = k->gamma;
+  e.ln_stats = k->ln_stats; e.ln_cs = k->ln_cs; e.xb = k->xb; e.st_part = k->st_part;
+  e.M = k->M; e.N = k->N; e.dim = k->dim; e.heads = k->heads; e.s_pad = k->s_pad; e.nt_store = k->nt_store;
+  return e;
+}
+
+// columns of a lane inside its wave's 64-column block under the W-row permutation:
+//   swapped:    acc[i][j][r] = C[16 i + lc][32 (j >> 1) + 8 g + 4 (j & 1) + r]
+//   un-swapped: acc[i][j][r] = C[16 i + 4 g + r][32 (j >> 1) + 8 (lc >> 2) + 4 (j & 1) + (lc & 3)]
+template <int EPI>
+__device__ __forceinline__ void q_epilogue_swapped(const EpiArgs& p, f32x4 (&acc)[8][4], int mb, int nb, int lane) {
+  const int g = lane >> 4, lc = lane & 15;
+  if constexpr (EPI == EPI_RESID) {
+    // x[m, n] += gamma[n] * (acc + bias[n]); fp32 read-modify-write, 32 B per lane and row.  Buffer addressing as in
+    // gemm_epilogue_resid_sq (one descriptor at the block, 32-bit lane offset); the row offset of a STORE goes into
+    // the VGPR offset (see RS_ST there: an SGPR soffset on a 128-bit buffer store lost a hazard wait state on gfx950).
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(p.x + (size_t)mb * p.N + nb, 0, 0x7fffffff, 0x00020000);
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    const int loff = (lc * p.N + 8 * g) * 4;
+    const int rstep = p.N * 64;  // bytes per 16 rows
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      __builtin_amdgcn_sched_barrier(0);  // keep the second round's 16 loads behind the first round's stores
+      float4 xl[8], xh[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xl[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, loff + jp * 128, i * rstep, 0));
+        xh[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, loff + jp * 128 + 16, i * rstep, 0));
+      }
+      const int c = nb + 32 * jp + 8 * g;
+      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c), g1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+      float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+      if (p.bias != nullptr) {
+        q0 = *reinterpret_cast<const float4*>(p.bias + c);
+        q1 = *reinterpret_cast<const float4*>(p.bias + c + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 u = acc[i][2 * jp], v = acc[i][2 * jp + 1];
+        float4 o0 = xl[i], o1 = xh[i];
+        o0.x += g0.x * (u[0] + q0.x); o0.y += g0.y * (u[1] + q0.y); o0.z += g0.z * (u[2] + q0.z); o0.w += g0.w * (u[3] + q0.w);
+        o1.x += g1.x * (v[0] + q1.x); o1.y += g1.y * (v[1] + q1.y); o1.z += g1.z * (v[2] + q1.z); o1.w += g1.w * (v[3] + q1.w);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o0), xr, loff + jp * 128 + i * rstep, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o1), xr, loff + jp * 128 + 16 + i * rstep, 0, 0);
+        if (p.xb != nullptr) {  // LayerNorm producer side (ln_fold): bf16(x) and the row's partial (sum, sum of squares)
+          typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+          const u32x4_t pk = {pack2(o0.x, o0.y), pack2(o0.z, o0.w), pack2(o1.x, o1.y), pack2(o1.z, o1.w)};
+          *reinterpret_cast<u32x4_t*>(p.xb + (size_t)(mb + i * 16 + lc) * p.N + c) = pk;
+          s1[i] += ((o0.x + o0.y) + (o0.z + o0.w)) + ((o1.x + o1.y) + (o1.z + o1.w));
+          s2[i] += ((o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w)) +
+                   ((o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
+        }
+      }
+    }
+    if (p.xb != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // the 4 lanes lc + 16 g hold the row's 64 columns
+        float a = s1[i], b = s2[i];
+        a += __shfl_xor(a, 16, 64);
+        b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (g == 0) p.st_part[(size_t)(nb >> 6) * p.M + mb + i * 16 + lc] = make_float2(a, b);
+      }
+    }
+  } else {
+    const bool ln = (EPI == EPI_QKV || EPI == EPI_GELU) && p.ln_stats != nullptr;
+    float2 st[8];
+    if (ln) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st[i] = p.ln_stats[mb + i * 16 + lc];
+    }
+    const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
+    bf16_t* orow = p.out + (size_t)(mb + lc) * ldo + nb + 8 * g;
+    float4 cs[2][2], bs[2][2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const int c = nb + 32 * jp + 8 * g;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        cs[jp][hh] = bs[jp][hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ln) cs[jp][hh] = *reinterpret_cast<const float4*>(p.ln_cs + c + 4 * hh);
+        if (p.bias != nullptr) bs[jp][hh] = *reinterpret_cast<const float4*>(p.bias + c + 4 * hh);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][2 * jp][r];
+          v[4 + r] = acc[i][2 * jp + 1][r];
+        }
+        const float cv[8] = {cs[jp][0].x, cs[jp][0].y, cs[jp][0].z, cs[jp][0].w, cs[jp][1].x, cs[jp][1].y, cs[jp][1].z, cs[jp][1].w};
+        const float bv[8] = {bs[jp][0].x, bs[jp][0].y, bs[jp][0].z, bs[jp][0].w, bs[jp][1].x, bs[jp][1].y, bs[jp][1].z, bs[jp][1].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (ln) v[e] = fmaf(st[i].y, v[e] - st[i].x * cv[e], bv[e]);  // rstd * (acc - mean * cs) + b'
+          else v[e] += bv[e];
+          if (EPI == EPI_GELU) v[e] = gelu_erf(v[e]);
+        }
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(orow + (size_t)i * 16 * ldo + 32 * jp);
+        if (p.nt_store) __builtin_nontemporal_store(pk, dst);
+        else *dst = pk;
+      }
+    }
+  }
+}
+
+// V tiles of the qkv GEMM (un-swapped operands): vt[b][h][d][s], the lane's 4 rows are 4 consecutive tokens
+__device__ __forceinline__ void q_epilogue_v(const EpiArgs& p, f32x4 (&acc)[8][4], int mb, int nb, int lane) {
+  const int g = lane >> 4, lc = lane & 15;
+  const bool ln = p.ln_stats != nullptr;
+  const int b = mb / p.s_pad, s0 = mb - b * p.s_pad;  // a 128-row block never straddles two images
+  float cs[4], bs[4];
+  int col[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    col[j] = nb + 32 * (j >> 1) + 8 * (lc >> 2) + 4 * (j & 1) + (lc & 3);
+    cs[j] = ln ? p.ln_cs[col[j]] : 0.f;
+    bs[j] = p.bias != nullptr ? p.bias[col[j]] : 0.f;
+  }
+  float4 sa[8], sb[8];  // (mean, rstd) of rows 16 i + 4 g + {0, 1} and {2, 3}
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sa[i] = sb[i] = make_float4(0.f, 1.f, 0.f, 1.f);
+  if (ln) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4* sp = reinterpret_cast<const float4*>(p.ln_stats + mb + i * 16 + 4 * g);
+      sa[i] = sp[0];
+      sb[i] = sp[1];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float mu[4] = {sa[i].x, sa[i].z, sb[i].x, sb[i].z}, rs[4] = {sa[i].y, sa[i].w, sb[i].y, sb[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = ln ? fmaf(rs[r], acc[i][j][r] - mu[r] * cs[j], bs[j]) : acc[i][j][r] + bs[j];
+      const int f = col[j] - 2 * p.dim, h = f >> 6, d = f & 63;
+      uint2 pk;
+      pk.x = pack2(v[0], v[1]);
+      pk.y = pack2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(p.vt + ((size_t)(b * p.heads + h) * 64 + d) * p.s_pad + s0 + i * 16 + 4 * g) = pk;
+    }
+  }
+}
+
+__device__ __forceinline__ TileMap map_tile_id(int id, int mt, int nt, int group, int mblock) {
+  const int per_group = group * mt;
+  int g = id / per_group;
+  const int full = nt / group;
+  int width = group;
+  if (g >= full) {
+    g = full;
+    width = nt - full * group;
+  }
+  const int rem = id - g * per_group;
+  TileMap t;
+  if (mblock <= 1) {
+    t.m = rem / width;
+    t.n = g * group + rem % width;
+  } else {
+    const int per_block = mblock * width;
+    const int mbk = rem / per_block, r2 = rem - mbk * per_block;
+    const int left = mt - mbk * mblock, hb = left < mblock ? left : mblock;
+    t.n = g * group + r2 / hb;
+    t.m = mbk * mblock + r2 % hb;
+  }
+  return t;
+}
+
+// the k-loop + epilogue of one tile; FIRST: the workgroup's first tile (its prologue was issued by the caller)
+template <int EPI, bool SWAP>
+__device__ __forceinline__ void q_tile(kernarg_ptr_t kp, f32x4 (&acc)[8][4], char* smem, char* ldsw, const QSrc& cur,
+                                       const QSrc& nxt, bool first, int nk, const int (&voA)[2],
+                                       const int (&voB)[2], int hA, int hB, int oa0, int oa1, int ob0, int ob1, int mb,
+                                       int nb, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int S = P8QStores<EPI>::n;
+#define Q_ARGS acc, smem, ldsw, cur, nxt
+#define Q_TAIL nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1
+  int t = 0;
+  if (!first) {  // the previous tile's epilogue stores sit between this tile's first DMAs and the ones issued now
+    q_ktile<SWAP, 0, 8 + S, 8 + S, 8 + S>(Q_ARGS, 0, Q_TAIL);
+    t = 1;
+  }
+  for (; t < nk - 2; ++t) q_ktile<SWAP, 0, 8, 8, 8>(Q_ARGS, t, Q_TAIL);
+  // The last two k-tiles ALWAYS continue the ring into `nxt` -- when no tile follows, `nxt` is a zero-length
+  // descriptor (out-of-range buffer loads: no memory traffic) and the DMAs are drained before the workgroup exits.
+  // A second code path for "no next tile" would merge with 128 live accumulators behind it: hipcc's register
+  // allocator then spills ~280 VGPRs (measured on the .s), the straight-line body needs 206 and none.
+  q_ktile<SWAP, 3, 8, 8, 8>(Q_ARGS, nk - 2, Q_TAIL);
+  q_ktile<SWAP, 4, 8, 8, 8>(Q_ARGS, nk - 1, Q_TAIL);
+#undef Q_ARGS
+#undef Q_TAIL
+  asm volatile("" : "+s"(kp));  // opaque: the loads below are not hoisted above the k-loop
+  const EpiArgs e = load_epi_args(kp);
+  if constexpr (SWAP) q_epilogue_swapped<EPI>(e, acc, mb, nb, lane);
+  else q_epilogue_v(e, acc, mb, nb, lane);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8q(GemmBArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * 16384];  // the ring only: 8 half-tile slots
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int mt = p.M / 256, nt = p.N / 256, ntiles = mt * nt;
+  // workgroup -> run of `tpw` consecutive tiles of the order; XCD x owns a contiguous range of runs
+  int wid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int first_tile = wid * p.tpw;
+  const int count = min(p.tpw, ntiles - first_tile);
+  const int nk = p.K / GBK;
+
+  // per-lane parts of the DMA source addresses (bytes); the half (h) and the k-tile go into the scalar offset
+  int voA[2], voB[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s_ = it * 512 + tid, r = s_ >> 3, c = (s_ & 7) ^ (r & 7);
+    voA[it] = (((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2;
+    const int rho = r & 31, jj = rho >> 4, l16 = rho & 15;
+    voB[it] = (((r >> 5) * 64 + 8 * (l16 >> 2) + 4 * jj + (l16 & 3)) * p.ldw + c * 8) * 2;
+  }
+  const int hA = 64 * p.lda * 2, hB = 32 * p.ldw * 2;  // second half-tile: +64 A rows / +32 W rows
+  char* const ldsw = smem + wave * 1024;
+  const int cg = lane >> 4;
+  const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
+  const int oa0 = ra * 128 + (((0 + cg) ^ (ra & 7)) << 4), oa1 = ra * 128 + (((4 + cg) ^ (ra & 7)) << 4);
+  const int ob0 = rb * 128 + (((0 + cg) ^ (rb & 7)) << 4), ob1 = rb * 128 + (((4 + cg) ^ (rb & 7)) << 4);
+
+  auto src_of = [&](int id, bool valid, int& m0, int& n0) {
+    const TileMap tm = map_tile_id(valid ? id : first_tile, mt, nt, p.group, p.mblock);
+    m0 = tm.m * 256;
+    n0 = tm.n * 256;
+    const int len = valid ? 0x7fffffff : 0;  // no tile: every access is out of range
+    QSrc s;
+    s.a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, len, 0x00020000);
+    s.b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, len, 0x00020000);
+    return s;
+  };
+  int m0, n0;
+  QSrc cur = src_of(first_tile, true, m0, n0);
+  {  // prologue: A0 B0 B1 A1 of k-tile 0, A0 B0 of k-tile 1 -- the order the steady state continues
+    constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
+#define Q_STAGE0(RS, VO, soff, off)                                                                              \
+  do {                                                                                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, VO[0], soff, 0, 0);              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, VO[1], soff, 0, 0);       \
+  } while (0)
+    Q_STAGE0(cur.a, voA, 0, OFF_A0);
+    Q_STAGE0(cur.b, voB, 0, OFF_B0);
+    Q_STAGE0(cur.b, voB, hB, OFF_B1);
+    Q_STAGE0(cur.a, voA, hA, OFF_A1);
+    Q_STAGE0(cur.a, voA, 128, BUF + OFF_A0);
+    Q_STAGE0(cur.b, voB, 128, BUF + OFF_B0);
+#undef Q_STAGE0
+  }
+  wait_vm<8>();
+  P8_BAR();
+  if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on (through every tile of the run)
+
+  f32x4 acc[8][4];
+  kernarg_ptr_t kp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  for (int ti = 0; ti < count; ++ti) {
+    int m1, n1;
+    const QSrc nxt = src_of(first_tile + ti + 1, ti + 1 < count, m1, n1);
+    const int mb = m0 + wm * 128, nb = n0 + wn * 64;
+#define Q_CALL(SW) q_tile<EPI, SW>(kp, acc, smem, ldsw, cur, nxt, ti == 0, nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1, mb, nb, lane)
+    if constexpr (EPI == EPI_QKV) {
+      if (n0 >= 2 * p.dim) Q_CALL(false);
+      else Q_CALL(true);
+    } else {
+      Q_CALL(true);
+    }
+#undef Q_CALL
+    cur = nxt;
+    m0 = m1;
+    n0 = n1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (empty) DMAs of the non-existent next tile
+  if (wm == 0) P8_BAR();  // balance group 1's extra barrier
+}
+
 // W bytes kept L2-resident per N-tile group.  4800 KiB = every N tile of a K = 768 GEMM in ONE group (qkv: 9
 // tiles, fc1: 12): each 393-KB A panel is then fetched once instead of once per group (measured: GEMMs 907 ->
 // 931 TF/s in the extractor; 9600 KiB the same, 1200 KiB 900).
@@ -1061,6 +1505,8 @@ int g_vit_mblock = 0;
 int g_vit_nt_store = 0;
 // LayerNorm folded into the qkv / fc1 GEMMs and the proj / fc2 residual epilogues (ln_fold)
 int g_vit_fuse_ln = 1;
+// 8q kernel: tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
+int g_vit_tpw = 0;
 
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
@@ -1078,7 +1524,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   }
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, a.work > 0.0 ? a.work : 2.0 * a.M * a.N * a.K);
   if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK &&
-      (g_vit_gemm_variant == 0 || g_vit_gemm_variant == 4)) {
+      (g_vit_gemm_variant == 0 || g_vit_gemm_variant >= 4)) {
     const int nt = a.N / 256;
     // N tiles per group: W slices of a group stay L2-resident, but never fewer than 3 tiles share
     // an A panel (K = 3072: one tile per group re-read A three times from HBM, 1.03 -> 1.23 PF/s)
@@ -1089,7 +1535,16 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.group = g;
     a.mblock = g_vit_mblock > 0 ? g_vit_mblock : (g >= 6 ? 4 : 1);
     a.nt_store = g_vit_nt_store;
-    if (g_vit_gemm_variant == 4)
+    const int nk = a.K / GBK;
+    if (g_vit_gemm_variant == 5 && EPI != EPI_EMBED && nk >= 4 && nk % 2 == 0) {
+      // tiles per workgroup: a workgroup should not live much longer than ~50 us (the fit's kernels on the other
+      // stream start where a GEMM workgroup exits): 3 tiles at K = 768 (19 us each), 1 at K = 3072
+      int tpw = g_vit_tpw > 0 ? g_vit_tpw : (nk <= 16 ? 3 : 1);
+      const int tiles = (a.M / 256) * nt;
+      tpw = tpw > tiles ? tiles : tpw;
+      a.tpw = tpw;
+      hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI>), dim3((tiles + tpw - 1) / tpw), dim3(512), 0, s, a);
+    } else if (g_vit_gemm_variant >= 4)
       hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     else
       hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
@@ -1454,6 +1909,10 @@ int dvt_vit_tune(int v) {
     g_vit_nt_store = v == -51;
     return 0;
   }
+  if (v <= -200) {  // -200 - n: tiles per workgroup of the 8q kernel, 0 = auto
+    g_vit_tpw = -200 - v > 16 ? 16 : -200 - v;
+    return 0;
+  }
   if (v <= -100) {  // -100 - b: M panels per block of the tile order
     g_vit_mblock = -100 - v < 0 ? 0 : -100 - v;  // 0 = auto
     return 0;
@@ -1462,7 +1921,7 @@ int dvt_vit_tune(int v) {
     g_vit_group_bytes = v * 1024;
     return 0;
   }
-  if (v < 0 || v > 4) return DVT_E_BADARG;
+  if (v < 0 || v > 5) return DVT_E_BADARG;
   g_vit_gemm_variant = v;
   return 0;
 }
@@ -1584,7 +2043,7 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
   }
   // LayerNorm folded into the GEMMs (ln_fold): needs the folded weights, the 8-phase kernel on every GEMM of the
   // block (whole 256-row / 256-column tiles) and is switched by dvt_vit_tune; otherwise the LayerNorm kernels run.
-  bool fuse_ln = g_vit_fuse_ln && g_vit_gemm_variant == 4 && T % 256 == 0 && D % 256 == 0 && c->mlp_dim % 256 == 0 &&
+  bool fuse_ln = g_vit_fuse_ln && g_vit_gemm_variant >= 4 && T % 256 == 0 && D % 256 == 0 && c->mlp_dim % 256 == 0 &&
                  n_blocks > 0;
   for (int l = 0; l < n_blocks; ++l) {
     const DvtVitBlockWeights& bw = w->blocks[l];

@@ -254,16 +254,20 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
                      int OW, void* stream);
 
 /* Schedule selection (developer use).  Every selectable value computes the SAME results (each one
- * is parity-tested); the knobs only trade speed.  The state is process-global: set it before any
+ * is parity-tested); the knobs only trade speed -- with ONE documented exception: key 10 = 0 selects an
+ * approximate replay arithmetic (v_rcp_f32 / v_sqrt_f32, 1 ulp each) that is tolerance-tested, not
+ * bit-identical, and is NOT the default.  The state is process-global: set it before any
  * work is enqueued, never concurrently with launches (the compute entry points themselves are
  * re-entrant on distinct streams).
  * key 0 = fp32 GEMM tile configuration override
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
- * key 1 = ViT bf16 GEMM schedule (4, default: 256x256 8-phase ring; 0: 256x256 two-stage; 1: always
+ * key 1 = ViT bf16 GEMM schedule (4: 256x256 8-phase ring; 5: the same ring with a register epilogue and
+ *         several tiles per workgroup [-200 - n: n tiles, 0 = auto]; 0: 256x256 two-stage; 1: always
  *         128x128 two-stage; 2: 256x128 lock-step three-stage; 3: 256x128 ping-pong;
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation;
  *         -100 - b: b M panels per block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output
- *         stores off / on).  No value changes results: every schedule and order is bit-identical;
+ *         stores off / on).  No value changes the result beyond the summation order of the folded-LayerNorm row
+ *         statistics (fp32, ~1e-7 relative);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);
@@ -275,8 +279,10 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         n >= 2 = lazy with a full refresh every n steps (default 32);
  * key 12 = the merged Adam launch also stores the bf16 weight shadow (1, default) or shadow_build_kernel runs (0);
  * key 11 = the lazy catch-up of the next step shares the Adam launch (1, default) or is its own launch (0);
- * key 10 = lazy Adam replays with IEEE division / square root (1: bit-identical to the dense sweep, slower; default 0:
- *         v_rcp_f32 / v_sqrt_f32, 1 ulp each);
+ * key 10 = lazy Adam replay arithmetic: 1 (default) IEEE division / square root, the dense kernel's own update
+ *         function -- every entry ends bit-identical to the dense sweep; 0: v_rcp_f32 / v_sqrt_f32 (1 ulp each), an
+ *         APPROXIMATION of the reference's Adam kept for A/B timing only (agrees with the dense sweep to rounding
+ *         over ~150 steps, decorrelates in the unread weight-decay jitter over thousands);
  * key 8 = Adam sweeps the arena in alternating directions on consecutive steps (1, default) or always forward (0);
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);

@@ -1,0 +1,166 @@
+"""Developer tool (round 3): the 8q ViT GEMM (register epilogue + tile loop, dvt_tune_set(1, 5)) against the 8p
+kernel (4): element-wise correctness on small M with every tiles-per-workgroup setting (tails included), the
+whole extractor 5-vs-4, and per-shape / whole-extractor timings.
+
+    python tools/lab_gemm8q.py [check] [time] [vit]
+"""
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "denoising-vit_amd")]
+from dvt_amd import _lib  # noqa: E402
+import dvt_amd.vit  # noqa: E402,F401  (registers the ViT entry points)
+
+dev = torch.device("cuda:0")
+L = _lib.lib()
+what = set(sys.argv[1:]) or {"check", "time", "vit"}
+S = _lib.stream
+
+
+def tune(v):
+    assert L.dvt_tune_set(1, v) == 0, v
+
+
+def run_bias(x, w, b, y, m, n, k):
+    rc = L.dvt_vit_gemm_bias(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k, S())
+    assert rc == 0, rc
+
+
+def run_resid(a, w, b, g, x, m, n, k):
+    rc = L.dvt_vit_gemm_residual(a.data_ptr(), w.data_ptr(), b.data_ptr(), g.data_ptr(), x.data_ptr(), m, n, k, S())
+    assert rc == 0, rc
+
+
+if "check" in what:
+    ok = True
+    for (m, n, k) in [(1792, 2304, 768), (1792, 768, 768), (1280, 3072, 768), (768, 768, 3072), (512, 256, 256)]:
+        torch.manual_seed(m + n + k)
+        x = (torch.randn(m, k) + torch.linspace(-1, 1, k)[None, :] * torch.linspace(0.5, 2, m)[:, None]).bfloat16().to(dev)
+        w = (torch.randn(n, k) / k ** 0.5 + torch.linspace(-0.02, 0.03, n)[:, None]).bfloat16().to(dev)
+        b, gm = torch.randn(n, device=dev), torch.randn(n, device=dev)
+        want = x.float() @ w.float().t() + b
+        x0 = torch.randn(m, n, device=dev)
+        want_r = x0 + gm * want
+        for tpw in (1, 2, 3, 4, 5, 7):
+            tune(5)
+            tune(-200 - tpw)
+            y = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
+            run_bias(x, w, b, y, m, n, k)
+            xr = x0.clone()
+            run_resid(x, w, b, gm, xr, m, n, k)
+            torch.cuda.synchronize()
+            e1 = float((y.float() - want).abs().max() / want.abs().max())
+            e2 = float((xr - want_r).abs().max() / want_r.abs().max())
+            bad1 = int(((y.float() - want).abs() > 0.02 * want.abs().max()).sum())
+            bad2 = int(((xr - want_r).abs() > 0.005 * want_r.abs().max()).sum())
+            flag = "OK " if (e1 < 6e-3 and e2 < 2e-3) else "BAD"
+            ok &= flag == "OK "
+            print(f"check {flag} M={m} N={n} K={k} tpw={tpw}: bias rel err {e1:.2e} (bad {bad1}), resid rel err {e2:.2e} (bad {bad2})",
+                  flush=True)
+        # repeated launches (race screen): 20 runs must be bit-identical
+        tune(5)
+        tune(-200)
+        ref = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
+        run_bias(x, w, b, ref, m, n, k)
+        same = True
+        for _ in range(20):
+            y = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
+            run_bias(x, w, b, y, m, n, k)
+            same &= bool(torch.equal(y, ref))
+        print(f"race screen M={m} N={n} K={k}: 20 repeats identical: {same}", flush=True)
+        ok &= same
+    tune(-200)
+    tune(4)
+    print("CHECK", "PASSED" if ok else "FAILED", flush=True)
+
+if "vit" in what:
+    from dvt_amd.vit import HipViT, random_state_dict
+    for depth, batch in ((3, 2), (12, 3)):
+        sd = random_state_dict(768, depth, 14, 1370, seed=depth, well_conditioned=True)
+        g = torch.Generator().manual_seed(depth)
+        for kk in list(sd):
+            if kk.endswith("norm1.weight") or kk.endswith("norm2.weight"):
+                sd[kk] = sd[kk] * (1.0 + 0.3 * torch.randn(sd[kk].shape, generator=g))
+            if kk.endswith("norm1.bias") or kk.endswith("norm2.bias"):
+                sd[kk] = sd[kk] + 0.2 * torch.randn(sd[kk].shape, generator=g)
+        x = torch.randn(batch, 3, 518, 518, generator=g).to(dev)
+        vit = HipViT(sd, 14, 14, (518, 518), dev)
+        outs = {}
+        for name, knobs in (("8p", [4]), ("8q", [5]), ("8q tpw2", [5, -202]), ("8p LN kernels", [4, -60]), ("8q LN kernels", [5, -60])):
+            for v in knobs:
+                tune(v)
+            outs[name] = vit.forward_features(x, max_batch=batch).float().cpu()
+            tune(-200)
+            tune(-61)
+            tune(4)
+        for a_, b_ in (("8q", "8p"), ("8q tpw2", "8p"), ("8q LN kernels", "8p LN kernels")):
+            d = outs[a_] - outs[b_]
+            cos = torch.nn.functional.cosine_similarity(outs[a_].reshape(-1, 768), outs[b_].reshape(-1, 768), dim=-1)
+            print(f"vit depth {depth} batch {batch}: {a_} vs {b_}: rel-L2 {float(d.norm() / outs[b_].norm()):.3e}, "
+                  f"max |diff| {float(d.abs().max()):.3e}, per-token cos min {float(cos.min()):.7f}, finite "
+                  f"{bool(torch.isfinite(outs[a_]).all())}", flush=True)
+
+if "time" in what:
+    M = 110 * 1408
+    torch.manual_seed(0)
+    for name, n, k, resid in [("qkv", 2304, 768, False), ("fc1", 3072, 768, False), ("proj", 768, 768, True), ("fc2", 768, 3072, True)]:
+        x = torch.randn(M, k, device=dev).bfloat16()
+        w = (torch.randn(n, k, device=dev) / k ** 0.5).bfloat16()
+        b, gm = torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-3
+        y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        xr = torch.randn(M, n, device=dev)
+        configs = [("8p", [4])] + [(f"8q tpw{t}", [5, -200 - t]) for t in ((1, 2, 3, 4, 6) if k == 768 else (1, 2))]
+        res = {c[0]: 1e9 for c in configs}
+        for rnd in range(3):  # interleaved rounds
+            for cname, knobs in configs:
+                for v in knobs:
+                    tune(v)
+                fn = (lambda: run_resid(x, w, b, gm, xr, M, n, k)) if resid else (lambda: run_bias(x, w, b, y, M, n, k))
+                fn()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(5):
+                    fn()
+                ev1.record()
+                torch.cuda.synchronize()
+                res[cname] = min(res[cname], ev0.elapsed_time(ev1) / 5)
+                tune(-200)
+                tune(4)
+        for cname, ms in res.items():
+            print(f"time {name:5s} N={n:5d} K={k:5d} {cname:10s}: {ms * 1e3:8.1f} us {2.0 * M * n * k / ms / 1e9:7.1f} TF/s", flush=True)
+        del x, w, y, xr
+
+    from dvt_amd.models import PretrainedViTWrapper
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14, allow_random_init=True)
+    x = torch.randn(110, 3, 518, 518, device=dev)
+    out = torch.empty(110, 37, 37, 768, device=dev)
+    configs = [("8p", [4]), ("8q auto", [5]), ("8q tpw2", [5, -202]), ("8q tpw4", [5, -204]), ("8q tpw1", [5, -201])]
+    best = {c[0]: (1e9, None, None) for c in configs}
+    for rnd in range(3):
+        for cname, knobs in configs:
+            for v in knobs:
+                tune(v)
+            vit.features_nhwc(x, out=out)
+            torch.cuda.synchronize()
+            _lib.prof_enable(["vit_gemm", "vit_attn"])
+            t0 = time.perf_counter()
+            vit.features_nhwc(x, out=out)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            g, a = _lib.prof_collect("vit_gemm"), _lib.prof_collect("vit_attn")
+            _lib.prof_enable([])
+            if t < best[cname][0]:
+                best[cname] = (t, g, a)
+            tune(-200)
+            tune(4)
+    for cname, (t, g, a) in best.items():
+        print(f"extractor 110 views {cname:8s}: {t * 1e3:7.1f} ms ({t * 7 * 1e3:6.1f} ms per 770 views); gemm {g['total_ms']:6.1f} ms "
+              f"{g['work'] / g['total_ms'] / 1e9:6.1f} TF/s; attn {a['total_ms']:6.1f} ms {a['work'] / a['total_ms'] / 1e9:6.1f} TF/s",
+              flush=True)

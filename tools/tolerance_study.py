@@ -1,0 +1,135 @@
+"""Measured distributions behind the HIP-vs-HIP tolerances of tests/test_gpu_fit.py (Weak #1 ii).
+
+For every asserted quantity: N seeds (data, initial parameters, index stream all change with the seed), and for
+each seed BOTH the cross-path value the test asserts on and the SAME-path run-to-run value (the identical
+configuration launched twice: what atomics order alone does).  Output: one JSON document (stdout + the file
+given as argv[1]); committed as profiles/r03/tolerance_study.json and cited by the tests.
+
+    python tools/tolerance_study.py gpurun_out/tolerance_study.json [n_seeds]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "denoising-vit_amd")]
+from dvt_amd import _lib  # noqa: E402
+from dvt_amd.fit import FitEngine, FitSettings, fit_many  # noqa: E402
+from tests.test_gpu_fit import per_patch_cos, synthetic_image  # noqa: E402
+
+DEV = "cuda"
+L = _lib.lib()
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+out = {"n_seeds": N}
+
+
+def run(feats, xy, idx, T, C, seed, knobs=(), warm=None, log=1):
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=max(1, T // 10) if warm is None else warm, mlp_dtype="bfloat16")
+    try:
+        for k, v in knobs:
+            assert L.dvt_tune_set(k, v) == 0
+        e = FitEngine(s, feats.shape[0], DEV)
+        e.reset(torch.Generator(device=DEV).manual_seed(seed))
+        e.fit(feats, xy, idx, log_every=log)
+        torch.cuda.synchronize()
+    finally:
+        L.dvt_tune_set(6, 1)
+        L.dvt_tune_set(9, 32)
+        L.dvt_tune_set(7, 1)
+        L.dvt_tune_set(10, DEFAULT_REPLAY)
+    return e
+
+
+DEFAULT_REPLAY = int(os.environ.get("DVT_DEFAULT_REPLAY", "1"))
+
+
+def stats(v):
+    v = np.asarray(v, np.float64)
+    return {"min": float(v.min()), "median": float(np.median(v)), "max": float(v.max()), "values": [float(x) for x in v]}
+
+
+# ---- T1: fused row kernel vs layer-by-layer launches, 16 steps (test_fused_row_kernel_equals_layer_by_layer)
+for C, V in ((768, 6), (1024, 4), (384, 6)):
+    cross, same, cosx = [], [], []
+    for sd in range(N):
+        feats, xy = synthetic_image(V, 37, 37, C, seed=1000 * C + sd)
+        f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+        idx = np.random.RandomState(C + sd).randint(0, f.shape[0], (16, 2048)).astype(np.int32)
+        a = run(f, c, idx, 16, C, sd, warm=2)
+        b = run(f, c, idx, 16, C, sd, warm=2)
+        l = run(f, c, idx, 16, C, sd, knobs=[(6, 0)], warm=2)
+        cross.append(float((a.params - l.params).abs().max()))
+        same.append(float((a.params - b.params).abs().max()))
+        cosx.append(float(per_patch_cos(a.infer(xy[-1].to(DEV)).cpu(), l.infer(xy[-1].to(DEV)).cpu()).min()))
+        del a, b, l
+    out[f"T1_fused_vs_layer_C{C}"] = {"param_max_abs_diff_cross_path": stats(cross), "param_max_abs_diff_same_path_rerun": stats(same),
+                                      "saved_tensor_cos_min_cross_path": stats(cosx)}
+    print(f"T1 C={C}: cross max {max(cross):.4f} median {np.median(cross):.4f}; same-path rerun max {max(same):.4f}", flush=True)
+
+# ---- T2: batched fused fits vs separate fits, 70 steps (test_batched_fused_fits_equal_separate_fits)
+cross, same, cosx, coss = [], [], [], []
+for sd in range(N):
+    C, V, T, k = 768, 4, 70, 2
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=7, mlp_dtype="bfloat16")
+    data = [synthetic_image(V, 37, 37, C, seed=200 + 10 * sd + j) for j in range(k)]
+    fs = [d[0].reshape(-1, C).to(DEV) for d in data]
+    cs = [d[1].reshape(-1, 2).to(DEV) for d in data]
+    idxs = [np.random.RandomState(300 + 10 * sd + j).randint(0, fs[0].shape[0], (T, 2048)).astype(np.int32) for j in range(k)]
+
+    def solo():
+        es = []
+        for j in range(k):
+            e = FitEngine(s, fs[0].shape[0], DEV)
+            e.reset(torch.Generator(device=DEV).manual_seed(j))
+            e.fit(fs[j], cs[j], idxs[j], log_every=0)
+            es.append(e)
+        return es
+
+    s1, s2 = solo(), solo()
+    bt = []
+    for j in range(k):
+        b = FitEngine(s, fs[0].shape[0], DEV)
+        b.reset(torch.Generator(device=DEV).manual_seed(j))
+        bt.append(b)
+    fit_many(bt, fs, cs, idxs, log_every=0)
+    torch.cuda.synchronize()
+    for j in range(k):
+        q = data[j][1][-1].to(DEV)
+        cross.append(float((s1[j].params - bt[j].params).abs().max()))
+        same.append(float((s1[j].params - s2[j].params).abs().max()))
+        cosx.append(float(per_patch_cos(s1[j].infer(q).cpu(), bt[j].infer(q).cpu()).min()))
+        coss.append(float(per_patch_cos(s1[j].infer(q).cpu(), s2[j].infer(q).cpu()).min()))
+    del s1, s2, bt
+out["T2_batched_vs_solo_70_steps"] = {"param_max_abs_diff_cross_path": stats(cross), "param_max_abs_diff_same_path_rerun": stats(same),
+                                      "saved_tensor_cos_min_cross_path": stats(cosx), "saved_tensor_cos_min_same_path_rerun": stats(coss)}
+print(f"T2: cross max {max(cross):.4f} cos min {min(cosx):.6f}; same-path rerun max {max(same):.4f} cos min {min(coss):.6f}", flush=True)
+
+# ---- T3: 2500 steps, dense Adam vs exact lazy replay vs 1-ulp lazy replay (test_long_run_many_list_chunks)
+rel = {"exact_vs_dense": [], "fast_vs_dense": [], "dense_vs_dense_rerun": []}
+cosm = {"exact_vs_dense": [], "fast_vs_dense": [], "dense_vs_dense_rerun": []}
+for sd in range(N):
+    C, V, T = 768, 4, 2500
+    feats, xy = synthetic_image(V, 37, 37, C, seed=700 + sd)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    idx = np.random.RandomState(70 + sd).randint(0, f.shape[0], (T, 2048)).astype(np.int32)
+    q = xy[-1].to(DEV)
+    dense = run(f, c, idx, T, C, 1, knobs=[(9, 0)])
+    ref, ld = dense.infer(q).cpu(), dense.loss_log()[T - 1]["loss"]
+    for name, knobs in (("exact_vs_dense", [(10, 1)]), ("fast_vs_dense", [(10, 0)]), ("dense_vs_dense_rerun", [(9, 0)])):
+        o = run(f, c, idx, T, C, 1, knobs=knobs)
+        rel[name].append(abs(o.loss_log()[T - 1]["loss"] - ld) / abs(ld))
+        cosm[name].append(float(per_patch_cos(o.infer(q).cpu(), ref).min()))
+        del o
+    del dense
+out["T3_2500_steps"] = {k: {"final_loss_rel_diff": stats(rel[k]), "saved_tensor_cos_min": stats(cosm[k])} for k in rel}
+for k in rel:
+    print(f"T3 {k}: final loss rel diff max {max(rel[k]):.4f}; cos min {min(cosm[k]):.6f}", flush=True)
+
+doc = json.dumps(out, indent=1)
+if len(sys.argv) > 1:
+    os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)
+    open(sys.argv[1], "w").write(doc)
+print(doc)
