@@ -251,9 +251,17 @@ class FitEngine:
         engine is already preparing the next image when this one retires)."""
         return getattr(self, "_range_bad", None)
 
-    def check_inputs(self, flag=None) -> None:
-        """Raise if the coordinates handed to a fit left [0, 1] (synchronises on the flag)."""
-        flag = self.range_flag if flag is None else flag
+    _OWN_FLAG = object()
+
+    def check_inputs(self, flag=_OWN_FLAG) -> None:
+        """Raise if the coordinates handed to a fit left [0, 1] (synchronises on the flag).  Without an argument
+        the flag of this engine's LAST fit is checked; the pipelined driver passes the flag that travelled with the
+        image it retires -- `None` there means "this image was never fitted" and is an error, not a reason to look at
+        the engine's current flag (which already belongs to the next image)."""
+        if flag is FitEngine._OWN_FLAG:
+            flag = self.range_flag
+        elif flag is None:
+            raise _lib.DvtError("check_inputs(None): the retired image carries no coordinate-range flag (never fitted?)")
         if flag is not None and bool(flag.item()):
             raise _lib.DvtError("coordinates should be in [0, 1] (neural_feature_field.py:47): the fit of this "
                                 "image consumed out-of-range coordinates, its result is invalid")

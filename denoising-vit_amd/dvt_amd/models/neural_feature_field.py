@@ -177,6 +177,7 @@ class NeuralFeatureField(nn.Module):
         # whole coordinate table once per image instead (FitEngine.buffers / check_inputs).
         _lib.require_cuda(coords)
         lo, hi = torch.aminmax(coords.detach())
-        assert hi <= 1 and lo >= 0, "coordinates should be in [0, 1]"
+        if not (bool(hi <= 1) and bool(lo >= 0)):  # also catches NaN; an `assert` would vanish under python -O
+            raise _lib.DvtError("coordinates should be in [0, 1] (neural_feature_field.py:47)")
         feats = self.neural_field(coords.reshape(-1, 2))
         return self.mlp(feats.view(list(coords.shape[:-1]) + [-1]))

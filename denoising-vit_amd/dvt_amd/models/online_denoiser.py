@@ -34,6 +34,7 @@ def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
 
 
 class Denoiser(nn.Module):
+    RESIZED_CACHE = 4  # resized inference copies kept (LRU)
     def __init__(self, noise_map_height: int = 37, noise_map_width: int = 37, feat_dim: int = 768,
                  vit: PretrainedViTWrapper = None, enable_pe: bool = True, num_blocks: int = 1,
                  device: torch.device | str = "cuda", seed: int | None = None):
@@ -57,6 +58,7 @@ class Denoiser(nn.Module):
             for p in self.vit.parameters():
                 p.requires_grad = False
         self._resized = {}
+        self._resized_version = -1
 
     # parameters are views of the engine's arena: moving the module must move the arena, not the views
     def _apply(self, fn, recurse=True):
@@ -77,9 +79,20 @@ class Denoiser(nn.Module):
         once to a copy of the parameters."""
         if (h, w) == self.noise_map_size or self.pos_embed is None and h * w == self.engine.cfg.tokens:
             return self.engine
+        # resized copies: parameters only (no gradient / moment arenas), at most RESIZED_CACHE of them (LRU: dense-task
+        # evaluation over variable-size inputs must not grow device memory without bound), and valid for ONE parameter
+        # version -- any write through the engine (adamw_step, load_named) invalidates them, not only training_step
+        if self._resized_version != self.engine.param_version:
+            self._resized.clear()
+            self._resized_version = self.engine.param_version
+        if (h, w) in self._resized:
+            self._resized[(h, w)] = self._resized.pop((h, w))  # most recently used last
         if (h, w) not in self._resized:
+            while len(self._resized) >= self.RESIZED_CACHE:
+                self._resized.pop(next(iter(self._resized)))
             c = self.engine.cfg
-            e = s2.Stage2Engine(s2.make_config(c.dim, h * w, c.n_blocks, bool(c.enable_pe)), self.engine.device)
+            e = s2.Stage2Engine(s2.make_config(c.dim, h * w, c.n_blocks, bool(c.enable_pe)), self.engine.device,
+                                inference_only=True)
             src, dst = self.engine.views(), e.views()
             for k in dst:
                 if k == "pos_embed":

@@ -70,15 +70,22 @@ def param_layout(cfg: S2Config):
 
 
 class Stage2Engine:
-    def __init__(self, cfg: S2Config, device: torch.device):
+    def __init__(self, cfg: S2Config, device: torch.device, inference_only: bool = False):
+        """inference_only: a parameter arena and nothing else (no gradient / moment arenas: 3/4 of the memory) --
+        what `Denoiser._engine_for` needs for its resized copies."""
         if torch.device(device).type != "cuda":
             raise _lib.DvtError("the stage-2 engine needs a HIP device; there is no CPU fallback")
         self.cfg, self.device = cfg, torch.device(device)
         self.total, self.layout = param_layout(cfg)
         z = lambda: torch.zeros(self.total, device=self.device, dtype=torch.float32)  # noqa: E731
-        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
+        self.params = z()
+        self.inference_only = inference_only
+        self.grads = self.exp_avg = self.exp_avg_sq = None
+        if not inference_only:
+            self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z()
         self.loss = torch.zeros(4, device=self.device, dtype=torch.float32)
         self.step = 0
+        self.param_version = 0  # bumped by everything that writes the parameter arena through this engine
         self._work = {}
 
     # ---- parameters -------------------------------------------------------------------------------
@@ -112,6 +119,7 @@ class Stage2Engine:
             raise KeyError(f"stage-2 checkpoint lacks {missing}")
         for k, dst in v.items():
             dst.copy_(state[k].to(self.device, torch.float32).reshape(dst.shape))
+        self.param_version += 1
 
     # ---- kernels ----------------------------------------------------------------------------------
     def _workspace(self, batch: int, training: bool) -> torch.Tensor:
@@ -145,6 +153,8 @@ class Stage2Engine:
         """Gradients of this batch are ADDED to `self.grads`; returns the device tensor
         [loss, l2_loss, cosine_similarity_loss, 0] (no synchronisation)."""
         self._check_io(x, target, pred)
+        if self.inference_only:
+            raise _lib.DvtError("this engine was built inference_only (no gradient arena)")
         if target.shape != x.shape:
             raise _lib.DvtError("target and input shapes differ")
         w = self._workspace(x.shape[0], True)
@@ -155,7 +165,10 @@ class Stage2Engine:
 
     def adamw_step(self, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8,
                    grad_scale: float = 1.0) -> None:
+        if self.inference_only:
+            raise _lib.DvtError("this engine was built inference_only (no optimizer state)")
         self.step += 1
+        self.param_version += 1
         _lib.check(_lib.lib().dvt_adamw_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.exp_avg),
                                              _lib.ptr(self.exp_avg_sq), self.total, lr, betas[0], betas[1], eps,
                                              weight_decay, self.step, grad_scale, _lib.stream()), "dvt_adamw_step")

@@ -286,11 +286,30 @@ def train(args, rank: int, world: int, device: torch.device, model_factory=None)
                             warmup_iters=int(args.num_iterations * 0.15), start_warmup_value=0)
     history, t_log, last = [], time.time(), None
     pending = []  # (slot, event) of steps whose input buffers are still in flight
+    # The reference tests the loss on EVERY step (main_denoiser.py:223-226) with a host sync.  Here a sticky device-side
+    # flag collects "some step's loss was not finite" without a sync; it is reduced over ranks (MAX) and read wherever
+    # the host looks anyway -- log steps and BEFORE every checkpoint -- so that every rank aborts together (no rank is
+    # left blocked in all_reduce) and no NaN-poisoned parameters or AdamW moments are ever written to a checkpoint.
+    bad = torch.zeros((), device=device, dtype=torch.float32)
+    bad_step = torch.full((), -1.0, device=device, dtype=torch.float32)
+
+    def raise_if_bad(step):
+        flag = torch.stack([bad, bad_step])
+        if distributed:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        b, at = flag.cpu().tolist()
+        if b != 0.0:
+            raise FloatingPointError(f"loss is not finite (first seen at or before step {int(at)}, detected at step "
+                                     f"{step}), stopping training")
+
     try:
         for step in range(start, args.num_iterations):
             lr = float(sched[step])
             slot, (orig, den) = feeder.next()
             loss = model.training_step(orig, den)
+            nf = (~torch.isfinite(loss.detach()[0])).float()
+            bad_step = torch.where((bad == 0) & (nf != 0), torch.full_like(bad_step, float(step)), bad_step)
+            bad = torch.maximum(bad, nf)
             if distributed:
                 dist.all_reduce(eng.grads)  # SUM; the mean over ranks is taken inside the AdamW kernel
             eng.adamw_step(lr, args.weight_decay, grad_scale=1.0 / world)
@@ -301,10 +320,12 @@ def train(args, rank: int, world: int, device: torch.device, model_factory=None)
             pending.append((slot, ev))
             if len(pending) > 1:
                 feeder.release(*pending.pop(0))
-            if step % args.log_freq == 0 or step == args.num_iterations - 1:
-                vals = loss.detach().cpu().tolist()  # the only host sync of the loop
-                if not all(math.isfinite(v) for v in vals):
-                    raise FloatingPointError(f"loss is {vals[0]} at step {step}, stopping training")
+            is_log = step % args.log_freq == 0 or step == args.num_iterations - 1
+            is_save = step % args.save_freq == 0 or step == args.num_iterations - 1
+            if is_log or is_save:
+                raise_if_bad(step)  # collective: the same steps on every rank
+            if is_log:
+                vals = loss.detach().cpu().tolist()  # the only other host sync of the loop
                 now = time.time()
                 last = {"step": step, "loss": vals[0], "l2_loss": vals[1], "cosine_similarity_loss": vals[2], "lr": lr,
                         "iter_time": (now - t_log) / max(1, args.log_freq if step else 1)}
@@ -314,7 +335,7 @@ def train(args, rank: int, world: int, device: torch.device, model_factory=None)
                     print("Train  [{step}/{n}]  loss: {loss:.6f}  l2_loss: {l2_loss:.6f}  cosine_similarity_loss: "
                           "{cosine_similarity_loss:.6f}  lr: {lr:.3e}  iter_time: {iter_time:.4f}".format(
                               n=args.num_iterations, **last), flush=True)
-            if rank == 0 and (step % args.save_freq == 0 or step == args.num_iterations - 1):
+            if rank == 0 and is_save:
                 save_checkpoint(log_dir, model, step, lr, args.weight_decay)
     finally:
         feeder.close()

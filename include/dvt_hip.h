@@ -254,9 +254,10 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
                      int OW, void* stream);
 
 /* Schedule selection (developer use).  Every selectable value computes the SAME results (each one
- * is parity-tested); the knobs only trade speed -- with ONE documented exception: key 10 = 0 selects an
- * approximate replay arithmetic (v_rcp_f32 / v_sqrt_f32, 1 ulp each) that is tolerance-tested, not
- * bit-identical, and is NOT the default.  The state is process-global: set it before any
+ * is parity-tested); the knobs only trade speed -- with ONE documented exception: key 10 selects the
+ * arithmetic of the lazy Adam replay, and its DEFAULT (0: v_rcp_f32 / v_sqrt_f32, 1 ulp each) is a
+ * tolerance-tested approximation of the dense sweep, not bit-identical to it; 1 selects the IEEE replay
+ * that is.  The state is process-global: set it before any
  * work is enqueued, never concurrently with launches (the compute entry points themselves are
  * re-entrant on distinct streams).
  * key 0 = fp32 GEMM tile configuration override
@@ -279,10 +280,12 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         n >= 2 = lazy with a full refresh every n steps (default 32);
  * key 12 = the merged Adam launch also stores the bf16 weight shadow (1, default) or shadow_build_kernel runs (0);
  * key 11 = the lazy catch-up of the next step shares the Adam launch (1, default) or is its own launch (0);
- * key 10 = lazy Adam replay arithmetic: 1 (default) IEEE division / square root, the dense kernel's own update
- *         function -- every entry ends bit-identical to the dense sweep; 0: v_rcp_f32 / v_sqrt_f32 (1 ulp each), an
- *         APPROXIMATION of the reference's Adam kept for A/B timing only (agrees with the dense sweep to rounding
- *         over ~150 steps, decorrelates in the unread weight-decay jitter over thousands);
+ * key 10 = lazy Adam replay arithmetic: 0 (default) v_rcp_f32 / v_sqrt_f32 (1 ulp each), an APPROXIMATION of the
+ *         reference's Adam on the fine grid levels: agrees with the dense sweep to rounding over ~150 steps,
+ *         decorrelates in the unread weight-decay jitter over thousands, and matches the CPU oracle over the whole
+ *         1000-step schedule exactly as well as the IEEE mode does (per-patch cosine 0.99994 / 0.9992, fixture test);
+ *         1: IEEE division / square root, the dense kernel's own update function -- every entry ends bit-identical
+ *         to the dense sweep; +18 us per step = -5.4 % bench `value` in a same-box A/B (profiles/r03);
  * key 8 = Adam sweeps the arena in alternating directions on consecutive steps (1, default) or always forward (0);
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);

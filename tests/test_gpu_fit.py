@@ -280,8 +280,11 @@ def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
     print(f"fused vs layer-by-layer (C={C}): params max |diff| {float(d.max()):.3e} (scale {scale:.2f}), "
           f"mean {float(d.mean()):.3e}")
     # Adam normalises every step to ~lr, so a sign flip of a near-zero gradient moves a parameter by ~2 lr;
-    # the bulk must be tight, single elements may differ by a few lr
-    assert float(d.mean()) < 2e-5 and float(d.max()) < 0.15
+    # the bulk must be tight, single elements may differ by a few lr.  Measured distribution of d.max over 10 seeds x 3
+    # widths (profiles/r03/tolerance_study.json, T1; tools/tolerance_study.py): cross-path 0.015-0.052 (median 0.035)
+    # while the SAME path launched twice agrees to 1e-6 -- the difference is the two paths' bf16 rounding order, not
+    # scheduling noise.  Bound = 2 x the observed maximum.
+    assert float(d.mean()) < 2e-5 and float(d.max()) < 0.1
     assert per_patch_cos(o1, o0).min() > 0.9999
 
 
@@ -314,6 +317,9 @@ def test_bf16_fit_any_batch_size(built_lib, B):
     assert per_patch_cos(outs[0][1], outs[1][1]).min() > 0.9999
 
 
+LAZY_REPLAY_DEFAULT = 0  # dvt_tune_set(10, .): 0 = v_rcp / v_sqrt replay (default), 1 = IEEE replay
+
+
 def _bf16_run(built_lib, feats, xy, idx, T, knobs=(), splits=None, C=768, seed=1, warmup=None):
     from dvt_amd.fit import FitEngine, FitSettings
     n_rows = feats.shape[0]
@@ -329,6 +335,7 @@ def _bf16_run(built_lib, feats, xy, idx, T, knobs=(), splits=None, C=768, seed=1
     finally:
         built_lib.dvt_tune_set(9, 32)
         built_lib.dvt_tune_set(7, 1)
+        built_lib.dvt_tune_set(10, LAZY_REPLAY_DEFAULT)
     return eng
 
 
@@ -383,10 +390,14 @@ def test_lazy_adam_equals_dense_adam(built_lib):
     T = 150
     idx = np.random.RandomState(5).randint(0, f.shape[0], (T, 2048)).astype(np.int32)
     lazy = _bf16_run(built_lib, f, c, idx, T)
+    ieee = _bf16_run(built_lib, f, c, idx, T, knobs=[(10, 1)])
     dense = _bf16_run(built_lib, f, c, idx, T, knobs=[(9, 0)])
-    # default replay = the dense kernel's own update function (IEEE division / sqrt): never-touched entries are
-    # BIT-IDENTICAL to the dense sweep (the opt-in 1-ulp replay, dvt_tune_set(10, 0), sat at 1.4e-4 relative here)
-    _arena_agreement(lazy, dense, _never_touched_mask(built_lib, lazy, c, idx), "lazy vs dense Adam", rtol=0.0)
+    mask = _never_touched_mask(built_lib, lazy, c, idx)
+    # IEEE replay = the dense kernel's own update function: never-touched entries are BIT-IDENTICAL to the dense sweep
+    _arena_agreement(ieee, dense, mask, "IEEE lazy replay vs dense Adam", rtol=0.0)
+    # default replay (150 steps of 1-ulp rcp / sqrt differences in a recurrence that contracts p to ~4e-7: 1.4e-4
+    # relative, 6e-11 absolute)
+    _arena_agreement(lazy, dense, mask, "lazy vs dense Adam", rtol=2e-3)
     assert float(lazy.grads.abs().max()) == 0.0 and int(lazy.touched.abs().max()) == 0
     la, ld = lazy.loss_log(), dense.loss_log()
     worst = max(abs(la[s]["loss"] - ld[s]["loss"]) / abs(ld[s]["loss"]) for s in range(T))
@@ -440,8 +451,12 @@ def test_batched_fused_fits_equal_separate_fits(built_lib):
     for j in range(k):
         d = (solo[j].params - batched[j].params).abs()
         # single parameters may differ by a few lr after 70 steps (Adam turns the sign of a near-zero gradient into
-        # +-lr; atomics order differs between the launches): the bulk must be tight, the output must agree
-        assert float(d.mean()) < 2e-5 and float(d.max()) < 0.3, (j, float(d.mean()), float(d.max()))
+        # +-lr; atomics order differs between the launches): the bulk must be tight, the output must agree.
+        # Measured over 10 seeds x 2 fits (profiles/r03/tolerance_study.json, T2): batched-vs-solo d.max 1.5e-8 .. 0.095,
+        # saved-tensor cosine min 0.9994; the SAME solo configuration launched twice: d.max up to 0.095 as well, cosine
+        # min 0.9999 -- i.e. this is the run-to-run spread of one path (fp32 atomics order in the coarse grid levels).
+        # Bounds = 2 x the observed maximum / the observed minimum rounded down.
+        assert float(d.mean()) < 2e-5 and float(d.max()) < 0.2, (j, float(d.mean()), float(d.max()))
         a, b = solo[j].infer(data[j][1][-1].to(DEV)), batched[j].infer(data[j][1][-1].to(DEV))
         assert per_patch_cos(a.cpu(), b.cpu()).min() > 0.999
         assert float(batched[j].grads.abs().max()) == 0.0
@@ -449,21 +464,18 @@ def test_batched_fused_fits_equal_separate_fits(built_lib):
 
 def test_long_run_many_list_chunks(built_lib):
     """2500 steps = 20 chunks of sorted lists, 78 refreshes, replay tables longer than their LDS window.
-    * exact replay mode (the DEFAULT since round 3: IEEE division / sqrt, the dense kernel's own update function): every
+    * exact replay mode (dvt_tune_set(10, 1): IEEE division / sqrt, the dense kernel's own update function): every
       never-touched entry ends BIT-IDENTICAL to the dense sweep in p, m and v -- step counters, pending gradients,
       per-step scalar tables, refresh and chunk bookkeeping cannot be off by anything;
-    * opt-in fast mode (dvt_tune_set(10, 0), 1-ulp rcp / sqrt): the same entries' weight-decay jitter (|p| ~ 2e-4, never read by anything)
+    * default mode (1-ulp rcp / sqrt): the same entries' weight-decay jitter (|p| ~ 2e-4, never read by anything)
       decorrelates over thousands of steps like any two runs would; what is read -- losses, the saved tensor -- agrees."""
     V, H, C, T = 4, 37, 768, 2500
     feats, xy = synthetic_image(V, H, H, C, seed=7)
     f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
     idx = np.random.RandomState(7).randint(0, f.shape[0], (T, 2048)).astype(np.int32)
     dense = _bf16_run(built_lib, f, c, idx, T, knobs=[(9, 0)])
-    exact = _bf16_run(built_lib, f, c, idx, T)            # the default: IEEE replay
-    try:
-        lazy = _bf16_run(built_lib, f, c, idx, T, knobs=[(10, 0)])  # the approximate 1-ulp replay (opt-in)
-    finally:
-        built_lib.dvt_tune_set(10, 1)
+    exact = _bf16_run(built_lib, f, c, idx, T, knobs=[(10, 1)])  # IEEE replay
+    lazy = _bf16_run(built_lib, f, c, idx, T, knobs=[(10, 0)])   # 1-ulp replay (default)
     mask = _never_touched_mask(built_lib, lazy, c, idx)
     assert int(mask.sum()) > 1000
     n8 = mask.numel() * 8
@@ -480,6 +492,10 @@ def test_long_run_many_list_chunks(built_lib):
     for other in (exact, lazy):
         assert float(other.grads.abs().max()) == 0.0 and int(other.touched.abs().max()) == 0
         lo = other.loss_log()
-        # (2500 steps of a chaotic bf16 training run: these two only guard against a gross failure)
-        assert abs(lo[T - 1]["loss"] - ld[T - 1]["loss"]) < 5e-2 * abs(ld[T - 1]["loss"])
+        # 2500 steps of a bf16-mode run.  Measured over 10 seeds (profiles/r03/tolerance_study.json, T3): final-loss
+        # relative difference vs the dense sweep <= 8e-4 (exact replay) / 1.4e-3 (1-ulp replay), and 1.4e-3 for the DENSE
+        # path against ITSELF launched twice; saved-tensor cosine min 0.9979 / 0.9937 / 0.9963 (dense rerun).  So the
+        # round-2 loss bound of 2 % is restored; the cosine bound stays at 0.99 because the same-path rerun itself
+        # reaches 0.9963 (the old 0.995 sat inside the run-to-run spread).
+        assert abs(lo[T - 1]["loss"] - ld[T - 1]["loss"]) < 2e-2 * abs(ld[T - 1]["loss"])
         assert per_patch_cos(other.infer(xy[-1].to(DEV)).cpu(), ref).min() > 0.99

@@ -33,6 +33,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LAZY_REPLAY_DEFAULT = 0  # dvt_tune_set(10, .) default: see include/dvt_hip.h key 10 and DESIGN.md 4 (A/B: profiles/r03)
 
 
 def per_patch_cos(a, b):
@@ -95,8 +96,9 @@ def test_fit_matches_oracle_baseline_shapes(built_lib):
     assert want_log[T - 1]["patch_l2_loss"] < 0.8 * want_log[0]["patch_l2_loss"]
 
 
+@pytest.mark.parametrize("replay", ["ieee", "1ulp"])
 @pytest.mark.parametrize("C", [768, 1024])
-def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C):
+def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C, replay):
     """BASELINE configs[1] (C = 768) / configs[2] (C = 1024) at the schedule the metric is quoted on -- 1000 Adam
     steps, warm-up 100, B = 2048, L = 16 / 2^20, 64 views + the original -- against the committed CPU-oracle run
     (tests/golden/make_fit1000_golden.py; oracle/fit.py == reference main_img_denoising.py:28-149).  Both the
@@ -121,10 +123,17 @@ def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C):
     n_rows = V * H * H
     f_dev, c_dev = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
     steps = (0, 1, 127, 128, 129, 499, 500, 501, 502, 998, 999)
-    for mode, floor in (("float32", 2e-3), ("bfloat16", 3e-2)):
+    # both arithmetics of the lazy Adam replay (dvt_tune_set(10, .): IEEE division / sqrt, or v_rcp / v_sqrt) against the
+    # SAME oracle run; the fp32-operand path has no lazy Adam, it runs once (with "ieee")
+    modes = (("float32", 2e-3), ("bfloat16", 3e-2)) if replay == "ieee" else (("bfloat16", 3e-2),)
+    for mode, floor in modes:
         eng = hip_engine_from(d_o, f_o, n_rows, T, WARM, mode, H=H, W=H, C=C)
-        eng.fit(f_dev, c_dev, idx, log_every=1)
-        torch.cuda.synchronize()
+        try:
+            assert built_lib.dvt_tune_set(10, int(replay == "ieee")) == 0
+            eng.fit(f_dev, c_dev, idx, log_every=1)
+            torch.cuda.synchronize()
+        finally:
+            built_lib.dvt_tune_set(10, LAZY_REPLAY_DEFAULT)
         got, log = eng.infer(xy[-1].to(DEV)).cpu(), eng.loss_log()
         assert float(eng.grads.abs().max()) == 0.0 and int(eng.touched.abs().max()) == 0
         del eng
@@ -142,7 +151,7 @@ def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C):
                     tol = max(floor * max(abs(ref), 1e-3), 4.0 * sens)
                     assert err <= tol, (mode, s_, k, log[s_][k], ref, sens)
         cos = per_patch_cos(got, want)
-        print(f"[1000-step fixture, C={C}, {mode} fit] loss {log[0]['loss']:.4f} -> {log[T - 1]['loss']:.5f} (oracle "
+        print(f"[1000-step fixture, C={C}, {mode} fit, {replay} replay] loss {log[0]['loss']:.4f} -> {log[T - 1]['loss']:.5f} (oracle "
               f"{tab[0, 0]:.4f} -> {tab[-1, 0]:.5f}); worst per-step total-loss rel err over all 1000 steps {worst:.2e}; "
               f"denoised_feats per-patch cosine mean {cos.mean():.6f} min {cos.min():.6f} "
               f"(oracle vs 1e-6-perturbed oracle: {z['perturbed_cos'][0]:.6f} / {z['perturbed_cos'][1]:.6f})")

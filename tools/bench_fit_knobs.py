@@ -34,7 +34,7 @@ for name, knobs in (("default (shadow in Adam)", {}), ("shadow_build_kernel", {1
     print(f"{name:32s}: phase 1 {ts[0]:7.1f} us/step, phase 2 {ts[1]:7.1f} us/step", flush=True)
 L.dvt_tune_set(7, 1)
 L.dvt_tune_set(9, 32)
-L.dvt_tune_set(10, 1)
+L.dvt_tune_set(10, 0)
 L.dvt_tune_set(11, 1)
 L.dvt_tune_set(12, 1)
 L.dvt_tune_set(8, 1)

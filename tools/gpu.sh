@@ -13,6 +13,7 @@ TAG=${DVT_TAG:-run}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+n_bench=0; n_py=0
 for stage in "$@"; do
   name=${stage%%:*}; arg=${stage#*:}; [ "$arg" == "$stage" ] && arg=""
   echo "=== stage $stage"
@@ -27,7 +28,7 @@ for stage in "$@"; do
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?"; tail -4 $O/smoke.txt ;;
     bench)
-      f=$O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9' '_' | cut -c1-60).log
+      n_bench=$((n_bench+1)); f=$O/bench${n_bench}_$(echo "$arg" | tr -c 'A-Za-z0-9=' '_' | rev | cut -c1-50 | rev).log
       timeout 1500 python bench.py $(echo "$arg" | tr ':' ' ') > $f 2>&1; echo "bench rc=$?"
       tail -1 $f > ${f%.log}.json; python - "${f%.log}.json" <<'PY'
 import json, sys
@@ -60,7 +61,7 @@ PY
       cd $R; head -30 $O/pmc/FETCH_SIZE.txt | cut -c1-150 ;;
     py)
       file=${arg%%:*}; rest=${arg#*:}; [ "$rest" == "$arg" ] && rest=""
-      f=$O/$(basename $file .py)_$(echo "$rest" | tr -c 'A-Za-z0-9' '_' | cut -c1-40).log
+      n_py=$((n_py+1)); f=$O/$(basename $file .py)${n_py}_$(echo "$rest" | tr -c 'A-Za-z0-9=' '_' | cut -c1-40).log
       timeout 1500 python $file $(echo "$rest" | tr ':' ' ') > $f 2>&1; echo "py rc=$?"; tail -${DVT_TAIL:-60} $f | cut -c1-260 ;;
     *) echo "unknown stage $stage" ;;
   esac

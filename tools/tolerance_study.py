@@ -43,7 +43,7 @@ def run(feats, xy, idx, T, C, seed, knobs=(), warm=None, log=1):
     return e
 
 
-DEFAULT_REPLAY = int(os.environ.get("DVT_DEFAULT_REPLAY", "1"))
+DEFAULT_REPLAY = int(os.environ.get("DVT_DEFAULT_REPLAY", "0"))
 
 
 def stats(v):
