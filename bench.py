@@ -33,17 +33,31 @@ for _p in (ROOT, os.path.join(ROOT, "denoising-vit_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# HBM-side bytes per launch from PMC counters, collected in separate rocprofv3 --pmc passes
-# (profiles/r02/pmc_final/{fetch,write}.txt; tools/gpu_r3c.sh on a 128-view batch + 60 fit steps):
-# (FETCH_SIZE x 2 [gfx950 wide-load correction, MI355X_MICROARCH.md HBM section] + WRITE_SIZE)
-# x 1024 B / launches.  Calibration: layernorm reads + writes 830.6 MB/launch = its algorithmic 830 MB.
-# vit_gemm = launch-weighted mean of the qkv (1932 MB), proj / fc2 (2081 MB) and fc1 (2494 MB) GEMMs;
-# adam = the dense part only (coarse grid levels + MLPs + G; the fine levels are stepped lazily).
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {"vit_gemm": 2146.6e6, "vit_attn": 1107.6e6, "adam": 53.7e6,
-                                "fit_gemm": 66.4e6, "fit_rows": 94.4e6, "grid": None}
+# HBM-side bytes per launch from PMC counters: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over
+# tools/pmc_target.py at THIS bench's batching (110-view extractor launches + 60 fit steps; `bash tools/gpu.sh pmc`),
+# reduced by tools/pmc_traffic.py to profiles/<round>/pmc_traffic.json: (FETCH_SIZE x 2 [gfx950 wide-load correction,
+# MI355X_MICROARCH.md HBM section] + WRITE_SIZE) x 1024 B / launches, calibrated there on layernorm (reads + writes =
+# its algorithmic bytes).  The newest committed file wins; without one `traffic` is null.
+def _pmc_traffic():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return {}, None
+    try:
+        with open(files[-1]) as fh:
+            doc = json.load(fh)
+        return {k: v.get("bytes_per_launch") for k, v in doc.get("probes", {}).items()}, os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return {}, None
+
+
+PMC_TRAFFIC_BYTES_PER_LAUNCH, PMC_TRAFFIC_SOURCE = _pmc_traffic()
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA
+# SURVEY.md 8(d) image-level ceilings for ViT-B/14: extractor 233.1 TFLOP / 2.5 PF/s = 93 ms, fit 0.549 TB / 8 TB/s =
+# 69 ms per image -> serial 1 / (93 + 69 ms) = 6.2 images/s, phases overlapped across images 1 / max = 10.7 images/s
+IMAGE_CEILINGS = {"vit_base_patch14_dinov2.lvd142m": (6.2, 10.7)}
 
 
 def parse():
@@ -68,6 +82,10 @@ def parse():
                         "its autocast mode, which the ViT of this bench always runs in)")
     p.add_argument("--pixel-bsz", type=int, default=2048,
                    help="developer experiment only: anything but 2048 is not BASELINE's workload")
+    p.add_argument("--no-npy", action="store_true",
+                   help="do not write the two .npy files per image (tmpfs) inside the timed region")
+    p.add_argument("--save-root", default=None, help="where the timed region writes its .npy pairs (default: a "
+                                                     "directory under /dev/shm, removed afterwards)")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="images in flight per GPU (1 = strictly serial reference flow)")
     return p.parse_args()
@@ -207,6 +225,22 @@ def main():
         for k in range(n):
             yield k, (lambda slot: None)  # views already resident
 
+    # one image includes its two .npy writes (main_img_denoising.py:131-146).  They happen on the
+    # retiring thread of the pipeline, as in the driver (dvt_amd/stage1.py), into a tmpfs directory: the metric must
+    # not depend on the GPU box's disk.  Layout and atomic rename are the driver's.
+    save_root = None
+    if not a.no_npy:
+        import tempfile
+        save_root = a.save_root or tempfile.mkdtemp(prefix=f"dvt_bench_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    written = [0]
+
+    def write_pair(tag, raw_h, den_h):
+        if save_root is None:
+            return
+        misc.atomic_save_npy(os.path.join(save_root, "raw_features", a.model, f"{tag % 16}.npy"), raw_h)
+        misc.atomic_save_npy(os.path.join(save_root, "denoised_features", a.model, f"{tag % 16}.npy"), den_h)
+        written[0] += int(raw_h.nbytes + den_h.nbytes)
+
     def set_fit_dtype(mode):
         for e in st.engines:
             e.s.mlp_dtype = mode
@@ -225,7 +259,8 @@ def main():
     # distort the metric
     probes = [n for n in probes if n in ("adam", "vit_gemm", "vit_attn")]
     _lib.prof_enable(probes)
-    n_done, elapsed, per_rank = D.timed(lambda: st.run(jobs(a.steps)), device)
+    n_done, elapsed, per_rank = D.timed(lambda: st.run(jobs(a.steps), on_result=write_pair), device)
+    npy_bytes = written[0]
     assert n_done == a.steps
     prof = {n: _lib.prof_collect(n) for n in probes}
     _lib.prof_enable([])
@@ -235,24 +270,28 @@ def main():
         k2 = max(2, a.steps // 3)
         set_fit_dtype(other)
         st.run(jobs(1))
-        n2, el2, _ = D.timed(lambda: st.run(jobs(k2)), device)
+        n2, el2, _ = D.timed(lambda: st.run(jobs(k2), on_result=write_pair), device)
         st.process(lambda slot: None)
         second = {"images_per_s": world * n2 / el2, "images_timed_per_rank": n2,
                   "t_fit_s_serial": st.timings[-1]["t_fit"]}
         set_fit_dtype(a.fit_dtype)
     full_fp32 = None
-    if not a.no_fp32_fit and rank == 0 and world == 1:
-        # the reference's DEFAULT precision end to end (--dtype float32: fp32 extractor + fp32 fit), one image,
-        # strictly serial (exact-fp32 matrix cores: 1/16 of the bf16 rate)
+    if not a.no_fp32_fit and world == 1 and a.model in IMAGE_CEILINGS:
+        # the reference's DEFAULT precision end to end (--dtype float32: fp32 extractor + fp32 fit), the same pipelined
+        # driver inside the same timed bracket, 3 images (exact-fp32 matrix cores: 1/16 of the bf16 rate)
         set_fit_dtype("float32")
         st.extract_dtype = "float32"
-        st.process(lambda slot: None)  # first call builds the fp32 weight copies / workspace
+        st.run(jobs(1))  # builds the fp32 weight copies / workspace, warms the pipeline
+        n3, el3, _ = D.timed(lambda: st.run(jobs(3), on_result=write_pair), device)
         st.process(lambda slot: None)
         t = st.timings[-1]
-        full_fp32 = {"images_per_s": 1.0 / (t["t_extract"] + t["t_fit"]), "t_extract_s": t["t_extract"],
-                     "t_fit_s": t["t_fit"], "images_timed": 1, "flow": "serial"}
+        full_fp32 = {"images_per_s": n3 / el3, "images_timed": n3, "flow": f"pipelined (depth {a.pipeline_depth})",
+                     "t_extract_s_serial": t["t_extract"], "t_fit_s_serial": t["t_fit"]}
         st.extract_dtype = "bfloat16"
         set_fit_dtype(a.fit_dtype)
+    if save_root is not None and a.save_root is None:
+        import shutil
+        shutil.rmtree(save_root, ignore_errors=True)
 
     if rank == 0:
         out = {
@@ -262,17 +301,24 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: DINOv2 ViT-B/14 518x518, 768 views + original, "
-                            "1k-step per-image fit (B=2048, L=16, F=8, 2^20 hash) on 1 MI355X per rank",
+                "workload": (("BASELINE configs[1]: DINOv2 ViT-B/14" if "vit_base" in a.model else
+                              f"BASELINE configs[2]: DINOv2 ViT-L/14, {a.fit_batch} concurrent neural fields per GPU"
+                              if "vit_large" in a.model else a.model) +
+                             f" 518x518, {a.views} views + original, {a.num_iters}-step per-image fit (B={a.pixel_bsz}, "
+                             "L=16, F=8, 2^20 hash) on 1 MI355X per rank; one image = 769 ViT forwards + the fit + the "
+                             "final inference + D2H + " + ("its two .npy files (tmpfs)" if not a.no_npy else "NO file writes")),
                 "model": a.model, "views": a.views + 1, "num_iters": a.num_iters,
                 "warmup_iters": a.warmup_iters, "pixel_bsz": a.pixel_bsz,
+                "npy_writes": None if a.no_npy else {"where": "tmpfs (/dev/shm), retiring thread, atomic rename",
+                                                      "bytes_per_image": npy_bytes // max(1, a.steps)},
                 "precision_mode": "reference --dtype bfloat16 (autocast) end to end: ViT bf16 MFMA / fp32 accumulate; "
                                   f"fit MLP GEMMs {a.fit_dtype} operands / fp32 accumulate + outputs; hash grid, "
                                   "losses, Adam: fp32.  The reference's DEFAULT is --dtype float32 (see value_fp32_fit)",
                 "fit_dtype": a.fit_dtype,
                 "fit_step": ("bfloat16: fused row kernel, hash-grid gradient gathered from per-step sorted lists, dense Adam "
                              "for coarse grid levels + MLPs + G, lazy Adam (same recurrence applied on demand, refresh every 32 "
-                             "steps, v_rcp / v_sqrt 1-ulp replay) for the fine grid levels; float32: layer-by-layer kernels, "
+                             "steps; replay arithmetic v_rcp / v_sqrt, 1 ulp each, unless --tune 10=1 selects the IEEE replay) for the fine "
+                             "grid levels; float32: layer-by-layer kernels, "
                              "dense Adam"),
                 "extractor": "LayerNorm folded into the qkv / fc1 GEMMs (bf16 path); LayerNorm kernels in the fp32 path",
                 "weights": "random init (no network for checkpoints)",
@@ -316,7 +362,14 @@ def main():
         if kern:
             dom = max(kern, key=lambda k: kern[k]["ms_per_image"])
             out["roofline"] = {"kernel": dom, **{k: kern[dom][k] for k in
-                                                 ("bound", "achieved", "peak", "unit", "frac", "traffic")}}
+                                                 ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+                               "traffic_source": PMC_TRAFFIC_SOURCE}
+        if a.model in IMAGE_CEILINGS and a.num_iters == 1000 and a.views == 768:
+            ser, ovl = IMAGE_CEILINGS[a.model]
+            per_gpu = out["value"] / world
+            out["image_level"] = {"per_gpu_images_per_s": per_gpu, "ceiling_serial": ser, "ceiling_overlapped": ovl,
+                                  "frac_of_serial_ceiling": per_gpu / ser, "frac_of_overlapped_ceiling": per_gpu / ovl,
+                                  "definition": "SURVEY.md 8(d): 233.1 TFLOP / 2.5 PF/s + 0.549 TB / 8 TB/s per image"}
             out["kernels"] = kern  # inside the timed (pipelined) region
             out["kernels_isolated"] = kernel_table(prof_iso, 1)  # serial pass, one stream
         if world == 1 and not a.no_cpu_baseline:

@@ -79,6 +79,7 @@ struct GemmBArgs {
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int mblock;         // M panels per block of the tile order (1: n fastest)
   int tpw;            // 8q kernel: consecutive tiles of the order per workgroup
+  int stagger;        // 8q kernel: first-round workgroups start (bid / 8 % 8) * stagger half-microseconds late
   int nt_store;       // bf16 outputs with the non-temporal hint
   // LayerNorm folded into the GEMMs (see ln_fold): consumer side (EPI_QKV / EPI_GELU) ...
   const float2* ln_stats;  // [M] (mean, rstd) of the fp32 residual rows; A is then bf16(x), W is bf16(gamma (.) W)
@@ -1089,7 +1090,7 @@ struct QSrc {  // one tile's operands: descriptors based at its first A / W row
 // one k-tile = 4 phases.  STG: 0 steady (this tile's k-tiles t+1, t+2); 1 / 2 the last two k-tiles of the
 // workgroup's LAST tile (nothing left to stage); 3 / 4 the last two k-tiles when another tile follows (stage the
 // next tile's k-tiles 0 and 1 where the steady state would stage t+1 / t+2).
-template <bool SWAP, int STG, int W1, int W2, int W4>
+template <bool SWAP, int STG, int W1, int W2, int W4, int ABL = 0>
 __device__ __forceinline__ void q_ktile(f32x4 (&acc)[8][4], char* smem, char* ldsw, const QSrc& cur, const QSrc& nxt,
                                         int t, int nk, const int (&voA)[2], const int (&voB)[2], int hA, int hB,
                                         int oa0, int oa1, int ob0, int ob1) {
@@ -1104,14 +1105,25 @@ __device__ __forceinline__ void q_ktile(f32x4 (&acc)[8][4], char* smem, char* ld
   constexpr bool ST12 = (STG == 0 || STG == 1 || STG == 3 || STG == 4);
   constexpr bool ST34 = (STG == 0 || STG == 3 || STG == 4);
   bf16x8 a[4][2], b0[2][2], b1[2][2];
-#define Q_RD(p_, off) (*reinterpret_cast<const bf16x8*>((p_) + (off)))
+#define Q_RD(p_, off) ((ABL & 2) ? (bf16x8){(short)ob0, (short)oa0, (short)ob1, (short)oa1, 1, 2, 3, 4} : *reinterpret_cast<const bf16x8*>((p_) + (off)))
 #define Q_STAGE(RS, VO, soff, off)                                                                               \
   do {                                                                                                           \
+    if constexpr (!(ABL & 4)) {                                                                                  \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, VO[0], soff, 0, 0);              \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, VO[1], soff, 0, 0);       \
+    }                                                                                                            \
   } while (0)
+#define Q_BAR2() do { if constexpr (!(ABL & 16)) P8_BAR(); } while (0)
+#define Q_BAR1() do { if constexpr (!(ABL & 32)) P8_BAR(); } while (0)
 #define Q_MFMA(IB, JB, AF, BF)                                                                       \
   do {                                                                                               \
+    if constexpr (ABL & 1) {                                                                         \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(AF[i][ks]));            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(BF[j][ks]));            \
+      }                                                                                              \
+      break;                                                                                         \
+    }                                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
@@ -1135,10 +1147,10 @@ __device__ __forceinline__ void q_ktile(f32x4 (&acc)[8][4], char* smem, char* ld
   }
   if constexpr (ST12) Q_STAGE(s1.b, voB, hB + k1 * 128, bn_ + OFF_B1);
   wait_vm_q<W1>();
-  P8_BAR();
+  Q_BAR1();
   P8_LGKM0();
   Q_MFMA(0, 0, a, b0);
-  P8_BAR();
+  Q_BAR2();
   /* P2 */
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1147,10 +1159,10 @@ __device__ __forceinline__ void q_ktile(f32x4 (&acc)[8][4], char* smem, char* ld
   }
   if constexpr (ST12) Q_STAGE(s1.a, voA, hA + k1 * 128, bn_ + OFF_A1);
   wait_vm_q<W2>();
-  P8_BAR();
+  Q_BAR1();
   P8_LGKM0();
   Q_MFMA(0, 2, a, b1);
-  P8_BAR();
+  Q_BAR2();
   /* P3 */
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -1158,19 +1170,21 @@ __device__ __forceinline__ void q_ktile(f32x4 (&acc)[8][4], char* smem, char* ld
     a[i][1] = Q_RD(base_ + OFF_A1 + i * 2048, oa1);
   }
   if constexpr (ST34) Q_STAGE(s2.a, voA, k2 * 128, bo_ + OFF_A0);
-  P8_BAR();
+  Q_BAR1();
   P8_LGKM0();
   Q_MFMA(4, 2, a, b1);
-  P8_BAR();
+  Q_BAR2();
   /* P4 */
   if constexpr (ST34) Q_STAGE(s2.b, voB, k2 * 128, bo_ + OFF_B0);
   wait_vm_q<W4>();
-  P8_BAR();
+  Q_BAR1();
   Q_MFMA(4, 0, a, b0);
-  P8_BAR();
+  Q_BAR2();
 #undef Q_RD
 #undef Q_STAGE
 #undef Q_MFMA
+#undef Q_BAR1
+#undef Q_BAR2
 }
 
 // What an epilogue needs of the launch arguments.  Read from the kernarg segment (scalar loads) per tile, behind an
@@ -1374,7 +1388,7 @@ __device__ __forceinline__ TileMap map_tile_id(int id, int mt, int nt, int group
 }
 
 // the k-loop + epilogue of one tile; FIRST: the workgroup's first tile (its prologue was issued by the caller)
-template <int EPI, bool SWAP>
+template <int EPI, bool SWAP, int ABL = 0>
 __device__ __forceinline__ void q_tile(kernarg_ptr_t kp, f32x4 (&acc)[8][4], char* smem, char* ldsw, const QSrc& cur,
                                        const QSrc& nxt, bool first, int nk, const int (&voA)[2],
                                        const int (&voB)[2], int hA, int hB, int oa0, int oa1, int ob0, int ob1, int mb,
@@ -1388,25 +1402,30 @@ __device__ __forceinline__ void q_tile(kernarg_ptr_t kp, f32x4 (&acc)[8][4], cha
 #define Q_TAIL nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1
   int t = 0;
   if (!first) {  // the previous tile's epilogue stores sit between this tile's first DMAs and the ones issued now
-    q_ktile<SWAP, 0, 8 + S, 8 + S, 8 + S>(Q_ARGS, 0, Q_TAIL);
+    q_ktile<SWAP, 0, 8 + S, 8 + S, 8 + S, ABL>(Q_ARGS, 0, Q_TAIL);
     t = 1;
   }
-  for (; t < nk - 2; ++t) q_ktile<SWAP, 0, 8, 8, 8>(Q_ARGS, t, Q_TAIL);
+  for (; t < nk - 2; ++t) q_ktile<SWAP, 0, 8, 8, 8, ABL>(Q_ARGS, t, Q_TAIL);
   // The last two k-tiles ALWAYS continue the ring into `nxt` -- when no tile follows, `nxt` is a zero-length
   // descriptor (out-of-range buffer loads: no memory traffic) and the DMAs are drained before the workgroup exits.
   // A second code path for "no next tile" would merge with 128 live accumulators behind it: hipcc's register
   // allocator then spills ~280 VGPRs (measured on the .s), the straight-line body needs 206 and none.
-  q_ktile<SWAP, 3, 8, 8, 8>(Q_ARGS, nk - 2, Q_TAIL);
-  q_ktile<SWAP, 4, 8, 8, 8>(Q_ARGS, nk - 1, Q_TAIL);
+  q_ktile<SWAP, 3, 8, 8, 8, ABL>(Q_ARGS, nk - 2, Q_TAIL);
+  q_ktile<SWAP, 4, 8, 8, 8, ABL>(Q_ARGS, nk - 1, Q_TAIL);
 #undef Q_ARGS
 #undef Q_TAIL
   asm volatile("" : "+s"(kp));  // opaque: the loads below are not hoisted above the k-loop
   const EpiArgs e = load_epi_args(kp);
-  if constexpr (SWAP) q_epilogue_swapped<EPI>(e, acc, mb, nb, lane);
+  if constexpr (ABL & 8) {  // ablation: no epilogue (accumulators kept alive)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+  } else if constexpr (SWAP) q_epilogue_swapped<EPI>(e, acc, mb, nb, lane);
   else q_epilogue_v(e, acc, mb, nb, lane);
 }
 
-template <int EPI>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8q(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[8 * 16384];  // the ring only: 8 half-tile slots
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1421,6 +1440,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const int first_tile = wid * p.tpw;
   const int count = min(p.tpw, ntiles - first_tile);
+  // De-synchronise the CUs.  Every workgroup of a launch starts at the same instant and every tile takes the same
+  // time, so all 256 CUs reach their epilogues together: 256 x 128 KB = the whole 32-MB L2 written within a
+  // microsecond, once per tile period, and the store issue stalls on the HBM write-back (measured: the epilogue costs
+  // 5.6 us of a 26-us tile, and "barriers + epilogue only" runs at 3.3-4.2 TB/s of writes).  The first workgroup
+  // of every CU therefore starts up to 7/8 of a tile period late, in 8 phase groups; later workgroups inherit the
+  // phase of the one they replace.
+  if (p.stagger > 0 && blockIdx.x < 256) {
+    const int slot = (blockIdx.x >> 3) & 7;
+    for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles ~ 0.5 us
+  }
   const int nk = p.K / GBK;
 
   // per-lane parts of the DMA source addresses (bytes); the half (h) and the k-tile go into the scalar offset
@@ -1476,7 +1505,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int m1, n1;
     const QSrc nxt = src_of(first_tile + ti + 1, ti + 1 < count, m1, n1);
     const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-#define Q_CALL(SW) q_tile<EPI, SW>(kp, acc, smem, ldsw, cur, nxt, ti == 0, nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1, mb, nb, lane)
+#define Q_CALL(SW) q_tile<EPI, SW, ABL>(kp, acc, smem, ldsw, cur, nxt, ti == 0, nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1, mb, nb, lane)
     if constexpr (EPI == EPI_QKV) {
       if (n0 >= 2 * p.dim) Q_CALL(false);
       else Q_CALL(true);
@@ -1507,6 +1536,8 @@ int g_vit_nt_store = 0;
 int g_vit_fuse_ln = 1;
 // 8q kernel: tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
 int g_vit_tpw = 0;
+int g_vit_stagger = 0;  // dvt_tune_set(1, -400 - n): n half-microseconds per phase slot (0 off); -399: auto
+int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 8q kernel (EPI_BIAS only)
 
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
@@ -1543,7 +1574,16 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       const int tiles = (a.M / 256) * nt;
       tpw = tpw > tiles ? tiles : tpw;
       a.tpw = tpw;
-      hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI>), dim3((tiles + tpw - 1) / tpw), dim3(512), 0, s, a);
+      // per-slot delay in half-microseconds: tile period (~2.1 us per k-tile + 2 us) / 8 slots; -400 - n overrides (0 = off)
+      a.stagger = g_vit_stagger >= 0 ? g_vit_stagger : (int)((nk * 2.1 + 2.0) / 8.0 * 2.0 + 0.5);
+      const dim3 grid((tiles + tpw - 1) / tpw);
+      bool done = false;
+      if constexpr (EPI == EPI_BIAS) {  // developer ablations of the 8q structure (timing only, results are wrong)
+#define Q_ABL(n) if (g_vit_abl == n) { hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI, n>), grid, dim3(512), 0, s, a); done = true; }
+        Q_ABL(1) Q_ABL(2) Q_ABL(4) Q_ABL(8) Q_ABL(16) Q_ABL(3) Q_ABL(6) Q_ABL(7) Q_ABL(14) Q_ABL(15) Q_ABL(48) Q_ABL(24)
+#undef Q_ABL
+      }
+      if (!done) hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI>), grid, dim3(512), 0, s, a);
     } else if (g_vit_gemm_variant >= 4)
       hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     else
@@ -1907,6 +1947,14 @@ int dvt_vit_tune(int v) {
   }
   if (v == -50 || v == -51) {  // non-temporal bf16 output stores off / on
     g_vit_nt_store = v == -51;
+    return 0;
+  }
+  if (v <= -399) {
+    g_vit_stagger = v == -399 ? -1 : -400 - v;
+    return 0;
+  }
+  if (v <= -300) {
+    g_vit_abl = -300 - v;
     return 0;
   }
   if (v <= -200) {  // -200 - n: tiles per workgroup of the 8q kernel, 0 = auto

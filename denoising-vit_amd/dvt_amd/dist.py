@@ -23,8 +23,37 @@ def env_ranks() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", 0)))
 
 
+def pin_host_threads(local_rank: int | None = None, local_world: int | None = None) -> dict:
+    """Host budget of one rank on a multi-GPU node.  Every rank runs ~4 host threads (extractor,
+    fit, retire + write, index-stream look-ahead) that spend most of their life blocked on a full HIP queue, plus
+    the numpy index draws (2 M draws = ~20 ms per image) and torch's intra-op pool.  Eight ranks on one host must not
+    fight over the same cores: each rank gets a contiguous slice of the CPUs this process may run on
+    (`sched_setaffinity`) and caps its torch / OpenMP pools to that slice (at most 8 threads).  A single-process run
+    (local_world == 1) is left alone.  DVT_NO_AFFINITY=1 disables the pinning; returns what was done."""
+    local_rank = int(os.environ.get("LOCAL_RANK", 0)) if local_rank is None else local_rank
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", 1))) if local_world is None \
+        else local_world
+    info = {"local_rank": local_rank, "local_world": local_world, "pinned": False}
+    if local_world <= 1 or os.environ.get("DVT_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return info
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // local_world)
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return info
+    n = max(1, min(8, len(mine)))
+    torch.set_num_threads(n)
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))
+    info.update(pinned=True, cpus=[mine[0], mine[-1]], n_cpus=len(mine), torch_threads=n)
+    return info
+
+
 def init(device: torch.device, world: int) -> bool:
     """Join the env:// rendezvous when world > 1 (RCCL for a HIP device, gloo for cpu)."""
+    if world > 1:
+        pin_host_threads()
     if world <= 1 or dist.is_initialized():
         return dist.is_initialized()
     if device.type == "cuda":

@@ -294,27 +294,71 @@ class FitEngine:
                 if host[i, 0] != 0.0}
 
 
-FIT_BATCH_MAX = 4  # DVT_FIT_BATCH_MAX
+FIT_BATCH_MAX = 4    # DVT_FIT_BATCH_MAX: fits that share every launch of a step
+FIT_CONCURRENT_MAX = 16  # fits advanced concurrently by one fit_many call (groups of FIT_BATCH_MAX on side streams)
+
+_side_streams: dict = {}
 
 
-def fit_many(engines, feats, xys, idxs=None, log_every: int = 1000, step_begin: int = 0,
-             step_end: int | None = None) -> None:
-    """Advance k independent fits (k images, identical settings) in lock step on the CURRENT
-    stream with shared launches (`dvt_fit_run_batched`): every kernel of a step covers all k
-    fits, so the fixed per-launch latency of the ~10 dependent launches per step is paid once
-    per k images.  Each engine keeps its own arena / Adam state / index stream; index streams
-    are drawn in engine order from the reference's numpy RNG when `idxs` is None."""
+def _fit_group(engines, feats, xys, idxs, log_every, step_begin, step_end) -> None:
     k = len(engines)
-    if not 1 <= k <= FIT_BATCH_MAX:
-        raise _lib.DvtError(f"fit_many takes 1..{FIT_BATCH_MAX} engines")
-    ref = bytes(engines[0].cfg)
-    if any(bytes(e.cfg) != ref for e in engines[1:]):
-        raise _lib.DvtError("batched fits must share one configuration")
-    if len({id(e) for e in engines}) != k:
-        raise _lib.DvtError("batched fits need distinct engines")
-    idxs = idxs if idxs is not None else [None] * k
     bufs = [e.buffers(f, x, i, log_every) for e, f, x, i in zip(engines, feats, xys, idxs)]
     buf_arr = (C.POINTER(_lib.FitBuffers) * k)(*[C.pointer(b) for b in bufs])
     end = engines[0].s.num_iters if step_end is None else step_end
     _lib.check(_lib.lib().dvt_fit_run_batched(C.byref(engines[0].cfg), k, buf_arr, step_begin, end,
                                               _lib.stream()), "dvt_fit_run_batched")
+
+
+def fit_many(engines, feats, xys, idxs=None, log_every: int = 1000, step_begin: int = 0,
+             step_end: int | None = None) -> None:
+    """Advance k independent fits (k images, identical settings) concurrently -- BASELINE configs[2], "many concurrent
+    neural fields per GPU".  Up to FIT_BATCH_MAX fits share every launch of a step (`dvt_fit_run_batched`, blockIdx.y =
+    fit); more than that (k <= FIT_CONCURRENT_MAX) run as groups of FIT_BATCH_MAX on side streams, one host thread per
+    group (the native call is back-pressured by the HIP queue for the length of the fit), joined back into the CURRENT
+    stream.  Measured (tools/bench_fit_batch.py, profiles/r03): one fit alone is latency-bound (94 us per step at
+    C = 768), two or more concurrent fits saturate the GPU at 68-72 us per step and fit whether they share launches or
+    streams -- 1.4 x, flat from K = 4 to 16.  Each engine keeps its own arena / Adam state / index stream; index streams
+    are drawn in engine order from the reference's numpy RNG when `idxs` is None (before any group starts)."""
+    k = len(engines)
+    if not 1 <= k <= FIT_CONCURRENT_MAX:
+        raise _lib.DvtError(f"fit_many takes 1..{FIT_CONCURRENT_MAX} engines")
+    ref = bytes(engines[0].cfg)
+    if any(bytes(e.cfg) != ref for e in engines[1:]):
+        raise _lib.DvtError("batched fits must share one configuration")
+    if len({id(e) for e in engines}) != k:
+        raise _lib.DvtError("batched fits need distinct engines")
+    s0 = engines[0].s  # missing index streams: the reference's draw order, image by image, before any group starts
+    idxs = [i if i is not None else FitEngine.sample_indices(engines[0].cfg.n_rows, s0.num_iters, s0.pixel_bsz)
+            for i in (idxs if idxs is not None else [None] * k)]
+    if k <= FIT_BATCH_MAX:
+        _fit_group(engines, feats, xys, idxs, log_every, step_begin, step_end)
+        return
+    import threading
+    dev = engines[0].device
+    cur = torch.cuda.current_stream(dev)
+    groups = [range(i, min(k, i + FIT_BATCH_MAX)) for i in range(0, k, FIT_BATCH_MAX)]
+    pool = _side_streams.setdefault(torch.device(dev), [])
+    while len(pool) < len(groups):
+        pool.append(torch.cuda.Stream(device=dev))
+    errors = []
+
+    def work(gi, members):
+        try:
+            torch.cuda.set_device(dev)
+            side = pool[gi]
+            side.wait_stream(cur)  # inputs produced on the caller's stream
+            with torch.cuda.stream(side):
+                _fit_group([engines[j] for j in members], [feats[j] for j in members], [xys[j] for j in members],
+                           [idxs[j] for j in members], log_every, step_begin, step_end)
+        except Exception as exc:  # surfaced on the calling thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(gi, m), daemon=True) for gi, m in enumerate(groups)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for gi in range(len(groups)):
+        cur.wait_stream(pool[gi])
+    if errors:
+        raise errors[0]

@@ -27,7 +27,7 @@ import torch
 
 from . import dist as D
 from . import views as V
-from .fit import FIT_BATCH_MAX, FitEngine, FitSettings, fit_many
+from .fit import FIT_CONCURRENT_MAX, FitEngine, FitSettings, fit_many
 from .models import MODEL_LIST, PretrainedViTWrapper
 from .utils import misc
 
@@ -70,7 +70,8 @@ def get_args(argv=None):
                    help="run without a checkpoint on RANDOM ViT weights (tests / plumbing runs only; implied by "
                         "--synthetic).  Without it a missing checkpoint is an error, as in the reference.")
     p.add_argument("--fit_batch", type=int, default=1,
-                   help="images fitted together by shared launches (dvt_fit_run_batched), 1..4")
+                   help="images fitted concurrently (BASELINE configs[2]): groups of 4 share every launch "
+                        "(dvt_fit_run_batched), further groups run on side streams; 1..16")
     args = p.parse_args(argv)
     if isinstance(args.input_size, int):
         args.input_size = (args.input_size, args.input_size)
@@ -153,7 +154,7 @@ class Stage1:
         n = args.num_views + 1
         dev = self.device
         depth = max(1, depth)
-        self.fit_batch = kb = min(max(1, fit_batch), FIT_BATCH_MAX) if depth > 1 else 1
+        self.fit_batch = kb = min(max(1, fit_batch), FIT_CONCURRENT_MAX) if depth > 1 else 1
         self.depth = depth
         self.slots = [_Slot(n, args.input_size, self.pos_h, self.pos_w, self.feat_dim, dev)
                       for _ in range(depth * kb)]

@@ -150,11 +150,12 @@ def test_full_size_properties(built_lib):
     assert out.shape == (37, 37, 768) and bool(torch.isfinite(out).all())
 
 
-@pytest.mark.parametrize("k", [2, 3])
+@pytest.mark.parametrize("k", [2, 3, 6])
 def test_batched_fits_equal_separate_fits(built_lib, k):
     """dvt_fit_run_batched (k images advanced by shared launches, BASELINE configs[2]) against k
     separate dvt_fit_run calls with the same initial parameters and index streams, across the
-    phase switch.  Different images per fit; agreement up to fp32 atomics order."""
+    phase switch.  Different images per fit; agreement up to fp32 atomics order.  k = 6 exceeds
+    DVT_FIT_BATCH_MAX: fit_many runs two groups (4 + 2) on side streams and joins them."""
     from dvt_amd.fit import FitEngine, FitSettings, fit_many
     V, H, W, C = 6, 37, 37, 768
     s = FitSettings(num_iters=30, warmup_iters=3)

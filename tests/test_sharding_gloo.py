@@ -83,3 +83,27 @@ def test_two_rank_sharded_sweep(tmp_path, n_images):
     mp.spawn(_worker, args=(2, port + 1, str(tmp_path), n_images), nprocs=2, join=True)
     assert [int(np.load(tmp_path / f"done{r}.npy")[0]) for r in range(2)] == [0, 0]
     assert json.loads((tmp_path / "work" / "summary.json").read_text())["images"] == 0
+
+
+def test_ranks_pin_disjoint_host_cpu_slices():
+    """dist.pin_host_threads (called by dist.init when world > 1): the ranks of one node take disjoint, contiguous
+    slices of the CPUs and cap their torch pools -- 8 ranks x (4 blocked launch threads + numpy draws + torch pool)
+    must not oversubscribe the same cores.  Run in child processes: the affinity of the test runner stays untouched."""
+    import json
+    import subprocess
+    import sys
+    n_cpu = len(os.sched_getaffinity(0))
+    if n_cpu < 2:
+        pytest.skip("needs >= 2 CPUs")
+    code = ("import os, sys, json; sys.path[:0] = [%r, %r]; from dvt_amd import dist as D; info = D.pin_host_threads(); "
+            "import torch; info['affinity'] = sorted(os.sched_getaffinity(0)); info['threads'] = torch.get_num_threads(); "
+            "print(json.dumps(info))") % (ROOT, os.path.join(ROOT, "denoising-vit_amd"))
+    seen = []
+    for r in range(2):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", WORLD_SIZE="2")
+        env.pop("DVT_NO_AFFINITY", None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+        info = json.loads(out.strip().splitlines()[-1])
+        assert info["pinned"] and len(info["affinity"]) == n_cpu // 2 and info["threads"] <= 8
+        seen.append(set(info["affinity"]))
+    assert not (seen[0] & seen[1])

@@ -164,3 +164,72 @@ if "time" in what:
         print(f"extractor 110 views {cname:8s}: {t * 1e3:7.1f} ms ({t * 7 * 1e3:6.1f} ms per 770 views); gemm {g['total_ms']:6.1f} ms "
               f"{g['work'] / g['total_ms'] / 1e9:6.1f} TF/s; attn {a['total_ms']:6.1f} ms {a['work'] / a['total_ms'] / 1e9:6.1f} TF/s",
               flush=True)
+
+if "abl" in what:
+    # ablations of the 8q structure (timing only; results are wrong by construction): which ingredient bounds a tile?
+    M = 110 * 1408
+    names = {0: "full", 8: "no epilogue", 1: "no MFMA", 2: "no ds_read", 4: "no DMA", 16: "no 2nd barrier", 48: "no barriers",
+             3: "no MFMA, no ds_read (DMA + barriers + epilogue)", 6: "no ds_read, no DMA (MFMA + barriers + epilogue)",
+             14: "MFMA + barriers only", 7: "barriers + epilogue only", 15: "barriers only", 24: "no epilogue, no 2nd barrier"}
+    for name, n, k in [("qkv", 2304, 768), ("fc2-shape", 768, 3072)]:
+        torch.manual_seed(1)
+        x = torch.randn(M, k, device=dev).bfloat16()
+        w = (torch.randn(n, k, device=dev) / k ** 0.5).bfloat16()
+        b = torch.randn(n, device=dev)
+        y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        for tpw in ((1, 3) if k == 768 else (1,)):
+            res = {}
+            for rnd in range(2):
+                for mask in names:
+                    tune(5)
+                    tune(-200 - tpw)
+                    tune(-300 - mask)
+                    run_bias(x, w, b, y, M, n, k)
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    for _ in range(5):
+                        run_bias(x, w, b, y, M, n, k)
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    res[mask] = min(res.get(mask, 1e9), ev0.elapsed_time(ev1) / 5)
+                    tune(-300)
+                    tune(-200)
+                    tune(4)
+            tiles = (M // 256) * (n // 256)
+            for mask, ms in res.items():
+                print(f"abl {name:9s} tpw{tpw} {names[mask]:50s}: {ms * 1e3:8.1f} us = {ms * 1e3 / (tiles / 256):6.2f} us per tile-round "
+                      f"({ms * 1e3 / (tiles / 256) / (k // 64):5.2f} per k-tile)", flush=True)
+
+if "stagger" in what:
+    M = 110 * 1408
+    torch.manual_seed(0)
+    for name, n, k, resid in [("qkv", 2304, 768, False), ("fc1", 3072, 768, False), ("proj", 768, 768, True), ("fc2", 768, 3072, True)]:
+        x = torch.randn(M, k, device=dev).bfloat16()
+        w = (torch.randn(n, k, device=dev) / k ** 0.5).bfloat16()
+        b, gm = torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-3
+        y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        xr = torch.randn(M, n, device=dev)
+        configs = [("8p", [4])]
+        for t in ((1, 3) if k == 768 else (1,)):
+            for st in (0, 3, 6, 10, 399):
+                configs.append((f"8q tpw{t} stagger {st if st != 399 else 'auto'}", [5, -200 - t, -400 - st if st != 399 else -399]))
+        res = {c[0]: 1e9 for c in configs}
+        for rnd in range(3):
+            for cname, knobs in configs:
+                for v in knobs:
+                    tune(v)
+                fn = (lambda: run_resid(x, w, b, gm, xr, M, n, k)) if resid else (lambda: run_bias(x, w, b, y, M, n, k))
+                fn()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(5):
+                    fn()
+                ev1.record()
+                torch.cuda.synchronize()
+                res[cname] = min(res[cname], ev0.elapsed_time(ev1) / 5)
+                tune(-400)
+                tune(-200)
+                tune(4)
+        for cname, ms in res.items():
+            print(f"stagger {name:5s} N={n:5d} K={k:5d} {cname:26s}: {ms * 1e3:8.1f} us {2.0 * M * n * k / ms / 1e9:7.1f} TF/s", flush=True)
+        del x, w, y, xr

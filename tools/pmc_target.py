@@ -1,4 +1,5 @@
-"""Small workload for PMC collection: one ViT forward of 128 views + 60 fit steps."""
+"""Small workload for PMC collection: one ViT forward of 110 views (the bench's extractor launch: 769 views = 7 x 110) + 60
+fit steps.  argv[1] overrides the view count."""
 import os
 import sys
 import warnings
@@ -15,11 +16,12 @@ dev = torch.device("cuda:0")
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14, allow_random_init=True)
-x = torch.randn(128, 3, 518, 518, device=dev)
-out = torch.empty(128, 37, 37, 768, device=dev)
+NV = int(sys.argv[1]) if len(sys.argv) > 1 else 110
+x = torch.randn(NV, 3, 518, 518, device=dev)
+out = torch.empty(NV, 37, 37, 768, device=dev)
 vit.features_nhwc(x, out=out)
 torch.cuda.synchronize()
-n_rows = 128 * 1369
+n_rows = NV * 1369
 eng = FitEngine(FitSettings(num_iters=60, warmup_iters=6, mlp_dtype="bfloat16"), n_rows, dev)
 eng.reset(torch.Generator(device=dev).manual_seed(0))
 np.random.seed(0)
