@@ -29,6 +29,8 @@
 //   layernorm   one wave per row, HBM-bound.
 #include <math.h>
 
+#include <type_traits>
+
 #include "../../include/dvt_vit.h"
 #include "dvt_common.h"
 
@@ -1536,6 +1538,7 @@ int g_vit_nt_store = 0;
 int g_vit_fuse_ln = 1;
 // 8q kernel: tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
 int g_vit_tpw = 0;
+int g_vit_attn_variant = 1;  // dvt_tune_set(1, -500 - v): 1 = round-2 kernel, 2 = software-pipelined + deferred max
 int g_vit_stagger = 0;  // dvt_tune_set(1, -400 - n): n half-microseconds per phase slot (0 off); -399: auto
 int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 8q kernel (EPI_BIAS only)
 
@@ -1895,6 +1898,226 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
   }
 }
 
+// ---- attention, round 3 ("v2"): the same tiling (128 queries per workgroup, 16 per wave, 64-key tiles, S^T = K.Q^T,
+// O^T = V^T.P^T, register-staged K / V^T tiles) with the two serial chains of the v1 loop taken apart:
+//   (1) S(t+1) is issued BEFORE the softmax of tile t.  In v1 a wave ran  S MFMAs -> softmax VALU -> PV MFMAs  strictly
+//       in sequence, and the per-tile barrier keeps the 8 waves of a workgroup in lock step, so the matrix pipe idled
+//       while everybody was in the softmax (SQ_VALU_MFMA_BUSY 22 %).  Now the 8 S MFMAs of the NEXT tile are
+//       interleaved with the softmax of the CURRENT one (sched_group_barrier: one MFMA per ~7 VALU), their results are
+//       needed an iteration later.  K therefore runs one tile further ahead: three K buffers, two V^T buffers (40 KB).
+//   (2) deferred running max (the guide's T13).  A query's 64 keys of a tile live in 4 lanes; v1 reduced the tile max
+//       across them with two dependent ds_bpermute round trips, recomputed alpha = exp(m_old - m_new) and rescaled l on
+//       EVERY tile.  Now every lane only compares its own 16 logits with the running max: while no logit of the whole
+//       wave exceeds it by more than THR = 8 (a wave vote, v_cmp + s_cbranch), nothing is reduced or rescaled and
+//       P = exp(s - m_run) <= e^8 (bf16 keeps its relative precision there; accumulation is fp32).  Otherwise -- the
+//       first tile, and rarely later -- the exact max is formed with v_permlane16/32_swap (no LDS) and o, l are rescaled.
+//       tests/test_gpu_vit.py forces the late-rescale branch with a spiked key row (guide 5.4 rule 26).
+constexpr int ATT2_KBUF = 3;
+
+__global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                           bf16_t* __restrict__ out, int heads, int s_pad, int n_valid) {
+  __shared__ __attribute__((aligned(16))) char smem[ATT2_KBUF * KV_TILE * 128 + 2 * 64 * VT_LD];
+  char* const Kb = smem;
+  char* const Vb = smem + ATT2_KBUF * KV_TILE * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lc = lane & 15;
+  const int nqb = s_pad / ATT_Q;
+  int id = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int qb = id % nqb, h = (id / nqb) % heads, b = id / (nqb * heads);
+  const int dim = heads * 64, ldq = 2 * dim;
+  const size_t row0 = (size_t)b * s_pad;
+
+  bf16x8 qf[2];
+  {
+    const bf16_t* qrow = qk + (row0 + qb * ATT_Q + wave * 16 + lc) * ldq + h * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      union { bf16x8 v; uint32_t u[4]; } raw;
+      raw.v = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = __uint_as_float(raw.u[j] << 16) * 0.125f;
+        const float hi = __uint_as_float(raw.u[j] & 0xffff0000u) * 0.125f;
+        raw.u[j] = pack2(lo, hi);
+      }
+      qf[ks] = raw.v;
+    }
+  }
+  const bf16_t* kbase = qk + row0 * ldq + dim + h * 64;
+  const bf16_t* vbase = vt + ((size_t)(b * heads + h) * 64) * s_pad;
+
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+  const float THR = 8.0f;
+
+  const int ntiles = (n_valid + KV_TILE - 1) / KV_TILE;
+  const int sr0 = tid >> 3, sc = tid & 7;
+  const bf16_t* kp0 = kbase + (size_t)sr0 * ldq + sc * 8;
+  const bf16_t* vp0 = vbase + (size_t)sr0 * s_pad + sc * 8;
+  const int kdo = sr0 * 128 + ((sc ^ (sr0 & 7)) << 4);
+  const int vks = sc >> 2, vc = sc & 3, vsw = (sr0 >> 1) & 7;
+  const int vdo0 = sr0 * VT_LD + (((vks * 4 + 2 * (vc & 1)) ^ vsw) << 4) + (vc >> 1) * 8;
+  const int vdo1 = sr0 * VT_LD + (((vks * 4 + 2 * (vc & 1) + 1) ^ vsw) << 4) + (vc >> 1) * 8;
+  uint4 kr0, vr0;
+#define A2_LOADK(kt) kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq)
+#define A2_LOADV(kt) vr0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * KV_TILE)
+#define A2_STOREK(kt) *reinterpret_cast<uint4*>(Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128) + kdo) = kr0
+#define A2_STOREV(kt)                                                                     \
+  do {                                                                                    \
+    char* vb_ = Vb + ((kt) & 1) * (64 * VT_LD);                                           \
+    *reinterpret_cast<uint2*>(vb_ + vdo0) = make_uint2(vr0.x, vr0.y);                     \
+    *reinterpret_cast<uint2*>(vb_ + vdo1) = make_uint2(vr0.z, vr0.w);                     \
+  } while (0)
+  // S^T of tile kt: acc s[mt][r] <-> key = 16*mt + 4*g + r, q = lc
+#define A2_S(dst, kt)                                                                                              \
+  do {                                                                                                             \
+    const char* Ks_ = Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128);                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                             \
+      dst[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                       \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+        const int krow = mt * 16 + lc;                                                                             \
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks_ + krow * 128 + (((ks * 4 + g) ^ (krow & 7)) << 4)); \
+        dst[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], dst[mt], 0, 0, 0);                           \
+      }                                                                                                            \
+    }                                                                                                              \
+  } while (0)
+
+  // prologue: K0, V0, K1 staged; S(0); K2 / V1 in flight in registers
+  A2_LOADK(0);
+  A2_LOADV(0);
+  A2_STOREK(0);
+  A2_STOREV(0);
+  if (ntiles > 1) {
+    A2_LOADK(1);
+    A2_STOREK(1);
+  }
+  if (ntiles > 2) A2_LOADK(2);
+  if (ntiles > 1) A2_LOADV(1);
+  __syncthreads();
+  f32x4 s[4], sn[4];
+  A2_S(s, 0);
+  // one tile.  LAST: the final tile (padding keys masked, no next tile to start).  The body of the common case is ONE
+  // basic block from the vote onwards, so that the scheduler hints can interleave the next tile's S MFMAs with it.
+  auto tile = [&](int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    if (kt + 2 < ntiles) A2_STOREK(kt + 2);  // loaded an iteration ago; that buffer was last read two barriers back
+    if (kt + 1 < ntiles) A2_STOREV(kt + 1);
+    if (kt + 3 < ntiles) A2_LOADK(kt + 3);
+    if (kt + 2 < ntiles) A2_LOADV(kt + 2);
+    if constexpr (LAST) {
+      const int kbase_idx = kt * KV_TILE;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kbase_idx + mt * 16 + 4 * g + r >= n_valid) s[mt][r] = -1e30f;
+    }
+    float tmax = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[0][2]);
+    tmax = max3f(tmax, s[0][3], s[1][0]);
+    tmax = max3f(tmax, s[1][1], s[1][2]);
+    tmax = max3f(tmax, s[1][3], s[2][0]);
+    tmax = max3f(tmax, s[2][1], s[2][2]);
+    tmax = max3f(tmax, s[2][3], s[3][0]);
+    tmax = max3f(tmax, s[3][1], s[3][2]);
+    tmax = fmaxf(tmax, s[3][3]);
+    if (!__all(tmax <= m_run + THR)) {  // wave-uniform, rare after the first tile
+      // exact max over the query's 4 lanes (lc + 16 g): swap rows 0<->1 / 2<->3, then the wave halves
+      const unsigned u = __float_as_uint(tmax);
+      const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+      tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+      const unsigned u2 = __float_as_uint(tmax);
+      const auto r32 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+      tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i][0] *= alpha;
+        o[i][1] *= alpha;
+        o[i][2] *= alpha;
+        o[i][3] *= alpha;
+      }
+      m_run = m_new;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) A2_S(sn, kt + 1);  // K(kt+1) became visible at the previous barrier (or in the prologue)
+    const float mb = m_run * LOG2E;
+    const f32x2 l2e2 = {LOG2E, LOG2E}, nmb2 = {-mb, -mb};
+    f32x2 ps2 = {0.f, 0.f};
+    float pv[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const f32x2 sv = {s[mt][2 * h2], s[mt][2 * h2 + 1]};
+        const f32x2 t = __builtin_elementwise_fma(sv, l2e2, nmb2);
+        f32x2 e;
+        e.x = __builtin_amdgcn_exp2f(t.x);
+        e.y = __builtin_amdgcn_exp2f(t.y);
+        ps2 += e;
+        pv[mt][2 * h2] = e.x;
+        pv[mt][2 * h2 + 1] = e.y;
+      }
+    l_run += ps2.x + ps2.y;
+    union { bf16x8 v; uint32_t u[4]; } pf0, pf1;
+    pf0.u[0] = pack2(pv[0][0], pv[0][1]); pf0.u[1] = pack2(pv[0][2], pv[0][3]);
+    pf0.u[2] = pack2(pv[1][0], pv[1][1]); pf0.u[3] = pack2(pv[1][2], pv[1][3]);
+    pf1.u[0] = pack2(pv[2][0], pv[2][1]); pf1.u[1] = pack2(pv[2][2], pv[2][3]);
+    pf1.u[2] = pack2(pv[3][0], pv[3][1]); pf1.u[3] = pack2(pv[3][2], pv[3][3]);
+    if constexpr (!LAST) {
+      // scheduler shape for the block above: one S MFMA of the next tile per ~6 VALU of this tile's softmax
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T[d][q] += V^T . P^T
+    const char* Vs = Vb + (kt & 1) * (64 * VT_LD);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+      const char* vrow = Vs + vr * VT_LD;
+      const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
+      const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf0.v, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf1.v, o[mt], 0, 0, 0);
+    }
+    __syncthreads();
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) s[mt] = sn[mt];
+    }
+  };
+  for (int kt = 0; kt < ntiles - 1; ++kt) tile(kt, std::false_type{});
+  tile(ntiles - 1, std::true_type{});
+#undef A2_LOADK
+#undef A2_LOADV
+#undef A2_STOREK
+#undef A2_STOREV
+#undef A2_S
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+  bf16_t* orow = out + (row0 + qb * ATT_Q + wave * 16 + lc) * dim + h * 64;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    uint2 pk;
+    pk.x = pack2(o[mt][0] * inv, o[mt][1] * inv);
+    pk.y = pack2(o[mt][2] * inv, o[mt][3] * inv);
+    *reinterpret_cast<uint2*>(orow + mt * 16 + 4 * g) = pk;
+  }
+}
+
 inline int64_t up256b(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct VitWork {
@@ -1947,6 +2170,11 @@ int dvt_vit_tune(int v) {
   }
   if (v == -50 || v == -51) {  // non-temporal bf16 output stores off / on
     g_vit_nt_store = v == -51;
+    return 0;
+  }
+  if (v <= -500) {
+    if (v != -501 && v != -502) return DVT_E_BADARG;
+    g_vit_attn_variant = -500 - v;
     return 0;
   }
   if (v <= -399) {
@@ -2050,9 +2278,13 @@ extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int 
     return DVT_E_BADARG;
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
                       4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
-  hipLaunchKernelGGL(attention_kernel, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
-                     (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads,
-                     s_pad, n_valid);
+  if (g_vit_attn_variant == 2)
+    hipLaunchKernelGGL(attention_kernel_v2, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
+                       (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
+  else
+    hipLaunchKernelGGL(attention_kernel, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
+                       (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads,
+                       s_pad, n_valid);
   DVT_CHECK_LAUNCH();
   return 0;
 }

@@ -334,7 +334,9 @@ def fit_many(engines, feats, xys, idxs=None, log_every: int = 1000, step_begin: 
         _fit_group(engines, feats, xys, idxs, log_every, step_begin, step_end)
         return
     import threading
-    dev = engines[0].device
+    dev = torch.device(engines[0].device)
+    if dev.index is None:  # worker threads and stream objects need the concrete device
+        dev = torch.device("cuda", torch.cuda.current_device())
     cur = torch.cuda.current_stream(dev)
     groups = [range(i, min(k, i + FIT_BATCH_MAX)) for i in range(0, k, FIT_BATCH_MAX)]
     pool = _side_streams.setdefault(torch.device(dev), [])

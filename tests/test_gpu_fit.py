@@ -282,8 +282,8 @@ def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
           f"mean {float(d.mean()):.3e}")
     # Adam normalises every step to ~lr, so a sign flip of a near-zero gradient moves a parameter by ~2 lr;
     # the bulk must be tight, single elements may differ by a few lr.  Measured distribution of d.max over 10 seeds x 3
-    # widths (profiles/r03/tolerance_study.json, T1; tools/tolerance_study.py): cross-path 0.015-0.052 (median 0.035)
-    # while the SAME path launched twice agrees to 1e-6 -- the difference is the two paths' bf16 rounding order, not
+    # widths, two runs (profiles/r03/tolerance_study*.json, T1; tools/tolerance_study.py): cross-path 0.014-0.052 (median 0.035)
+    # while the SAME path launched twice agrees to 1e-5 in 59 of 60 cases (one 0.011) -- the difference is the two paths' bf16 rounding order, not
     # scheduling noise.  Bound = 2 x the observed maximum.
     assert float(d.mean()) < 2e-5 and float(d.max()) < 0.1
     assert per_patch_cos(o1, o0).min() > 0.9999
@@ -453,9 +453,10 @@ def test_batched_fused_fits_equal_separate_fits(built_lib):
         d = (solo[j].params - batched[j].params).abs()
         # single parameters may differ by a few lr after 70 steps (Adam turns the sign of a near-zero gradient into
         # +-lr; atomics order differs between the launches): the bulk must be tight, the output must agree.
-        # Measured over 10 seeds x 2 fits (profiles/r03/tolerance_study.json, T2): batched-vs-solo d.max 1.5e-8 .. 0.095,
-        # saved-tensor cosine min 0.9994; the SAME solo configuration launched twice: d.max up to 0.095 as well, cosine
-        # min 0.9999 -- i.e. this is the run-to-run spread of one path (fp32 atomics order in the coarse grid levels).
+        # Measured over 10 seeds x 2 fits, two runs (profiles/r03/tolerance_study*.json, T2): batched-vs-solo d.max
+        # 1e-8 .. 0.095 / 0.058, saved-tensor cosine min 0.9994; the SAME solo configuration launched twice: d.max up to
+        # 0.095 / 0.058 as well, cosine min 0.9999 -- i.e. this is the run-to-run spread of ONE path (fp32 atomics order in
+        # the coarse grid levels).
         # Bounds = 2 x the observed maximum / the observed minimum rounded down.
         assert float(d.mean()) < 2e-5 and float(d.max()) < 0.2, (j, float(d.mean()), float(d.max()))
         a, b = solo[j].infer(data[j][1][-1].to(DEV)), batched[j].infer(data[j][1][-1].to(DEV))
@@ -493,9 +494,9 @@ def test_long_run_many_list_chunks(built_lib):
     for other in (exact, lazy):
         assert float(other.grads.abs().max()) == 0.0 and int(other.touched.abs().max()) == 0
         lo = other.loss_log()
-        # 2500 steps of a bf16-mode run.  Measured over 10 seeds (profiles/r03/tolerance_study.json, T3): final-loss
-        # relative difference vs the dense sweep <= 8e-4 (exact replay) / 1.4e-3 (1-ulp replay), and 1.4e-3 for the DENSE
-        # path against ITSELF launched twice; saved-tensor cosine min 0.9979 / 0.9937 / 0.9963 (dense rerun).  So the
+        # 2500 steps of a bf16-mode run.  Measured over 10 seeds, two runs (profiles/r03/tolerance_study*.json, T3):
+        # final-loss relative difference vs the dense sweep <= 1.7e-3 (IEEE replay) / 1.4e-3 (1-ulp replay), and 1.5e-3 for
+        # the DENSE path against ITSELF launched twice; saved-tensor cosine min 0.9963 / 0.9937 / 0.9963 (dense rerun).  So the
         # round-2 loss bound of 2 % is restored; the cosine bound stays at 0.99 because the same-path rerun itself
         # reaches 0.9963 (the old 0.995 sat inside the run-to-run spread).
         assert abs(lo[T - 1]["loss"] - ld[T - 1]["loss"]) < 2e-2 * abs(ld[T - 1]["loss"])

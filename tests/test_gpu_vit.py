@@ -15,6 +15,8 @@ from oracle import vit as ovit
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+ATTN_DEFAULT = 1   # dvt_tune_set(1, -500 - v): attention kernel of the bf16 extractor (1: round 2, 2: round 3)
+GEMM_DEFAULT = 4   # dvt_tune_set(1, v): ViT GEMM schedule
 
 
 def _s():
@@ -57,8 +59,8 @@ def test_gemm_bias_vs_torch(L, m, n, k):
     assert rel(y.float(), want) < 6e-3, (m, n, k)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4])
-@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (2816, 768, 768), (1408, 768, 3072), (256, 384, 192)])
+@pytest.mark.parametrize("variant", [0, 3, 4, 5])
+@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (2816, 768, 768), (1408, 768, 3072), (256, 384, 192), (1792, 768, 768)])
 def test_gemm_residual_vs_torch(L, m, n, k, variant):
     """x += gamma * (a @ w^T + b) (LayerScale + residual epilogue) on every GEMM schedule: 0 = 256x256
     two-stage, 4 = 256x256 8-phase ring, 3 = 256x128 ping-pong.  Every element is checked: the
@@ -74,12 +76,12 @@ def test_gemm_residual_vs_torch(L, m, n, k, variant):
         assert L.dvt_vit_gemm_residual(P(a), P(w), P(b), P(gm), x.data_ptr(), m, n, k, _s()) == 0
         torch.cuda.synchronize()
     finally:
-        L.dvt_tune_set(1, 4)
+        L.dvt_tune_set(1, GEMM_DEFAULT)
     err = (x.cpu() - want).abs()
     assert float(err.max()) < 2e-3 * float(want.abs().max()), (variant, (m, n, k), float(err.max()))
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 def test_gemm_bias_variants(L, variant):
     """the non-default GEMM schedules against torch on the four ViT-B shapes (one M panel pair each)"""
     for n, k in [(2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 640)]:
@@ -95,7 +97,7 @@ def test_gemm_bias_variants(L, variant):
             assert L.dvt_vit_gemm_bias(P(x), P(w), P(b), y.data_ptr(), m, n, k, _s()) == 0
             torch.cuda.synchronize()
         finally:
-            L.dvt_tune_set(1, 4)
+            L.dvt_tune_set(1, GEMM_DEFAULT)
         assert rel(y.float(), want) < 6e-3, (variant, n, k)
 
 
@@ -138,8 +140,10 @@ def test_layernorm_vs_torch(L, dim):
     assert rel(y.float(), F.layer_norm(x, (dim,), w, b, 1e-6)) < 5e-3
 
 
-@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370)])
-def test_attention_vs_torch(L, batch, heads, s_pad, n_valid):
+@pytest.mark.parametrize("attn_variant", [1, 2])
+@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370), (1, 1, 128, 1),
+                                                        (1, 1, 256, 65)])
+def test_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant):
     torch.manual_seed(s_pad + heads)
     dim = heads * 64
     q = torch.randn(batch, s_pad, heads, 64)
@@ -151,9 +155,50 @@ def test_attention_vs_torch(L, batch, heads, s_pad, n_valid):
     qk = torch.cat([qb.reshape(batch * s_pad, dim), kb.reshape(batch * s_pad, dim)], 1).contiguous().to(DEV)
     vt = vb.permute(0, 2, 3, 1).contiguous().to(DEV)  # [batch, heads, 64, s_pad]
     out = torch.empty((batch * s_pad, dim), device=DEV, dtype=torch.bfloat16)
-    assert L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
+    assert L.dvt_tune_set(1, -500 - attn_variant) == 0
+    try:
+        assert L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
+        torch.cuda.synchronize()
+    finally:
+        L.dvt_tune_set(1, -500 - ATTN_DEFAULT)
     got = out.float().reshape(batch, s_pad, dim).cpu()
     assert rel(got[:, :n_valid], want[:, :n_valid]) < 2e-2
+    assert bool(torch.isfinite(got).all())
+
+
+@pytest.mark.parametrize("attn_variant", [1, 2])
+@pytest.mark.parametrize("spike_tile", [1, 5, 21])
+def test_attention_late_max_growth(L, attn_variant, spike_tile):
+    """Online softmax with a running max that JUMPS late (programming guide 5.4 rule 26): one key row of tile
+    `spike_tile` is aligned with a few queries so that its logit exceeds everything seen before by far more than the
+    deferred-max threshold of the v2 kernel (8), forcing the rescale of o / l in the middle of the key loop -- a branch
+    bounded random data takes only on the first tile.  Full-tensor fp64 reference; every query row is checked."""
+    torch.manual_seed(spike_tile)
+    batch, heads, s_pad, n_valid = 1, 2, 1408, 1370
+    dim = heads * 64
+    q = torch.randn(batch, s_pad, heads, 64)
+    k = torch.randn(batch, s_pad, heads, 64)
+    v = torch.randn(batch, s_pad, heads, 64)
+    key = 64 * spike_tile + 17
+    k[:, key] = 0.0
+    for qi in (3, 200, 777, 1369):       # queries in different waves / workgroups
+        k[:, key] += q[:, qi] * 1.5       # q . k ~ 1.5 |q|^2 ~ 96 -> logit ~ 12 after the 1/8 scale, others ~ N(0, 1)
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    att = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qb.double() * 0.125, kb.double()[:, :n_valid]), -1)
+    want = torch.einsum("bhqk,bkhd->bqhd", att, vb.double()[:, :n_valid]).reshape(batch, s_pad, dim)
+    assert float(att[..., key].max()) > 0.5  # the spiked key really dominates some rows
+    qk = torch.cat([qb.reshape(batch * s_pad, dim), kb.reshape(batch * s_pad, dim)], 1).contiguous().to(DEV)
+    vt = vb.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.empty((batch * s_pad, dim), device=DEV, dtype=torch.bfloat16)
+    assert L.dvt_tune_set(1, -500 - attn_variant) == 0
+    try:
+        assert L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
+        torch.cuda.synchronize()
+    finally:
+        L.dvt_tune_set(1, -500 - ATTN_DEFAULT)
+    got = out.double().reshape(batch, s_pad, dim).cpu()
+    err = (got[:, :n_valid] - want[:, :n_valid]).abs().amax(dim=-1)  # per query row
+    assert float(err.max()) < 3e-2, (attn_variant, spike_tile, int(err.argmax()), float(err.max()))
     assert bool(torch.isfinite(got).all())
 
 

@@ -233,3 +233,33 @@ if "stagger" in what:
         for cname, ms in res.items():
             print(f"stagger {name:5s} N={n:5d} K={k:5d} {cname:26s}: {ms * 1e3:8.1f} us {2.0 * M * n * k / ms / 1e9:7.1f} TF/s", flush=True)
         del x, w, y, xr
+
+if "attn" in what:
+    # attention v1 (round 2) vs v2 (software-pipelined, deferred max): correctness on random data + timing at the bench shape
+    import ctypes
+    torch.manual_seed(0)
+    batch, heads, s_pad, n_valid = 110, 12, 1408, 1370
+    dim = heads * 64
+    qk = (torch.randn(batch * s_pad, 2 * dim, device=dev)).bfloat16()
+    vt = torch.randn(batch, heads, 64, s_pad, device=dev).bfloat16()
+    outs = {}
+    for v in (1, 2):
+        tune(-500 - v)
+        out = torch.empty(batch * s_pad, dim, device=dev, dtype=torch.bfloat16)
+        for rep in range(2):
+            assert L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, S()) == 0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for rnd in range(3):
+            ev0.record()
+            for _ in range(5):
+                L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, S())
+            ev1.record()
+            torch.cuda.synchronize()
+            best = min(best, ev0.elapsed_time(ev1) / 5)
+        outs[v] = out.float().view(batch, s_pad, dim)[:, :n_valid].clone()
+        fl = 4.0 * n_valid * n_valid * 64 * heads * batch
+        print(f"attention v{v}: {best * 1e3:8.1f} us  {fl / best / 1e9:7.1f} TF/s", flush=True)
+    tune(-501)
+    d = (outs[2] - outs[1]).abs()
+    print(f"attention v2 vs v1: max |diff| {float(d.max()):.3e}, rel-L2 {float((outs[2] - outs[1]).norm() / outs[1].norm()):.3e}", flush=True)
