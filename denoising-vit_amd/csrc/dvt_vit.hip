@@ -1538,7 +1538,7 @@ int g_vit_nt_store = 0;
 int g_vit_fuse_ln = 1;
 // 8q kernel: tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
 int g_vit_tpw = 0;
-int g_vit_attn_variant = 1;  // dvt_tune_set(1, -500 - v): 1 = round-2 kernel, 2 = software-pipelined + deferred max
+int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = software-pipelined S + deferred max, 1 = the round-2 kernel
 int g_vit_stagger = 0;  // dvt_tune_set(1, -400 - n): n half-microseconds per phase slot (0 off); -399: auto
 int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 8q kernel (EPI_BIAS only)
 
@@ -1912,15 +1912,8 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
 //       P = exp(s - m_run) <= e^8 (bf16 keeps its relative precision there; accumulation is fp32).  Otherwise -- the
 //       first tile, and rarely later -- the exact max is formed with v_permlane16/32_swap (no LDS) and o, l are rescaled.
 //       tests/test_gpu_vit.py forces the late-rescale branch with a spiked key row (guide 5.4 rule 26).
-//   (3) DEFER_PV (variant 3): the P.V product of tile t is issued one iteration LATER, so that the block which holds the
-//       softmax of tile t carries 16 independent MFMAs -- S(t+1) and PV(t-1) -- for its ~70 VALU + 16 v_exp: matrix and
-//       vector work of one wave are about equal there (256 vs ~240 cycles) and overlap.  P(t-1) waits in 8 packed
-//       registers; V^T(t) is then stored at the TOP of iteration t (visible for iteration t+1), still two buffers.
-//       When the rare rescale fires, everything still at the old max is scaled exactly once: o, l AND the pending
-//       P(t-1) fragments (unpack, scale, repack) -- the T13 hazard.
 constexpr int ATT2_KBUF = 3;
 
-template <bool DEFER_PV>
 __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                            bf16_t* __restrict__ out, int heads, int s_pad, int n_valid) {
   __shared__ __attribute__((aligned(16))) char smem[ATT2_KBUF * KV_TILE * 128 + 2 * 64 * VT_LD];
@@ -2011,35 +2004,16 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
   f32x4 s[4], sn[4];
   A2_S(s, 0);
   union PF { bf16x8 v; uint32_t u[4]; };
-  PF pp0, pp1;  // DEFER_PV: P fragments of the previous tile, still to be multiplied with V^T
-  pp0.v = pp1.v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  // O^T[d][q] += V^T(kt) . P^T
-#define A2_PV(kt, P0, P1)                                                                      \
-  do {                                                                                         \
-    const char* Vs_ = Vb + ((kt) & 1) * (64 * VT_LD);                                          \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                         \
-      const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;                                        \
-      const char* vrow = Vs_ + vr * VT_LD;                                                     \
-      const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));            \
-      const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));      \
-      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, (P0).v, o[mt], 0, 0, 0);            \
-      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, (P1).v, o[mt], 0, 0, 0);            \
-    }                                                                                          \
-  } while (0)
-  // one tile.  LAST: the final tile (padding keys masked, no next tile to start).  The body of the common case is ONE
-  // basic block from the vote onwards, so that the scheduler hints can interleave the MFMAs with the softmax.
-  auto tile = [&](int kt, auto first_tag, auto last_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+  // one tile.  LAST: the final tile (padding keys masked, no next tile to start).  From the vote onwards the body of
+  // the common case is ONE basic block, so that the scheduler hints can interleave the next tile's S MFMAs with it.
+  // (Tried and dropped, profiles/r03: also deferring P.V by one tile so that the block carries 16 independent MFMAs --
+  // +1 % with hints, -7 % with a hand-placed MFMA / exp interleave whose LDS reads ran only two slots ahead.)
+  auto tile = [&](int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     if (kt + 2 < ntiles) A2_STOREK(kt + 2);  // loaded an iteration ago; that buffer was last read two barriers back
-    if constexpr (DEFER_PV) {
-      // V^T(kt) -> its buffer now (read from the NEXT iteration on); V^T(kt-1), read below, sits in the other one
-      if constexpr (!FIRST) A2_STOREV(kt);
-      if (kt + 1 < ntiles) A2_LOADV(kt + 1);
-    } else {
-      if (kt + 1 < ntiles) A2_STOREV(kt + 1);
-      if (kt + 2 < ntiles) A2_LOADV(kt + 2);
-    }
+    if (kt + 1 < ntiles) A2_STOREV(kt + 1);
     if (kt + 3 < ntiles) A2_LOADK(kt + 3);
+    if (kt + 2 < ntiles) A2_LOADV(kt + 2);
     if constexpr (LAST) {
       const int kbase_idx = kt * KV_TILE;
 #pragma unroll
@@ -2066,7 +2040,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
       tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-      l_run *= alpha;
+      l_run *= alpha;  // everything still at the old max is scaled exactly once: o and l (P.V of the previous tile is complete)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         o[i][0] *= alpha;
@@ -2074,82 +2048,13 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
         o[i][2] *= alpha;
         o[i][3] *= alpha;
       }
-      if constexpr (DEFER_PV) {  // the pending P(kt-1) is still at the old max as well
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pp0.u[j] = pack2(__uint_as_float(pp0.u[j] << 16) * alpha, __uint_as_float(pp0.u[j] & 0xffff0000u) * alpha);
-          pp1.u[j] = pack2(__uint_as_float(pp1.u[j] << 16) * alpha, __uint_as_float(pp1.u[j] & 0xffff0000u) * alpha);
-        }
-      }
       m_run = m_new;
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) A2_S(sn, kt + 1);  // K(kt+1) became visible at the previous barrier (or in the prologue)
     const float mb = m_run * LOG2E;
     const f32x2 l2e2 = {LOG2E, LOG2E}, nmb2 = {-mb, -mb};
     f32x2 ps2 = {0.f, 0.f};
-    PF pf0, pf1;
-    if constexpr (DEFER_PV) {
-      // Hand-placed block (the scheduler hints of the other variant do not survive 16 MFMAs + 16 LDS reads): the
-      // independent MFMAs of this iteration -- S(kt+1) and PV(kt-1), alternating so that the two k-steps of one
-      // accumulator are two slots apart -- each with its operand fragment read two slots ahead, and between two
-      // MFMAs one half-step of the softmax of tile kt (fma + 2 exp, or the running sum + the bf16 packing).
-      constexpr int NS = LAST ? 0 : 8, NP = FIRST ? 0 : 8, NM = NS + NP;
-      const char* Ks_ = Kb + ((kt + 1) % ATT2_KBUF) * (KV_TILE * 128);
-      const char* Vs_ = Vb + ((kt - 1) & 1) * (64 * VT_LD);
-      auto is_s = [&](int j) { return NP == 0 || (NS != 0 && (j & 1) == 0); };
-      auto sub = [&](int j) { return (NS != 0 && NP != 0) ? j >> 1 : j; };  // index inside its own family, 0..7
-      auto ldf = [&](int j) -> bf16x8 {
-        const int q = sub(j), mt = q >> 1, hk = q & 1;
-        if (is_s(j)) {
-          const int krow = mt * 16 + lc;
-          return *reinterpret_cast<const bf16x8*>(Ks_ + krow * 128 + (((hk * 4 + g) ^ (krow & 7)) << 4));
-        }
-        const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
-        return *reinterpret_cast<const bf16x8*>(Vs_ + vr * VT_LD + (((hk * 4 + g) ^ vs_) << 4));
-      };
-      if constexpr (NS != 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) sn[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-      f32x2 ee[8];
-      auto half_step = [&](int hs) {  // 16 half-steps: even = fma + 2 exp of unit hs / 2, odd = its sum (+ packing)
-        const int u = hs >> 1, mt = u >> 1, h2 = u & 1;
-        if ((hs & 1) == 0) {
-          // asm volatile (+ "memory"): pure VALU code is not ordered against sched_barrier by instruction selection --
-          // left as builtins, all 40 VALU of the softmax sank below the 16 MFMAs however the source was interleaved
-          const f32x2 sv = {s[mt][2 * h2], s[mt][2 * h2 + 1]};
-          f32x2 t;
-          asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(sv), "v"(l2e2), "v"(nmb2) : "memory");
-          asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(ee[u].x), "=v"(ee[u].y) : "v"(t.x), "v"(t.y));
-        } else {
-          asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ps2) : "v"(ee[u]) : "memory");
-          // pack at once (pinned like the rest): the fp32 values die here instead of living to the end of the block
-          PF& pf = mt < 2 ? pf0 : pf1;
-          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pf.u[2 * (mt & 1) + h2]) : "v"(ee[u].x), "v"(ee[u].y));
-        }
-      };
-      if constexpr (NM == 0) {
-#pragma unroll
-        for (int hs = 0; hs < 16; ++hs) half_step(hs);
-      } else {
-        constexpr int HPS = 16 / NM;  // half-steps per MFMA slot
-        bf16x8 fr[NM + 2];
-        fr[0] = ldf(0);
-        fr[1] = ldf(1);
-#pragma unroll
-        for (int j = 0; j < NM; ++j) {
-          if (j + 2 < NM) fr[j + 2] = ldf(j + 2);
-          const int q = sub(j), mt = q >> 1, hk = q & 1;
-          if (is_s(j)) sn[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[j], qf[hk], sn[mt], 0, 0, 0);
-          else o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[j], hk ? pp1.v : pp0.v, o[mt], 0, 0, 0);
-#pragma unroll
-          for (int x = 0; x < HPS; ++x) half_step(j * HPS + x);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      l_run += ps2.x + ps2.y;
-    } else {
-    if constexpr (!LAST) A2_S(sn, kt + 1);  // K(kt+1) became visible at the previous barrier (or in the prologue)
     float pv[4][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -2165,26 +2070,30 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
         pv[mt][2 * h2 + 1] = e.y;
       }
     l_run += ps2.x + ps2.y;
+    PF pf0, pf1;
     pf0.u[0] = pack2(pv[0][0], pv[0][1]); pf0.u[1] = pack2(pv[0][2], pv[0][3]);
     pf0.u[2] = pack2(pv[1][0], pv[1][1]); pf0.u[3] = pack2(pv[1][2], pv[1][3]);
     pf1.u[0] = pack2(pv[2][0], pv[2][1]); pf1.u[1] = pack2(pv[2][2], pv[2][3]);
     pf1.u[2] = pack2(pv[3][0], pv[3][1]); pf1.u[3] = pack2(pv[3][2], pv[3][3]);
-    {
-      // scheduler shape for the block above: the next tile's S MFMAs spread over this tile's softmax VALU
-      constexpr int NM = LAST ? 0 : 8;
+    if constexpr (!LAST) {
+      // scheduler shape for the block above: one S MFMA of the next tile per ~6 VALU of this tile's softmax
 #pragma unroll
-      for (int i = 0; i < NM; ++i) {
+      for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
       }
     }
-    }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DEFER_PV) {
-      pp0 = pf0;
-      pp1 = pf1;
-    } else {
-      A2_PV(kt, pf0, pf1);
+    // ---- O^T[d][q] += V^T . P^T
+    const char* Vs = Vb + (kt & 1) * (64 * VT_LD);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+      const char* vrow = Vs + vr * VT_LD;
+      const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
+      const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf0.v, o[mt], 0, 0, 0);
+      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf1.v, o[mt], 0, 0, 0);
     }
     __syncthreads();
     if constexpr (!LAST) {
@@ -2192,19 +2101,8 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
       for (int mt = 0; mt < 4; ++mt) s[mt] = sn[mt];
     }
   };
-  if (ntiles == 1) {
-    tile(0, std::true_type{}, std::true_type{});
-  } else {
-    tile(0, std::true_type{}, std::false_type{});
-    for (int kt = 1; kt < ntiles - 1; ++kt) tile(kt, std::false_type{}, std::false_type{});
-    tile(ntiles - 1, std::false_type{}, std::true_type{});
-  }
-  if constexpr (DEFER_PV) {
-    // V^T(last) was stored at the top of the last iteration (or by the prologue when there is one tile only) and the
-    // barrier that ended that iteration made it visible
-    A2_PV(ntiles - 1, pp0, pp1);
-  }
-#undef A2_PV
+  for (int kt = 0; kt < ntiles - 1; ++kt) tile(kt, std::false_type{});
+  tile(ntiles - 1, std::true_type{});
 #undef A2_LOADK
 #undef A2_LOADV
 #undef A2_STOREK
@@ -2278,7 +2176,7 @@ int dvt_vit_tune(int v) {
     return 0;
   }
   if (v <= -500) {
-    if (v != -501 && v != -502 && v != -503) return DVT_E_BADARG;
+    if (v != -501 && v != -502) return DVT_E_BADARG;
     g_vit_attn_variant = -500 - v;
     return 0;
   }
@@ -2383,11 +2281,8 @@ extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int 
     return DVT_E_BADARG;
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
                       4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
-  if (g_vit_attn_variant == 3)
-    hipLaunchKernelGGL(attention_kernel_v2<true>, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
-                       (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
-  else if (g_vit_attn_variant == 2)
-    hipLaunchKernelGGL(attention_kernel_v2<false>, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
+  if (g_vit_attn_variant == 2)
+    hipLaunchKernelGGL(attention_kernel_v2, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
                        (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
   else
     hipLaunchKernelGGL(attention_kernel, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,

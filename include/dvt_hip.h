@@ -267,8 +267,11 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         128x128 two-stage; 2: 256x128 lock-step three-stage; 3: 256x128 ping-pong;
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation;
  *         -100 - b: b M panels per block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output
- *         stores off / on).  No value changes the result beyond the summation order of the folded-LayerNorm row
- *         statistics (fp32, ~1e-7 relative);
+ *         stores off / on; -501 / -502: attention kernel of the bf16 extractor, round-2 loop / software-pipelined loop
+ *         with deferred running max [default]; developer instrumentation of schedule 5: -300 - mask ablations [timing
+ *         only, EPI_BIAS entry point, results wrong by construction], -400 - n staggered workgroup start).  No other
+ *         value changes the result beyond the summation order of the folded-LayerNorm row statistics (fp32, ~1e-7
+ *         relative) and, between the two attention kernels, the bf16 rounding of P (different running max);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);

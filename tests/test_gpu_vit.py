@@ -15,7 +15,7 @@ from oracle import vit as ovit
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-ATTN_DEFAULT = 1   # dvt_tune_set(1, -500 - v): attention kernel of the bf16 extractor (1: round 2, 2: round 3)
+ATTN_DEFAULT = 2   # dvt_tune_set(1, -500 - v): attention kernel of the bf16 extractor (1: round 2, 2: round 3)
 GEMM_DEFAULT = 4   # dvt_tune_set(1, v): ViT GEMM schedule
 
 
@@ -140,7 +140,7 @@ def test_layernorm_vs_torch(L, dim):
     assert rel(y.float(), F.layer_norm(x, (dim,), w, b, 1e-6)) < 5e-3
 
 
-@pytest.mark.parametrize("attn_variant", [1, 2, 3])
+@pytest.mark.parametrize("attn_variant", [1, 2])
 @pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370), (1, 1, 128, 1),
                                                         (1, 1, 256, 65)])
 def test_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant):
@@ -166,7 +166,7 @@ def test_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant):
     assert bool(torch.isfinite(got).all())
 
 
-@pytest.mark.parametrize("attn_variant", [1, 2, 3])
+@pytest.mark.parametrize("attn_variant", [1, 2])
 @pytest.mark.parametrize("spike_tile", [1, 5, 20, 21])
 def test_attention_late_max_growth(L, attn_variant, spike_tile):
     """Online softmax with a running max that JUMPS late (programming guide 5.4 rule 26): one key row of tile

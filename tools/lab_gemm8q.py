@@ -243,7 +243,7 @@ if "attn" in what:
     qk = (torch.randn(batch * s_pad, 2 * dim, device=dev)).bfloat16()
     vt = torch.randn(batch, heads, 64, s_pad, device=dev).bfloat16()
     outs = {}
-    for v in (1, 2, 3):
+    for v in (1, 2):
         tune(-500 - v)
         out = torch.empty(batch * s_pad, dim, device=dev, dtype=torch.bfloat16)
         for rep in range(2):
@@ -260,7 +260,7 @@ if "attn" in what:
         outs[v] = out.float().view(batch, s_pad, dim)[:, :n_valid].clone()
         fl = 4.0 * n_valid * n_valid * 64 * heads * batch
         print(f"attention v{v}: {best * 1e3:8.1f} us  {fl / best / 1e9:7.1f} TF/s", flush=True)
-    tune(-501)
-    for v in (2, 3):
+    tune(-502)
+    for v in (2,):
         d = (outs[v] - outs[1]).abs()
         print(f"attention v{v} vs v1: max |diff| {float(d.max()):.3e}, rel-L2 {float((outs[v] - outs[1]).norm() / outs[1].norm()):.3e}", flush=True)
