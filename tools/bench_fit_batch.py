@@ -26,6 +26,10 @@ feat = torch.randn(n_rows, C_, device=dev, generator=g)
 xy = torch.rand(n_rows, 2, device=dev, generator=g)
 s = FitSettings(feat_dim=C_, num_iters=T, warmup_iters=T // 10, mlp_dtype="bfloat16")
 KMAX = 16
+from dvt_amd import _lib  # noqa: E402
+for kv in filter(None, os.environ.get("DVT_TUNE", "").split(",")):  # e.g. DVT_TUNE=13=0
+    k_, v_ = kv.split("=")
+    assert _lib.lib().dvt_tune_set(int(k_), int(v_)) == 0
 engines = [FitEngine(s, n_rows, dev) for _ in range(KMAX)]
 idxs = [np.random.RandomState(j).randint(0, n_rows, (T, 2048)).astype(np.int32) for j in range(KMAX)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(KMAX)]
@@ -53,7 +57,10 @@ def run(K, per_group):
     return (time.perf_counter() - t0) / T / K * 1e6
 
 
-for K, per in [(1, 1), (2, 2), (4, 4), (2, 1), (4, 1), (4, 2), (8, 4), (8, 2), (8, 1), (16, 4)]:
+CASES = [(1, 1), (2, 2), (4, 4), (2, 1), (4, 1), (4, 2), (8, 4), (8, 2), (8, 1), (16, 4)]
+if os.environ.get("DVT_FB_CASES"):  # e.g. "4:4,1:1" (profiling runs)
+    CASES = [tuple(int(v) for v in c.split(":")) for c in os.environ["DVT_FB_CASES"].split(",")]
+for K, per in CASES:
     if per > FIT_BATCH_MAX:
         continue
     run(K, per)
