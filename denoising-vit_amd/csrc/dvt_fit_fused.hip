@@ -334,9 +334,12 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(DvtShadowLayout L, co
 // Weight gradients of the step: dW[m][n] += sum_b dY[b][m] * X[b][n] for every layer, one launch.
 // Both operands arrive as bf16 [cols][batch] fragment-major copies (store_T above), so A and B fragments of
 // v_mfma_f32_16x16x32_bf16 are single coalesced 16-byte-per-lane loads, straight to VGPRs: every WAVE owns
-// a 32 x 32 block of one dW and one quarter of the batch -- no LDS, no barrier, 16 loads in flight --
-// and adds its partial sums with fp32 atomics (4 per element) into the gradient arena that Adam clears.
+// a 32 x 32 block of one dW and one quarter of the batch (16 loads in flight); the four quarter sums of a
+// block meet in LDS and ONE wave stores the total with plain stores into the zeroed gradient arena -- no
+// atomics, deterministic sums (see wgrad_block; round 1 used 4 fp32 atomics per element).
 // Bias gradients (column sums of dY, i.e. of the A operand) ride along in the waves of the first n-block.
+// (Round 3 tried 64 x 64 blocks per wave in their own launch: correct, +1 % at 4 concurrent fits, -9 % for one
+// fit; profiles/r03/r03d_wgrad64_experiment.txt.)
 // ======================================================================================================
 constexpr int WG_MAX_PROB = 5 * DVT_FIT_BATCH_MAX;
 struct WgradProb {
