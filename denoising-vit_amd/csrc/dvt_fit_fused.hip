@@ -30,9 +30,11 @@
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+int g_fit_rows32 = 1;  // dvt_tune_set(13, v), see launch_rows
+
 namespace {
 
-constexpr int FR = 16;   // rows per workgroup = M of the MFMA
+constexpr int FR0 = 16;  // rows per workgroup of the round-2 kernel = M of the MFMA; the kernel template takes FR = 16 or 32
 constexpr int FW = 8;    // waves per workgroup
 constexpr int FE = 128;  // encoding width: 16 levels x 8 features
 
@@ -55,12 +57,13 @@ __device__ __forceinline__ uint16_t bf16_of(float v) { return (uint16_t)(dvt_pac
 // One [16][NC] bf16 LDS image (pitch apitch(NC)) -> its slice of the transposed, fragment-major operand copy
 // dstT = [NC][B]: for every column the 16 batch rows of this workgroup are two 16-byte pieces (8 rows each)
 // of the 1-KB fragment block (tile col / 16, k-step b0 / 32).  Adjacent threads take adjacent columns.
-template <int NC>
+template <int NC, int FR>
 __device__ __forceinline__ void store_T(const char* img, uint16_t* __restrict__ dstT, int B, int b0, int tid) {
-  const int kstep = b0 >> 5, g0 = (b0 >> 3) & 3;
-  for (int item = tid; item < NC * 2; item += 64 * FW) {
-    const int half = item / NC, col = item - half * NC;
-    const char* src = img + half * 8 * apitch(NC) + col * 2;
+  // FR / 8 groups of 8 batch rows per column; group `grp` = batch rows b0 + 8 grp .. + 7 = lane group g of k-step
+  for (int item = tid; item < NC * (FR / 8); item += 64 * FW) {
+    const int grp = item / NC, col = item - grp * NC;
+    const int brow = b0 + grp * 8, kstep = brow >> 5, g = (brow >> 3) & 3;
+    const char* src = img + grp * 8 * apitch(NC) + col * 2;
     uint32_t w[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -68,7 +71,7 @@ __device__ __forceinline__ void store_T(const char* img, uint16_t* __restrict__ 
       const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * j + 1) * apitch(NC));
       w[j] = lo | (hi << 16);
     }
-    const long long off = ((long long)(col >> 4) * (B >> 5) + kstep) * 512 + ((((g0 + half) << 4) + (col & 15)) << 3);
+    const long long off = ((long long)(col >> 4) * (B >> 5) + kstep) * 512 + (((g << 4) + (col & 15)) << 3);
     *reinterpret_cast<uint4*>(dstT + off) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
@@ -79,10 +82,11 @@ __device__ __forceinline__ void store_T(const char* img, uint16_t* __restrict__ 
 //   act_out LDS bf16 image [16][N] for the next layer (may alias `mask`: every element is read, then
 //           written, by the one lane that owns it), or nullptr
 //   gout    global fp32 [16][N] (this workgroup's rows), or nullptr
-template <int K, int N, bool RELU, bool MASK>
+template <int K, int N, bool RELU, bool MASK, int RB>
 __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __restrict__ W,
                                           const float* __restrict__ bias, char* act_out,
                                           float* __restrict__ gout, const char* mask, int wave, int lane) {
+  // RB = row blocks of 16 (FR / 16): every weight fragment fetched from L2 is used for RB MFMAs
   constexpr int NTILES = N / 16, NT = (NTILES + FW - 1) / FW, S = K / 32;
   // k-steps of weights in flight per wave: ~24 x 1 KB.  The weights are L2 hits at best and memory-side
   // cache hits on first touch (every kernel starts with a cold L2), i.e. 0.3-2 us of latency: with 6 loads
@@ -91,11 +95,12 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
   constexpr int PD = PD0 < S ? PD0 : S;
   static_assert(K % 32 == 0 && N % 16 == 0, "layer shape");
   const int lc = lane & 15, g = lane >> 4;
-  f32x4 acc[NT];
+  f32x4 acc[RB][NT];
   const uint16_t* wp[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
-    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int t = wave + FW * i;
     const int tt = (NTILES % FW == 0 || t < NTILES) ? t : 0;  // surplus tiles compute tile 0 again, never stored
     wp[i] = W + (size_t)tt * S * 512 + lane * 8;  // fragment-major copy: 1 KB per (tile, k-step), lane-linear
@@ -111,10 +116,14 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
   const char* ap = actA + lc * apitch(K) + g * 16;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const bf16x8 av = *reinterpret_cast<const bf16x8*>(ap + s * 64);
+    bf16x8 av[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) av[rb] = *reinterpret_cast<const bf16x8*>(ap + rb * 16 * apitch(K) + s * 64);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[s % PD][i], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rb], b[s % PD][i], acc[rb][i], 0, 0, 0);
     if (s + PD < S) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) b[s % PD][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 512 * (s + PD));
@@ -129,21 +138,23 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
     const int n = t * 16 + lc;
     const float bv = bias != nullptr ? bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * g + r;
-      float v = acc[i][r] + bv;
-      if (RELU) v = fmaxf(v, 0.f);
-      if (MASK) {
-        const uint16_t m = *reinterpret_cast<const uint16_t*>(mask + row * apitch(N) + n * 2);
-        v = (m != 0 && !(m & 0x8000u)) ? v : 0.f;  // ReLU output > 0
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb * 16 + 4 * g + r;
+        float v = acc[rb][i][r] + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        if (MASK) {
+          const uint16_t m = *reinterpret_cast<const uint16_t*>(mask + row * apitch(N) + n * 2);
+          v = (m != 0 && !(m & 0x8000u)) ? v : 0.f;  // ReLU output > 0
+        }
+        if (act_out != nullptr) *reinterpret_cast<uint16_t*>(act_out + row * apitch(N) + n * 2) = bf16_of(v);
+        if (gout != nullptr) gout[(size_t)row * N + n] = v;
       }
-      if (act_out != nullptr) *reinterpret_cast<uint16_t*>(act_out + row * apitch(N) + n * 2) = bf16_of(v);
-      if (gout != nullptr) gout[(size_t)row * N + n] = v;
-    }
   }
 }
 
-template <int C, bool PH2>
+template <int C, bool PH2, int FR>
 struct FusedLds {
   static constexpr int H = C / 2, R = C / 4;
   static constexpr int O_ENC = 0;
@@ -155,9 +166,12 @@ struct FusedLds {
   static constexpr int TOTAL = PH2 ? O_R2 + FR * apitch(R) : O_RAW;
 };
 
-template <int C, bool PH2>
+template <int C, bool PH2, int FR>
 __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
-  using L = FusedLds<C, PH2>;
+  using L = FusedLds<C, PH2, FR>;
+  constexpr int RB = FR / 16;
+  static_assert(FR == 16 || FR == 32, "rows per workgroup");
+  static_assert(L::TOTAL <= 160 * 1024, "LDS images of the row kernel");
   constexpr int H = C / 2, R = C / 4, E = FE, cq = C / 4;
   __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
   const DvtFusedFit& f = a.f[blockIdx.y];
@@ -178,11 +192,14 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   {  // the rows the loss stage will read much later: this wave's sampled feature rows (random HBM rows) and
      // their lattice rows of G, one dword per 128-B line, so that their latency hides under the forward pass
     constexpr int LPR = (C * 4 + 127) / 128;  // lines per row
-    const int rr = lane / 32, j = lane % 32;  // 2 rows per wave, <= 32 lines each (C <= 1024)
-    if (rr < FR / FW && j < LPR) {
-      const int ri = f.ridx[row0 + wave + FW * rr];
-      warm[4] = __float_as_uint(f.feat[(size_t)ri * C + j * 32]) ^
-                __float_as_uint(P[a.off_G + (size_t)(ri % a.lattice) * C + j * 32]);
+    const int j = lane % 32;  // 2 rows per pass (lane / 32), <= 32 lines each (C <= 1024)
+#pragma unroll
+    for (int rr = lane / 32; rr < FR / FW; rr += 2) {
+      if (j < LPR) {
+        const int ri = f.ridx[row0 + wave + FW * rr];
+        warm[4] ^= __float_as_uint(f.feat[(size_t)ri * C + j * 32]) ^
+                   __float_as_uint(P[a.off_G + (size_t)(ri % a.lattice) * C + j * 32]);
+      }
     }
   }
   {
@@ -193,9 +210,9 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
     const long long l0 = slot * per, l1 = l0 + per < lines ? l0 + per : lines;
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(sh);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4 * RB; ++j) {
       const long long li = l0 + tid + (long long)j * 64 * FW;
-      if (li < l1) warm[j] = w32[li * 32];
+      if (li < l1) warm[j & 3] ^= w32[li * 32];
     }
   }
 
@@ -238,35 +255,35 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   // ---- forward: field MLP (neural_feature_field.py:40-44, :49), residual predictor (offline_denoiser.py:107)
   const int B = a.n;
   uint16_t* __restrict__ T = f.T;
-  mlp_layer<E, H, true, false>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1, nullptr,
+  mlp_layer<E, H, true, false, RB>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1, nullptr,
                                nullptr, wave, lane);
   if (PH2)
-    mlp_layer<C, R, true, false>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1, nullptr,
+    mlp_layer<C, R, true, false, RB>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1, nullptr,
                                  nullptr, wave, lane);
   __syncthreads();
-  mlp_layer<H, C, false, false>(smem + L::O_H1, sh + a.S.direct[1], P + a.off_b2, nullptr,
+  mlp_layer<H, C, false, false, RB>(smem + L::O_H1, sh + a.S.direct[1], P + a.off_b2, nullptr,
                                 f.F + (size_t)row0 * C, nullptr, wave, lane);
   // operands of the weight gradients leave as transposed bf16 copies while their LDS images are stable
-  store_T<H>(smem + L::O_H1, T + a.TL.off[DVT_T_H1], B, row0, tid);
-  store_T<E>(smem + L::O_ENC, T + a.TL.off[DVT_T_ENC], B, row0, tid);
+  store_T<H, FR>(smem + L::O_H1, T + a.TL.off[DVT_T_H1], B, row0, tid);
+  store_T<E, FR>(smem + L::O_ENC, T + a.TL.off[DVT_T_ENC], B, row0, tid);
   if (PH2) {
-    mlp_layer<R, R, true, false>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2, nullptr,
+    mlp_layer<R, R, true, false, RB>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2, nullptr,
                                  nullptr, wave, lane);
-    store_T<C>(smem + L::O_RAW, T + a.TL.off[DVT_T_RAW], B, row0, tid);
-    store_T<R>(smem + L::O_R1, T + a.TL.off[DVT_T_R1], B, row0, tid);
+    store_T<C, FR>(smem + L::O_RAW, T + a.TL.off[DVT_T_RAW], B, row0, tid);
+    store_T<R, FR>(smem + L::O_R1, T + a.TL.off[DVT_T_R1], B, row0, tid);
     __syncthreads();
-    mlp_layer<R, C, false, false>(smem + L::O_R2, sh + a.S.direct[4], P + a.off_bh3, nullptr,
+    mlp_layer<R, C, false, false, RB>(smem + L::O_R2, sh + a.S.direct[4], P + a.off_bh3, nullptr,
                                   f.Hres + (size_t)row0 * C, nullptr, wave, lane);
-    store_T<R>(smem + L::O_R2, T + a.TL.off[DVT_T_R2], B, row0, tid);
+    store_T<R, FR>(smem + L::O_R2, T + a.TL.off[DVT_T_R2], B, row0, tid);
   }
   __syncthreads();  // F (and Hres) rows of this workgroup are visible to all of its waves
 
   // ---- loss + gradients (offline_denoiser.py:113-140), one wave per row, two rows per wave; the
   //      gradient of G is gathered inside Adam from the d(pred) rows written here
-  static_assert(FR / FW == 2 && C <= 1024, "row warm-up above assumes 2 rows per wave, <= 32 lines per row");
+  static_assert(C <= 1024, "row warm-up above assumes <= 32 lines per row");
   {
     constexpr int NR = FR / FW;
-    constexpr int NB = (C <= 768) ? NR : 1;  // rows whose loads are in flight together (register budget)
+    constexpr int NB = (C <= 768) ? 2 : 1;  // rows whose loads are in flight together (register budget)
     DvtLossRowRegs<PH2> lr[NB];
 #pragma unroll
     for (int r0 = 0; r0 < NR; r0 += NB) {
@@ -294,24 +311,24 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
 
   // ---- data gradients: dh1 = (dF . W2) * (h1 > 0), denc = dh1 . W1; dr2 = (dH . Wh3) * (r2 > 0),
   //      dr1 = (dr2 . Wh2) * (r1 > 0)  (the [K][N] shadow copies make these k-contiguous as well)
-  mlp_layer<C, H, false, true>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1, nullptr,
+  mlp_layer<C, H, false, true, RB>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1, nullptr,
                                smem + L::O_H1, wave, lane);
-  store_T<C>(smem + L::O_DF, T + a.TL.off[DVT_T_DF], B, row0, tid);
+  store_T<C, FR>(smem + L::O_DF, T + a.TL.off[DVT_T_DF], B, row0, tid);
   if (PH2) {
-    mlp_layer<C, R, false, true>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2, nullptr,
+    mlp_layer<C, R, false, true, RB>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2, nullptr,
                                  smem + L::O_R2, wave, lane);
-    store_T<C>(smem + L::O_RAW, T + a.TL.off[DVT_T_DH], B, row0, tid);
+    store_T<C, FR>(smem + L::O_RAW, T + a.TL.off[DVT_T_DH], B, row0, tid);
   }
   __syncthreads();
-  mlp_layer<H, E, false, false>(smem + L::O_H1, sh + a.S.transp[0], nullptr, nullptr,
+  mlp_layer<H, E, false, false, RB>(smem + L::O_H1, sh + a.S.transp[0], nullptr, nullptr,
                                 f.denc + (size_t)row0 * E, nullptr, wave, lane);
-  store_T<H>(smem + L::O_H1, T + a.TL.off[DVT_T_DH1], B, row0, tid);
+  store_T<H, FR>(smem + L::O_H1, T + a.TL.off[DVT_T_DH1], B, row0, tid);
   if (PH2) {
-    mlp_layer<R, R, false, true>(smem + L::O_R2, sh + a.S.transp[3], nullptr, smem + L::O_R1, nullptr,
+    mlp_layer<R, R, false, true, RB>(smem + L::O_R2, sh + a.S.transp[3], nullptr, smem + L::O_R1, nullptr,
                                  smem + L::O_R1, wave, lane);
-    store_T<R>(smem + L::O_R2, T + a.TL.off[DVT_T_DR2], B, row0, tid);
+    store_T<R, FR>(smem + L::O_R2, T + a.TL.off[DVT_T_DR2], B, row0, tid);
     __syncthreads();
-    store_T<R>(smem + L::O_R1, T + a.TL.off[DVT_T_DR1], B, row0, tid);
+    store_T<R, FR>(smem + L::O_R1, T + a.TL.off[DVT_T_DR1], B, row0, tid);
   }
   // keeps the warm-up loads alive (a.n is never negative)
   if (a.n < 0) f.rows[tid] = __uint_as_float(warm[0] ^ warm[1] ^ warm[2] ^ warm[3] ^ warm[4]);
@@ -533,13 +550,28 @@ __global__ __launch_bounds__(1024) void fit_backward_kernel(BackwardArgs a) {
   wgrad_block(a.w, (int)blockIdx.x, wave, threadIdx.x & 63, smem);
 }
 
+// FR = 32 rows per workgroup halves the weight stream per row (every fragment feeds two MFMAs) and the number of
+// workgroups.  Measured (tools/bench_fit_batch.py, C = 768, us per step and fit, 16 -> 32 rows): one fit 96.7 -> 107.8
+// (latency-bound on 128 workgroups, worse on 64), two fits 74.1 -> 79.1 (128 workgroups leave half the chip empty),
+// four fits 71.8 -> 66.1, eight 66.9 -> 63.5.  So: 32 rows when k >= 4 fits share the launch and the LDS images fit
+// (158.7 KB at C = 768 in phase 2; C = 1024 only in phase 1) -- dvt_tune_set(13, v): 1 auto, 0 = always 16, 2 = 32
+// wherever it fits (the parity tests run both).
 template <int C>
 int launch_rows(const FusedArgs& a, int k, bool phase2, hipStream_t s) {
-  dim3 grid(a.n / FR, k), block(64 * FW);
-  if (phase2)
-    hipLaunchKernelGGL((fit_rows_kernel<C, true>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((fit_rows_kernel<C, false>), grid, block, 0, s, a);
+  const bool fits32 = phase2 ? (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) : (FusedLds<C, false, 32>::TOTAL <= 160 * 1024);
+  const bool r32 = fits32 && a.n % 32 == 0 && (g_fit_rows32 == 2 || (g_fit_rows32 == 1 && k >= 4));
+  dim3 grid(a.n / (r32 ? 32 : 16), k), block(64 * FW);
+  if (r32) {
+    if (phase2) {
+      if constexpr (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, true, 32>), grid, block, 0, s, a);
+    } else {
+      if constexpr (FusedLds<C, false, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, false, 32>), grid, block, 0, s, a);
+    }
+  } else if (phase2) {
+    hipLaunchKernelGGL((fit_rows_kernel<C, true, 16>), grid, block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((fit_rows_kernel<C, false, 16>), grid, block, 0, s, a);
+  }
   DVT_CHECK_LAUNCH();
   return 0;
 }

@@ -289,6 +289,8 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         1000-step schedule exactly as well as the IEEE mode does (per-patch cosine 0.99994 / 0.9992, fixture test);
  *         1: IEEE division / square root, the dense kernel's own update function -- every entry ends bit-identical
  *         to the dense sweep; +18 us per step = -5.4 % bench `value` in a same-box A/B (profiles/r03);
+ * key 13 = fused row kernel: rows per workgroup -- 1 (default) 32 when k >= 4 fits share the launch and the LDS images fit
+ *         (C <= 768; C = 1024 in phase 1), else 16; 0 = always 16; 2 = 32 whenever the images fit.  Same arithmetic per row;
  * key 8 = Adam sweeps the arena in alternating directions on consecutive steps (1, default) or always forward (0);
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);

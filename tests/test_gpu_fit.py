@@ -243,8 +243,9 @@ def test_bf16_operand_fit_vs_oracles(built_lib):
         assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (step, a, b)
 
 
+@pytest.mark.parametrize("rows32", [0, 2])
 @pytest.mark.parametrize("C,V", [(768, 6), (1024, 4), (384, 6)])
-def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
+def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V, rows32):
     """The fused row kernel of the bf16-mode step (dvt_fit_fused.hip: gather + grid forward + MLP forward +
     loss + dgrad in one launch, bf16 shadow weights maintained by Adam) against the layer-by-layer launch
     sequence (dvt_tune_set(6, 0)) on identical inputs, across the phase switch.  Both round the same operands
@@ -260,6 +261,9 @@ def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
     f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
     res = {}
     try:
+        # rows32: rows per workgroup of the fused kernel (dvt_tune_set(13, .): 0 = 16, 2 = 32 wherever the LDS images
+        # fit -- C <= 768, and C = 1024 in phase 1; elsewhere 16)
+        assert built_lib.dvt_tune_set(13, rows32) == 0
         for fused in (1, 0):
             assert built_lib.dvt_tune_set(6, fused) == 0
             eng = FitEngine(s, n_rows, DEV)
@@ -271,6 +275,7 @@ def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
             del eng
     finally:
         built_lib.dvt_tune_set(6, 1)
+        built_lib.dvt_tune_set(13, 1)
     (p1, l1, o1), (p0, l0, o0) = res[1], res[0]
     for step in range(T):
         for k, v in l0[step].items():

@@ -96,7 +96,7 @@ def test_fit_matches_oracle_baseline_shapes(built_lib):
     assert want_log[T - 1]["patch_l2_loss"] < 0.8 * want_log[0]["patch_l2_loss"]
 
 
-@pytest.mark.parametrize("replay", ["ieee", "1ulp"])
+@pytest.mark.parametrize("replay", ["ieee", "1ulp", "1ulp-rows32"])
 @pytest.mark.parametrize("C", [768, 1024])
 def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C, replay):
     """BASELINE configs[1] (C = 768) / configs[2] (C = 1024) at the schedule the metric is quoted on -- 1000 Adam
@@ -130,10 +130,14 @@ def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C, replay):
         eng = hip_engine_from(d_o, f_o, n_rows, T, WARM, mode, H=H, W=H, C=C)
         try:
             assert built_lib.dvt_tune_set(10, int(replay == "ieee")) == 0
+            # "-rows32": the 32-rows-per-workgroup row kernel that concurrent fits take (dvt_tune_set(13, 2) forces it
+            # for this single fit wherever its LDS images fit)
+            assert built_lib.dvt_tune_set(13, 2 if replay.endswith("rows32") else 1) == 0
             eng.fit(f_dev, c_dev, idx, log_every=1)
             torch.cuda.synchronize()
         finally:
             built_lib.dvt_tune_set(10, LAZY_REPLAY_DEFAULT)
+            built_lib.dvt_tune_set(13, 1)
         got, log = eng.infer(xy[-1].to(DEV)).cpu(), eng.loss_log()
         assert float(eng.grads.abs().max()) == 0.0 and int(eng.touched.abs().max()) == 0
         del eng
