@@ -55,6 +55,7 @@ PMC_TRAFFIC_BYTES_PER_LAUNCH, PMC_TRAFFIC_SOURCE = _pmc_traffic()
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA
+MFMA_BF16_SUSTAINED_TF = 2069.0  # measured: pure-MFMA loop, random operands, at the socket power cap (profiles/r03)
 # SURVEY.md 8(d) image-level ceilings for ViT-B/14: extractor 233.1 TFLOP / 2.5 PF/s = 93 ms, fit 0.549 TB / 8 TB/s =
 # 69 ms per image -> serial 1 / (93 + 69 ms) = 6.2 images/s, phases overlapped across images 1 / max = 10.7 images/s
 IMAGE_CEILINGS = {"vit_base_patch14_dinov2.lvd142m": (6.2, 10.7)}
@@ -368,6 +369,12 @@ def main():
             out["roofline"] = {"kernel": dom, **{k: kern[dom][k] for k in
                                                  ("bound", "achieved", "peak", "unit", "frac", "traffic")},
                                "traffic_source": PMC_TRAFFIC_SOURCE}
+            if kern[dom]["bound"] == "mfma" and kern[dom]["peak"] == MFMA_BF16_PEAK_TF:
+                # `peak` is the 2.5 PF/s the contract names (2.4 GHz).  Under the 1.4 kW socket cap this chip sustains
+                # 2.03 GHz on random operands: a PURE bf16 MFMA loop measures 2069 TF/s (tools/probes/mfma_power.hip,
+                # profiles/r03/r03c_power_probe_mfma_only.txt) -- the fraction against THAT is the structural one.
+                out["roofline"]["peak_sustained_measured"] = MFMA_BF16_SUSTAINED_TF
+                out["roofline"]["frac_of_sustained"] = kern[dom]["achieved"] / MFMA_BF16_SUSTAINED_TF
         if a.model in IMAGE_CEILINGS and a.num_iters == 1000 and a.views == 768:
             ser, ovl = IMAGE_CEILINGS[a.model]
             per_gpu = out["value"] / world
