@@ -277,9 +277,13 @@ def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V, rows32):
         built_lib.dvt_tune_set(6, 1)
         built_lib.dvt_tune_set(13, 1)
     (p1, l1, o1), (p0, l0, o0) = res[1], res[0]
+    # per-step losses.  Measured over 10 seeds x 3 widths (profiles/r03/tolerance_study_run3_*.json, T1): worst relative
+    # difference fused-vs-layer 1.2e-4 .. 2.8e-4, identical for 16 and 32 rows per workgroup, while the layer-by-layer path
+    # launched TWICE (fp32 atomics order in its grid backward / wgrad) already differs by up to 2.3e-4 -- the round-2 bound of
+    # 2e-4 sat inside that spread (and failed once in ~30 runs).  Bound = 2 x the observed maximum.
     for step in range(T):
         for k, v in l0[step].items():
-            assert abs(l1[step][k] - v) <= 2e-4 * max(1.0, abs(v)), (step, k, l1[step][k], v)
+            assert abs(l1[step][k] - v) <= 6e-4 * max(1.0, abs(v)), (step, k, l1[step][k], v)
     assert "residual_loss" in l1[T - 1] and l1[T - 1]["residual_loss"] != 0.0
     d = (p1 - p0).abs()
     scale = float(p0.abs().max())
@@ -319,7 +323,8 @@ def test_bf16_fit_any_batch_size(built_lib, B):
     finally:
         built_lib.dvt_tune_set(6, 1)
     for step in range(T):
-        assert abs(outs[0][0][step]["loss"] - outs[1][0][step]["loss"]) <= 2e-4 * abs(outs[1][0][step]["loss"])
+        # (C = 384: fused-vs-layer per-step loss differences up to 1.2e-4 over 10 seeds, profiles/r03/tolerance_study_run3_*.json)
+        assert abs(outs[0][0][step]["loss"] - outs[1][0][step]["loss"]) <= 3e-4 * abs(outs[1][0][step]["loss"])
     assert per_patch_cos(outs[0][1], outs[1][1]).min() > 0.9999
 
 

@@ -40,6 +40,7 @@ def run(feats, xy, idx, T, C, seed, knobs=(), warm=None, log=1):
         L.dvt_tune_set(9, 32)
         L.dvt_tune_set(7, 1)
         L.dvt_tune_set(10, DEFAULT_REPLAY)
+        L.dvt_tune_set(13, 1)
     return e
 
 
@@ -52,8 +53,13 @@ def stats(v):
 
 
 # ---- T1: fused row kernel vs layer-by-layer launches, 16 steps (test_fused_row_kernel_equals_layer_by_layer)
+def worst_loss_rel(a, b, T):
+    la, lb = a.loss_log(), b.loss_log()
+    return max(abs(la[t][k] - v) / max(1.0, abs(v)) for t in range(T) for k, v in lb[t].items())
+
+
 for C, V in ((768, 6), (1024, 4), (384, 6)):
-    cross, same, cosx = [], [], []
+    cross, same, cosx, lossx, losss, cross32, loss32 = [], [], [], [], [], [], []
     for sd in range(N):
         feats, xy = synthetic_image(V, 37, 37, C, seed=1000 * C + sd)
         f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
@@ -61,12 +67,24 @@ for C, V in ((768, 6), (1024, 4), (384, 6)):
         a = run(f, c, idx, 16, C, sd, warm=2)
         b = run(f, c, idx, 16, C, sd, warm=2)
         l = run(f, c, idx, 16, C, sd, knobs=[(6, 0)], warm=2)
+        r32 = run(f, c, idx, 16, C, sd, knobs=[(13, 2)], warm=2)   # 32 rows per workgroup where the LDS images fit
+        l2 = run(f, c, idx, 16, C, sd, knobs=[(6, 0)], warm=2)      # the layer-by-layer path launched a second time
         cross.append(float((a.params - l.params).abs().max()))
         same.append(float((a.params - b.params).abs().max()))
         cosx.append(float(per_patch_cos(a.infer(xy[-1].to(DEV)).cpu(), l.infer(xy[-1].to(DEV)).cpu()).min()))
-        del a, b, l
+        lossx.append(worst_loss_rel(a, l, 16))
+        losss.append(worst_loss_rel(l2, l, 16))
+        cross32.append(float((r32.params - l.params).abs().max()))
+        loss32.append(worst_loss_rel(r32, l, 16))
+        del a, b, l, r32, l2
     out[f"T1_fused_vs_layer_C{C}"] = {"param_max_abs_diff_cross_path": stats(cross), "param_max_abs_diff_same_path_rerun": stats(same),
-                                      "saved_tensor_cos_min_cross_path": stats(cosx)}
+                                      "saved_tensor_cos_min_cross_path": stats(cosx),
+                                      "worst_per_step_loss_rel_diff_cross_path": stats(lossx),
+                                      "worst_per_step_loss_rel_diff_layer_path_rerun": stats(losss),
+                                      "param_max_abs_diff_rows32_vs_layer": stats(cross32),
+                                      "worst_per_step_loss_rel_diff_rows32_vs_layer": stats(loss32)}
+    print(f"T1 C={C}: worst per-step loss rel diff: fused-vs-layer max {max(lossx):.2e}, rows32-vs-layer max {max(loss32):.2e}, "
+          f"layer path launched twice max {max(losss):.2e}", flush=True)
     print(f"T1 C={C}: cross max {max(cross):.4f} median {np.median(cross):.4f}; same-path rerun max {max(same):.4f}", flush=True)
 
 # ---- T2: batched fused fits vs separate fits, 70 steps (test_batched_fused_fits_equal_separate_fits)
