@@ -866,7 +866,13 @@ int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y,
   if ((a.K % BK) == 0 && (a.kchunk % BK) == 0) {
     dim3 grid(dvt_cdiv(a.N, 64), dvt_cdiv(a.M, 64), 1);
     DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<true, true>), grid, dim3(256), 0, s, a);
+    // 2 LDS stages (64 KB): two workgroups share a CU and fill each other's barrier / fragment-read gaps -- the stage-2
+    // trainer measured 81 -> 97 TF/s with it; round 3 gives the fp32 extractor the same ring (dvt_tune_set(4, 3)
+    // restores the 3-stage ring for A/B).  Same arithmetic order: results are bit-identical.
+    if (g_f32_ex_stages == 2)
+      hipLaunchKernelGGL((gemm_f32_glds_kernel<true, true, 2>), grid, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_f32_glds_kernel<true, true, 3>), grid, dim3(256), 0, s, a);
     DVT_CHECK_LAUNCH();
     return 0;
   }

@@ -27,14 +27,14 @@ void dvt_prof_begin(int probe, hipStream_t s) {
     if (hipEventCreate(&sm.a) != hipSuccess || hipEventCreate(&sm.b) != hipSuccess) return;
     p.pool.push_back(sm);
   }
-  hipEventRecord(p.pool[p.used].a, s);
+  (void)hipEventRecord(p.pool[p.used].a, s);
   p.pending = p.pool[p.used].a;
 }
 
 void dvt_prof_end(int probe, hipStream_t s, double work) {
   Probe& p = g_probes[probe];
   if (p.pending == nullptr) return;
-  hipEventRecord(p.pool[p.used].b, s);
+  (void)hipEventRecord(p.pool[p.used].b, s);
   p.pending = nullptr;
   p.used++;
   p.work += work;
