@@ -82,6 +82,7 @@ struct GemmBArgs {
   int mblock;         // M panels per block of the tile order (1: n fastest)
   int tpw;            // 8q kernel: consecutive tiles of the order per workgroup
   int stagger;        // 8q kernel: first-round workgroups start (bid / 8 % 8) * stagger half-microseconds late
+  unsigned long long* dbg;  // 8q timing build (ABL = 64): [tiles][8 waves][4] cycles: k-loop, epilogue issue, store drain, start stamp
   int nt_store;       // bf16 outputs with the non-temporal hint
   // LayerNorm folded into the GEMMs (see ln_fold): consumer side (EPI_QKV / EPI_GELU) ...
   const float2* ln_stats;  // [M] (mean, rstd) of the fp32 residual rows; A is then bf16(x), W is bf16(gamma (.) W)
@@ -1394,7 +1395,7 @@ template <int EPI, bool SWAP, int ABL = 0>
 __device__ __forceinline__ void q_tile(kernarg_ptr_t kp, f32x4 (&acc)[8][4], char* smem, char* ldsw, const QSrc& cur,
                                        const QSrc& nxt, bool first, int nk, const int (&voA)[2],
                                        const int (&voB)[2], int hA, int hB, int oa0, int oa1, int ob0, int ob1, int mb,
-                                       int nb, int lane) {
+                                       int nb, int lane, int tile_id) {
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1402,6 +1403,8 @@ __device__ __forceinline__ void q_tile(kernarg_ptr_t kp, f32x4 (&acc)[8][4], cha
   constexpr int S = P8QStores<EPI>::n;
 #define Q_ARGS acc, smem, ldsw, cur, nxt
 #define Q_TAIL nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1
+  long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
+  if constexpr (ABL & 64) tm0 = __builtin_readcyclecounter();
   int t = 0;
   if (!first) {  // the previous tile's epilogue stores sit between this tile's first DMAs and the ones issued now
     q_ktile<SWAP, 0, 8 + S, 8 + S, 8 + S, ABL>(Q_ARGS, 0, Q_TAIL);
@@ -1423,6 +1426,19 @@ __device__ __forceinline__ void q_tile(kernarg_ptr_t kp, f32x4 (&acc)[8][4], cha
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+  } else if constexpr (ABL & 64) {  // timing build: where does a tile's time go (wave-level cycle stamps)
+    tm1 = __builtin_readcyclecounter();
+    q_epilogue_swapped<EPI>(e, acc, mb, nb, lane);
+    tm2 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also drains the next tile's DMAs: this build measures, it is not fast)
+    tm3 = __builtin_readcyclecounter();
+    if (lane == 0 && kp->dbg != nullptr) {  // one slot per (tile, wave): plain stores
+      unsigned long long* d = kp->dbg + ((size_t)tile_id * 8 + (threadIdx.x >> 6)) * 4;
+      d[0] = (unsigned long long)(tm1 - tm0);
+      d[1] = (unsigned long long)(tm2 - tm1);
+      d[2] = (unsigned long long)(tm3 - tm2);
+      d[3] = (unsigned long long)tm0;
+    }
   } else if constexpr (SWAP) q_epilogue_swapped<EPI>(e, acc, mb, nb, lane);
   else q_epilogue_v(e, acc, mb, nb, lane);
 }
@@ -1507,7 +1523,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int m1, n1;
     const QSrc nxt = src_of(first_tile + ti + 1, ti + 1 < count, m1, n1);
     const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-#define Q_CALL(SW) q_tile<EPI, SW, ABL>(kp, acc, smem, ldsw, cur, nxt, ti == 0, nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1, mb, nb, lane)
+#define Q_CALL(SW) q_tile<EPI, SW, ABL>(kp, acc, smem, ldsw, cur, nxt, ti == 0, nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1, mb, nb, lane, first_tile + ti)
     if constexpr (EPI == EPI_QKV) {
       if (n0 >= 2 * p.dim) Q_CALL(false);
       else Q_CALL(true);
@@ -1540,6 +1556,7 @@ int g_vit_fuse_ln = 1;
 int g_vit_tpw = 0;
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = software-pipelined S + deferred max, 1 = the round-2 kernel
 int g_vit_stagger = 0;  // dvt_tune_set(1, -400 - n): n half-microseconds per phase slot (0 off); -399: auto
+unsigned long long* g_vit_dbg = nullptr;  // dvt_vit_debug_buffer(): device buffer of the 8q timing build
 int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 8q kernel (EPI_BIAS only)
 
 template <int EPI>
@@ -1577,13 +1594,14 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       const int tiles = (a.M / 256) * nt;
       tpw = tpw > tiles ? tiles : tpw;
       a.tpw = tpw;
+      a.dbg = g_vit_dbg;
       // per-slot delay in half-microseconds: tile period (~2.1 us per k-tile + 2 us) / 8 slots; -400 - n overrides (0 = off)
       a.stagger = g_vit_stagger >= 0 ? g_vit_stagger : (int)((nk * 2.1 + 2.0) / 8.0 * 2.0 + 0.5);
       const dim3 grid((tiles + tpw - 1) / tpw);
       bool done = false;
       if constexpr (EPI == EPI_BIAS) {  // developer ablations of the 8q structure (timing only, results are wrong)
 #define Q_ABL(n) if (g_vit_abl == n) { hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI, n>), grid, dim3(512), 0, s, a); done = true; }
-        Q_ABL(1) Q_ABL(2) Q_ABL(4) Q_ABL(8) Q_ABL(16) Q_ABL(3) Q_ABL(6) Q_ABL(7) Q_ABL(14) Q_ABL(15) Q_ABL(48) Q_ABL(24)
+        Q_ABL(1) Q_ABL(2) Q_ABL(4) Q_ABL(8) Q_ABL(16) Q_ABL(3) Q_ABL(6) Q_ABL(7) Q_ABL(14) Q_ABL(15) Q_ABL(48) Q_ABL(24) Q_ABL(64)
 #undef Q_ABL
       }
       if (!done) hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI>), grid, dim3(512), 0, s, a);
@@ -2202,6 +2220,13 @@ int dvt_vit_tune(int v) {
   }
   if (v < 0 || v > 5) return DVT_E_BADARG;
   g_vit_gemm_variant = v;
+  return 0;
+}
+
+// developer instrumentation: device buffer (tiles x 8 waves x 4 u64) the 8q timing build (dvt_tune_set(1, -364)) writes its
+// per-tile, per-wave cycle counts to; nullptr switches the reporting off
+extern "C" int dvt_vit_debug_buffer(void* dev_u64x4) {
+  g_vit_dbg = (unsigned long long*)dev_u64x4;
   return 0;
 }
 

@@ -51,6 +51,7 @@ _lib.register_signatures({
     "dvt_vit_workspace_bytes_f32": (C.c_int64, [C.POINTER(VitConfig), _I]),
     "dvt_vit_forward_f32": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
     "dvt_vit_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dvt_vit_debug_buffer": (_I, [_P]),
 })
 
 

@@ -114,6 +114,11 @@ int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, i
 int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
                       int n_valid, void* stream);
 
+/* Developer instrumentation (no reference counterpart): device buffer of (M/256)*(N/256) tiles x 8 waves x 4 uint64 that the
+ * timing build of GEMM schedule 5 (dvt_tune_set(1, -364), EPI_BIAS entry point only) fills with cycle counts per tile and wave:
+ * [0] k-loop, [1] epilogue issue, [2] store drain, [3] start stamp.  NULL switches it off. */
+int dvt_vit_debug_buffer(void* dev_u64x4);
+
 #ifdef __cplusplus
 }
 #endif

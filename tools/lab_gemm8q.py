@@ -264,3 +264,34 @@ if "attn" in what:
     for v in (2,):
         d = (outs[v] - outs[1]).abs()
         print(f"attention v{v} vs v1: max |diff| {float(d.max()):.3e}, rel-L2 {float((outs[v] - outs[1]).norm() / outs[1].norm()):.3e}", flush=True)
+
+if "timing" in what:
+    # cycle stamps of the 8q timing build: k-loop / epilogue issue / store drain per tile and wave (lane 0 of every wave)
+    M = 110 * 1408
+    for name, n, k in [("qkv", 2304, 768), ("fc1", 3072, 768), ("fc2-shape", 768, 3072)]:
+        torch.manual_seed(2)
+        x = torch.randn(M, k, device=dev).bfloat16()
+        w = (torch.randn(n, k, device=dev) / k ** 0.5).bfloat16()
+        b = torch.randn(n, device=dev)
+        y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        tiles = (M // 256) * (n // 256)
+        dbg = torch.zeros(tiles * 8 * 4, device=dev, dtype=torch.int64)
+        assert L.dvt_vit_debug_buffer(dbg.data_ptr()) == 0
+        for tpw in (1, 3):
+            tune(5); tune(-200 - tpw); tune(-364)
+            run_bias(x, w, b, y, M, n, k)
+            torch.cuda.synchronize()
+            dbg.zero_()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            run_bias(x, w, b, y, M, n, k)
+            ev1.record()
+            torch.cuda.synchronize()
+            c = dbg.view(tiles, 8, 4).double().cpu()
+            kl, ei, sd = c[..., 0], c[..., 1], c[..., 2]
+            print(f"timing {name:9s} tpw{tpw}: launch {ev0.elapsed_time(ev1) * 1e3:7.1f} us; cycles per tile (mean over waves; median / p90 "
+                  f"over tiles): k-loop {kl.mean(1).median():7.0f} / {kl.mean(1).quantile(0.9):7.0f}, epilogue issue "
+                  f"{ei.mean(1).median():6.0f} / {ei.mean(1).quantile(0.9):6.0f} (first wave {ei.min(1).values.median():6.0f}, last "
+                  f"{ei.max(1).values.median():6.0f}), store drain {sd.mean(1).median():6.0f} / {sd.mean(1).quantile(0.9):6.0f}", flush=True)
+            tune(-300); tune(-200); tune(4)
+        L.dvt_vit_debug_buffer(None)
