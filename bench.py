@@ -233,18 +233,24 @@ def main():
     # one image includes its two .npy writes (main_img_denoising.py:131-146).  They happen on the
     # retiring thread of the pipeline, as in the driver (dvt_amd/stage1.py), into a tmpfs directory: the metric must
     # not depend on the GPU box's disk.  Layout and atomic rename are the driver's.
-    save_root = None
+    save_root, npy_where = None, None
     if not a.no_npy:
+        import shutil
         import tempfile
-        save_root = a.save_root or tempfile.mkdtemp(prefix=f"dvt_bench_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    written = [0]
+        shm_ok = os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (512 << 20)  # (docker default: 64 MB)
+        save_root = a.save_root or tempfile.mkdtemp(prefix=f"dvt_bench_r{rank}_", dir="/dev/shm" if shm_ok else None)
+        npy_where = "caller's --save-root" if a.save_root else ("tmpfs (/dev/shm)" if shm_ok else "tempfile default directory")
+    written = [0, None]  # bytes, first error
 
     def write_pair(tag, raw_h, den_h):
-        if save_root is None:
+        if save_root is None or written[1] is not None:
             return
-        misc.atomic_save_npy(os.path.join(save_root, "raw_features", a.model, f"{tag % 16}.npy"), raw_h)
-        misc.atomic_save_npy(os.path.join(save_root, "denoised_features", a.model, f"{tag % 16}.npy"), den_h)
-        written[0] += int(raw_h.nbytes + den_h.nbytes)
+        try:  # (two slots per rank are enough for a rate; a full disk must not take the bench line down)
+            misc.atomic_save_npy(os.path.join(save_root, "raw_features", a.model, f"{tag % 2}.npy"), raw_h)
+            misc.atomic_save_npy(os.path.join(save_root, "denoised_features", a.model, f"{tag % 2}.npy"), den_h)
+            written[0] += int(raw_h.nbytes + den_h.nbytes)
+        except OSError as exc:
+            written[1] = repr(exc)
 
     def set_fit_dtype(mode):
         for e in st.engines:
@@ -295,7 +301,6 @@ def main():
         st.extract_dtype = "bfloat16"
         set_fit_dtype(a.fit_dtype)
     if save_root is not None and a.save_root is None:
-        import shutil
         shutil.rmtree(save_root, ignore_errors=True)
 
     if rank == 0:
@@ -311,11 +316,12 @@ def main():
                               if "vit_large" in a.model else a.model) +
                              f" 518x518, {a.views} views + original, {a.num_iters}-step per-image fit (B={a.pixel_bsz}, "
                              "L=16, F=8, 2^20 hash) on 1 MI355X per rank; one image = 769 ViT forwards + the fit + the "
-                             "final inference + D2H + " + ("its two .npy files (tmpfs)" if not a.no_npy else "NO file writes")),
+                             "final inference + D2H + " + ("its two .npy files" if not a.no_npy else "NO file writes")),
                 "model": a.model, "views": a.views + 1, "num_iters": a.num_iters,
                 "warmup_iters": a.warmup_iters, "pixel_bsz": a.pixel_bsz,
-                "npy_writes": None if a.no_npy else {"where": "tmpfs (/dev/shm), retiring thread, atomic rename",
-                                                      "bytes_per_image": npy_bytes // max(1, a.steps)},
+                "npy_writes": None if a.no_npy else {"where": f"{npy_where}, retiring thread, atomic rename",
+                                                      "bytes_per_image": npy_bytes // max(1, a.steps),
+                                                      "error": written[1]},
                 "precision_mode": "reference --dtype bfloat16 (autocast) end to end: ViT bf16 MFMA / fp32 accumulate; "
                                   f"fit MLP GEMMs {a.fit_dtype} operands / fp32 accumulate + outputs; hash grid, "
                                   "losses, Adam: fp32.  The reference's DEFAULT is --dtype float32 (see value_fp32_fit)",
