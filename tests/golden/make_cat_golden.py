@@ -33,6 +33,8 @@ CAT = "/root/reference/demo/cat.jpg"
 OUT = os.path.join(ROOT, "tests", "golden", "cat_demo.npz")
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # timm data config of the DINOv2 models
 V, T, WARM, B, SIZE, HP = 8, 60, 6, 2048, (518, 518), 37
+N_SEEDS = 10
+SENS_STREAMS = (0, 1, 5)
 
 
 def vit_weights():
@@ -76,10 +78,35 @@ def main():
     den = ofit.final_denoised_feats(d, f, feats, coords)[0]  # [37, 37, 768]
     keys = ("loss", "patch_l2_loss", "cosine_similarity_loss", "residual_loss", "residual_sparsity_loss")
     loss_tab = np.array([[logs[s].get(k, 0.0) for k in keys] for s in range(T)], np.float64)
+    # round 3: the oracle's FIRST and LAST total loss for ten index-stream seeds (same features, same initial parameters),
+    # so that the GPU test can hold the HIP chain's last-step loss against a distribution instead of one number
+    seeds_tab = np.zeros((N_SEEDS, 2), np.float64)
+    seeds_tab[0] = loss_tab[0, 0], loss_tab[-1, 0]
+    for seed in range(1, N_SEEDS):
+        d2, f2 = fresh_modules(0)
+        idx2 = np.random.RandomState(seed).randint(0, (V + 1) * HP * HP, (T, B))
+        lg = ofit.fit_image(d2, f2, feats, coords, idx2, num_iters=T, warmup_iters=WARM, log_every=T - 1)
+        seeds_tab[seed] = lg[0]["loss"], lg[T - 1]["loss"]
+    print("oracle last-step loss over index-stream seeds:", np.round(seeds_tab[:, 1], 4), flush=True)
+    # ... and the oracle against ITSELF: every initial parameter perturbed by 1e-6 relative (four draws, three streams).
+    # Step 59 of 60 sits on a steep curve at the peak learning rate; this is how far rounding-level input noise moves it.
+    sens = []
+    for seed in SENS_STREAMS:
+        idx2 = np.random.RandomState(seed).randint(0, (V + 1) * HP * HP, (T, B))
+        for draw in range(4):
+            d2, f2 = fresh_modules(0)
+            g = torch.Generator().manual_seed(100 + draw)
+            with torch.no_grad():
+                for p in list(d2.parameters()) + list(f2.parameters()):
+                    p.mul_(1.0 + 1e-6 * torch.randn(p.shape, generator=g))
+            lg = ofit.fit_image(d2, f2, feats, coords, idx2, num_iters=T, warmup_iters=WARM, log_every=T - 1)
+            sens.append((lg[T - 1]["loss"] - seeds_tab[seed, 1]) / seeds_tab[seed, 1])
+    sens = np.array(sens, np.float64)
+    print("oracle vs itself (init perturbed 1e-6), last-step loss rel diff:", np.round(sens, 5), flush=True)
     np.savez_compressed(
         OUT, image_u8=u8, boxes=boxes, denoised_f16=den.numpy().astype(np.float16),
         raw_orig_f16_sub=feats[-1, :, :, ::8].numpy().astype(np.float16), losses=loss_tab,
-        vit_checksum=np.float64(checksum(sd.values())), init_checksum=np.float64(init_sum),
+        vit_checksum=np.float64(checksum(sd.values())), init_checksum=np.float64(init_sum), losses_seeds=seeds_tab, last_loss_sensitivity=sens,
         meta=np.array([V, T, WARM, B], np.int64))
     print(f"wrote {OUT} ({os.path.getsize(OUT) / 1e6:.2f} MB); loss {loss_tab[0, 0]:.4f} -> {loss_tab[-1, 0]:.4f}")
 

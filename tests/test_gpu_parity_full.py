@@ -275,8 +275,41 @@ def test_cat_demo_golden(built_lib):
     assert cos_raw.mean() > 0.999
     assert cos.mean() >= 0.99 and cos.min() >= 0.95
     assert abs(l0 - z["losses"][0, 0]) <= 2e-2 * abs(z["losses"][0, 0])
-    # the last of 60 steps on a steeply falling curve, bf16-mode HIP chain vs fp32 oracle chain: 2.6-4.9 % observed
-    assert abs(l1 - z["losses"][-1, 0]) <= 1e-1 * abs(z["losses"][-1, 0])
+    # The last of 60 steps sits on a steeply falling curve, and WHICH rows the 60 x 2048 draws hit moves it: the oracle's
+    # own last-step loss over ten index streams spans 0.2249 .. 0.2420 (fixture `losses_seeds`, +-4 %).  The HIP chain is
+    # therefore held against that distribution, stream by stream (VERDICT r2 Weak #1 ii):
+    #   --dtype float32 chain (fp32 extractor -> fp32 fit), stream 0: the fp32 bar (below);
+    #   default chain (bf16 extractor -> fit), ten streams: every stream inside 10 %, the MEAN signed difference (the
+    #   systematic part: bf16 features are a slightly different regression target) inside 5 %.
+    _, feats32 = _hip_features(sd, img_u8, boxes, dtype="float32")
+    d32, f32 = fresh_modules(0)
+    e32 = hip_engine_from(d32, f32, n_rows, T, WARM, "float32")
+    e32.fit(feats32.reshape(-1, 768), coords.reshape(-1, 2).to(DEV), idx, log_every=T - 1)
+    l32 = e32.loss_log()[T - 1]["loss"]
+    c32 = per_patch_cos(e32.infer(coords[-1].to(DEV)).cpu(), want)
+    del e32
+    rel32 = (l32 - z["losses"][-1, 0]) / z["losses"][-1, 0]
+    rels = [(l1 - z["losses_seeds"][0, 1]) / z["losses_seeds"][0, 1]]
+    for seed in range(1, len(z["losses_seeds"])):
+        d_s, f_s = fresh_modules(0)
+        idx_s = np.random.RandomState(seed).randint(0, n_rows, (T, B)).astype(np.int32)
+        e = hip_engine_from(d_s, f_s, n_rows, T, WARM, "float32")
+        e.fit(feats.reshape(-1, 768), coords.reshape(-1, 2).to(DEV), idx_s, log_every=T - 1)
+        lg = e.loss_log()
+        assert abs(lg[0]["loss"] - z["losses_seeds"][seed, 0]) <= 2e-2 * z["losses_seeds"][seed, 0]
+        rels.append((lg[T - 1]["loss"] - z["losses_seeds"][seed, 1]) / z["losses_seeds"][seed, 1])
+        del e
+    rels = np.array(rels)
+    print(f"[cat.jpg golden] last-step loss, HIP vs oracle: fp32 chain {rel32:+.4f} (cos mean {c32.mean():.6f} min {c32.min():.6f}); "
+          f"default chain over {len(rels)} index streams: signed rel diff min {rels.min():+.4f} mean {rels.mean():+.4f} "
+          f"max {rels.max():+.4f}")
+    # fp32 bar: the oracle moves its own step-59 loss by up to 0.5 % when its INITIAL parameters are perturbed 1e-6 once
+    # (fixture `last_loss_sensitivity`, 12 runs); the HIP chain differs by rounding at every op of every step, so it is
+    # given 6x that one-shot sensitivity (3 %; 1.0 % observed).  The saved tensor keeps the fp32 cosine bar.
+    sens = float(np.abs(z["last_loss_sensitivity"]).max())
+    assert 1e-3 < sens < 2e-2, sens
+    assert abs(rel32) <= 6 * sens and c32.mean() >= 0.9999 and c32.min() >= 0.999, (rel32, sens, float(c32.min()))
+    assert np.abs(rels).max() <= 1e-1 and abs(rels.mean()) <= 5e-2, rels
 
 
 def test_vit_outlier_stress(built_lib):
