@@ -1554,6 +1554,9 @@ int g_vit_nt_store = 0;
 int g_vit_fuse_ln = 1;
 // 8q kernel: tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
 int g_vit_tpw = 0;
+// dvt_tune_set(1, -510 - mask): schedule mask of attention_kernel_v2 (see its header).  15 = k-step-major S, accumulator-major
+// P.V, no per-tile max tree, loop unrolled by two: 874-893 us against 908-928 us for mask 0 at 110 views (profiles/r03/r03i)
+int g_vit_attn_mask = 15;
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = software-pipelined S + deferred max, 1 = the round-2 kernel
 int g_vit_stagger = 0;  // dvt_tune_set(1, -400 - n): n half-microseconds per phase slot (0 off); -399: auto
 unsigned long long* g_vit_dbg = nullptr;  // dvt_vit_debug_buffer(): device buffer of the 8q timing build
@@ -1932,9 +1935,19 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
 //       tests/test_gpu_vit.py forces the late-rescale branch with a spiked key row (guide 5.4 rule 26).
 constexpr int ATT2_KBUF = 3;
 
+// VAR: experiment mask on top of the v2 structure (dvt_tune_set(1, -510 - mask); 0 = v2 as measured in r03):
+//   1  S MFMAs issued k-step-major (the two MFMAs of one accumulator four MFMA slots apart instead of adjacent)
+//   2  P.V: all eight V^T fragments read first, MFMAs accumulator-major per k-half (same-accumulator distance 4)
+//   4  no per-tile max tree: P is formed against the running max and the tile is redone exactly only when a lane's
+//      row sum leaves [0, e^8] (first tile: -1e30 running max -> inf -> exact path)
+//   8  tile loop unrolled by two (S / S-next swap roles instead of being copied)
+//   16 static priority for the second-dispatched half of the workgroup (waves 4-7)
+//   64 two barriers per tile, waves 4-7 one phase behind waves 0-3 (softmax of one group over P.V of the other)
+template <int VAR>
 __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                            bf16_t* __restrict__ out, int heads, int s_pad, int n_valid) {
-  __shared__ __attribute__((aligned(16))) char smem[ATT2_KBUF * KV_TILE * 128 + 2 * 64 * VT_LD];
+  constexpr int NV = (VAR & 64) ? 3 : 2;  // V^T buffers: the half-tile offset of the two wave groups needs a third
+  __shared__ __attribute__((aligned(16))) char smem[ATT2_KBUF * KV_TILE * 128 + NV * 64 * VT_LD];
   char* const Kb = smem;
   char* const Vb = smem + ATT2_KBUF * KV_TILE * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1989,7 +2002,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 #define A2_STOREK(kt) *reinterpret_cast<uint4*>(Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128) + kdo) = kr0
 #define A2_STOREV(kt)                                                                     \
   do {                                                                                    \
-    char* vb_ = Vb + ((kt) & 1) * (64 * VT_LD);                                           \
+    char* vb_ = Vb + ((kt) % NV) * (64 * VT_LD);                                          \
     *reinterpret_cast<uint2*>(vb_ + vdo0) = make_uint2(vr0.x, vr0.y);                     \
     *reinterpret_cast<uint2*>(vb_ + vdo1) = make_uint2(vr0.z, vr0.w);                     \
   } while (0)
@@ -1997,6 +2010,16 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 #define A2_S(dst, kt)                                                                                              \
   do {                                                                                                             \
     const char* Ks_ = Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128);                                                   \
+    if constexpr (VAR & 1) {                                                                                       \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                         \
+          const int krow = mt * 16 + lc;                                                                           \
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks_ + krow * 128 + (((ks * 4 + g) ^ (krow & 7)) << 4)); \
+          if (ks == 0) dst[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                      \
+          dst[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], dst[mt], 0, 0, 0);                         \
+        }                                                                                                          \
+      }                                                                                                            \
+    } else {                                                                                                       \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                             \
       dst[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                       \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
@@ -2004,6 +2027,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks_ + krow * 128 + (((ks * 4 + g) ^ (krow & 7)) << 4)); \
         dst[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], dst[mt], 0, 0, 0);                           \
       }                                                                                                            \
+    }                                                                                                              \
     }                                                                                                              \
   } while (0)
 
@@ -2019,14 +2043,22 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
   if (ntiles > 2) A2_LOADK(2);
   if (ntiles > 1) A2_LOADV(1);
   __syncthreads();
-  f32x4 s[4], sn[4];
-  A2_S(s, 0);
+  f32x4 sA[4], sB[4];
+  A2_S(sA, 0);
+  if constexpr (VAR & 16) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
+  if constexpr (VAR & 64) {
+    // ping-pong: waves 4-7 (the second wave of every SIMD) run one phase behind waves 0-3, so that one group's
+    // softmax (VALU) phase meets the other group's P.V (MFMA + LDS) phase on every SIMD
+    if (wave >= 4) __syncthreads();
+  }
   union PF { bf16x8 v; uint32_t u[4]; };
   // one tile.  LAST: the final tile (padding keys masked, no next tile to start).  From the vote onwards the body of
   // the common case is ONE basic block, so that the scheduler hints can interleave the next tile's S MFMAs with it.
   // (Tried and dropped, profiles/r03: also deferring P.V by one tile so that the block carries 16 independent MFMAs --
   // +1 % with hints, -7 % with a hand-placed MFMA / exp interleave whose LDS reads ran only two slots ahead.)
-  auto tile = [&](int kt, auto last_tag) {
+  auto tile = [&](int kt, auto last_tag, f32x4 (&s)[4], f32x4 (&sn)[4]) {
     constexpr bool LAST = decltype(last_tag)::value;
     if (kt + 2 < ntiles) A2_STOREK(kt + 2);  // loaded an iteration ago; that buffer was last read two barriers back
     if (kt + 1 < ntiles) A2_STOREV(kt + 1);
@@ -2040,16 +2072,17 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
         for (int r = 0; r < 4; ++r)
           if (kbase_idx + mt * 16 + 4 * g + r >= n_valid) s[mt][r] = -1e30f;
     }
-    float tmax = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[0][2]);
-    tmax = max3f(tmax, s[0][3], s[1][0]);
-    tmax = max3f(tmax, s[1][1], s[1][2]);
-    tmax = max3f(tmax, s[1][3], s[2][0]);
-    tmax = max3f(tmax, s[2][1], s[2][2]);
-    tmax = max3f(tmax, s[2][3], s[3][0]);
-    tmax = max3f(tmax, s[3][1], s[3][2]);
-    tmax = fmaxf(tmax, s[3][3]);
-    if (!__all(tmax <= m_run + THR)) {  // wave-uniform, rare after the first tile
-      // exact max over the query's 4 lanes (lc + 16 g): swap rows 0<->1 / 2<->3, then the wave halves
+    // exact running max over the query's 4 lanes (lc + 16 g) + rescale of o, l (everything still at the old max is scaled
+    // exactly once: P.V of the previous tile is complete)
+    auto exact_max = [&]() {
+      float tmax = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[0][2]);
+      tmax = max3f(tmax, s[0][3], s[1][0]);
+      tmax = max3f(tmax, s[1][1], s[1][2]);
+      tmax = max3f(tmax, s[1][3], s[2][0]);
+      tmax = max3f(tmax, s[2][1], s[2][2]);
+      tmax = max3f(tmax, s[2][3], s[3][0]);
+      tmax = max3f(tmax, s[3][1], s[3][2]);
+      tmax = fmaxf(tmax, s[3][3]);
       const unsigned u = __float_as_uint(tmax);
       const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
       tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
@@ -2058,7 +2091,7 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
       tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-      l_run *= alpha;  // everything still at the old max is scaled exactly once: o and l (P.V of the previous tile is complete)
+      l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         o[i][0] *= alpha;
@@ -2067,60 +2100,144 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
         o[i][3] *= alpha;
       }
       m_run = m_new;
+    };
+    if constexpr (!(VAR & 4)) {
+    float tmax = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[0][2]);
+      tmax = max3f(tmax, s[0][3], s[1][0]);
+      tmax = max3f(tmax, s[1][1], s[1][2]);
+      tmax = max3f(tmax, s[1][3], s[2][0]);
+      tmax = max3f(tmax, s[2][1], s[2][2]);
+      tmax = max3f(tmax, s[2][3], s[3][0]);
+      tmax = max3f(tmax, s[3][1], s[3][2]);
+      tmax = fmaxf(tmax, s[3][3]);
+      if (!__all(tmax <= m_run + THR)) {  // wave-uniform, rare after the first tile
+        // exact max over the query's 4 lanes (lc + 16 g): swap rows 0<->1 / 2<->3, then the wave halves
+        const unsigned u = __float_as_uint(tmax);
+        const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        const unsigned u2 = __float_as_uint(tmax);
+        const auto r32 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+        tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        l_run *= alpha;  // everything still at the old max is scaled exactly once: o and l (P.V of the previous tile is complete)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i][0] *= alpha;
+          o[i][1] *= alpha;
+          o[i][2] *= alpha;
+          o[i][3] *= alpha;
+        }
+        m_run = m_new;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!LAST) A2_S(sn, kt + 1);  // K(kt+1) became visible at the previous barrier (or in the prologue)
-    const float mb = m_run * LOG2E;
-    const f32x2 l2e2 = {LOG2E, LOG2E}, nmb2 = {-mb, -mb};
-    f32x2 ps2 = {0.f, 0.f};
+    const f32x2 l2e2 = {LOG2E, LOG2E};
     float pv[4][4];
+    f32x2 ps2;
+    auto softmax = [&]() {
+      const float mb = m_run * LOG2E;
+      const f32x2 nmb2 = {-mb, -mb};
+      ps2 = (f32x2){0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const f32x2 sv = {s[mt][2 * h2], s[mt][2 * h2 + 1]};
-        const f32x2 t = __builtin_elementwise_fma(sv, l2e2, nmb2);
-        f32x2 e;
-        e.x = __builtin_amdgcn_exp2f(t.x);
-        e.y = __builtin_amdgcn_exp2f(t.y);
-        ps2 += e;
-        pv[mt][2 * h2] = e.x;
-        pv[mt][2 * h2 + 1] = e.y;
-      }
-    l_run += ps2.x + ps2.y;
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2 sv = {s[mt][2 * h2], s[mt][2 * h2 + 1]};
+          const f32x2 t = __builtin_elementwise_fma(sv, l2e2, nmb2);
+          f32x2 e;
+          e.x = __builtin_amdgcn_exp2f(t.x);
+          e.y = __builtin_amdgcn_exp2f(t.y);
+          ps2 += e;
+          pv[mt][2 * h2] = e.x;
+          pv[mt][2 * h2 + 1] = e.y;
+        }
+    };
+    softmax();
+    float psum = ps2.x + ps2.y;
     PF pf0, pf1;
-    pf0.u[0] = pack2(pv[0][0], pv[0][1]); pf0.u[1] = pack2(pv[0][2], pv[0][3]);
-    pf0.u[2] = pack2(pv[1][0], pv[1][1]); pf0.u[3] = pack2(pv[1][2], pv[1][3]);
-    pf1.u[0] = pack2(pv[2][0], pv[2][1]); pf1.u[1] = pack2(pv[2][2], pv[2][3]);
-    pf1.u[2] = pack2(pv[3][0], pv[3][1]); pf1.u[3] = pack2(pv[3][2], pv[3][3]);
+    auto pack = [&]() {
+      pf0.u[0] = pack2(pv[0][0], pv[0][1]); pf0.u[1] = pack2(pv[0][2], pv[0][3]);
+      pf0.u[2] = pack2(pv[1][0], pv[1][1]); pf0.u[3] = pack2(pv[1][2], pv[1][3]);
+      pf1.u[0] = pack2(pv[2][0], pv[2][1]); pf1.u[1] = pack2(pv[2][2], pv[2][3]);
+      pf1.u[2] = pack2(pv[3][0], pv[3][1]); pf1.u[3] = pack2(pv[3][2], pv[3][3]);
+    };
+    pack();
     if constexpr (!LAST) {
       // scheduler shape for the block above: one S MFMA of the next tile per ~6 VALU of this tile's softmax
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, (VAR & 4) ? 5 : 6, 0);  // VALU
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (VAR & 4) {
+      // every P of this lane is within [0, e^8] iff its 16-term sum is (terms are >= 0; inf / NaN fail the compare)
+      if (!__all(psum <= 2980.0f)) {
+        exact_max();
+        softmax();
+        psum = ps2.x + ps2.y;
+        pack();
+      }
+    }
+    l_run += psum;
     // ---- O^T[d][q] += V^T . P^T
-    const char* Vs = Vb + (kt & 1) * (64 * VT_LD);
+    if constexpr (VAR & 64) __syncthreads();  // phase boundary: the other wave group starts its softmax phase here
+    const char* Vs = Vb + (kt % NV) * (64 * VT_LD);
+    if constexpr (VAR & 2) {
+      bf16x8 vf[8];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
-      const char* vrow = Vs + vr * VT_LD;
-      const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
-      const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
-      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf0.v, o[mt], 0, 0, 0);
-      o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf1.v, o[mt], 0, 0, 0);
+      for (int mt = 0; mt < 4; ++mt) {
+        const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+        const char* vrow = Vs + vr * VT_LD;
+        vf[mt] = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
+        vf[4 + mt] = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[mt], pf0.v, o[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[4 + mt], pf1.v, o[mt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the eight LDS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // then the MFMAs in source order
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+        const char* vrow = Vs + vr * VT_LD;
+        const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
+        const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pf0.v, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf1.v, o[mt], 0, 0, 0);
+      }
     }
     __syncthreads();
-    if constexpr (!LAST) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) s[mt] = sn[mt];
-    }
   };
-  for (int kt = 0; kt < ntiles - 1; ++kt) tile(kt, std::false_type{});
-  tile(ntiles - 1, std::true_type{});
+  if constexpr (VAR & 8) {
+    int kt = 0;
+    for (; kt + 2 <= ntiles - 1; kt += 2) {
+      tile(kt, std::false_type{}, sA, sB);
+      tile(kt + 1, std::false_type{}, sB, sA);
+    }
+    if (kt < ntiles - 1) {
+      tile(kt, std::false_type{}, sA, sB);
+      tile(ntiles - 1, std::true_type{}, sB, sA);
+    } else {
+      tile(ntiles - 1, std::true_type{}, sA, sB);
+    }
+  } else {
+    for (int kt = 0; kt < ntiles - 1; ++kt) {
+      tile(kt, std::false_type{}, sA, sB);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) sA[mt] = sB[mt];
+    }
+    tile(ntiles - 1, std::true_type{}, sA, sB);
+  }
+  if constexpr (VAR & 16) __builtin_amdgcn_s_setprio(0);
+  if constexpr (VAR & 64) {
+    if (wave < 4) __syncthreads();
+  }
 #undef A2_LOADK
 #undef A2_LOADV
 #undef A2_STOREK
@@ -2191,6 +2308,10 @@ int dvt_vit_tune(int v) {
   }
   if (v == -50 || v == -51) {  // non-temporal bf16 output stores off / on
     g_vit_nt_store = v == -51;
+    return 0;
+  }
+  if (v <= -510) {
+    g_vit_attn_mask = -510 - v;
     return 0;
   }
   if (v <= -500) {
@@ -2306,10 +2427,19 @@ extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int 
     return DVT_E_BADARG;
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
                       4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
-  if (g_vit_attn_variant == 2)
-    hipLaunchKernelGGL(attention_kernel_v2, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
-                       (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
-  else
+  if (g_vit_attn_variant == 2) {
+    const dim3 grid((s_pad / ATT_Q) * heads * batch);
+    bool done = false;
+#define A2_VAR(n)                                                                                                     \
+  if (g_vit_attn_mask == n) {                                                                                         \
+    hipLaunchKernelGGL(attention_kernel_v2<n>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,            \
+                       (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);                                       \
+    done = true;                                                                                                      \
+  }
+    A2_VAR(0) A2_VAR(1) A2_VAR(2) A2_VAR(4) A2_VAR(8) A2_VAR(16) A2_VAR(64) A2_VAR(3) A2_VAR(15) A2_VAR(31) A2_VAR(79)
+#undef A2_VAR
+    if (!done) return DVT_E_BADARG;
+  } else
     hipLaunchKernelGGL(attention_kernel, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
                        (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads,
                        s_pad, n_valid);
