@@ -298,6 +298,19 @@ def main():
         t = st.timings[-1]
         full_fp32 = {"images_per_s": n3 / el3, "images_timed": n3, "flow": f"pipelined (depth {a.pipeline_depth})",
                      "t_extract_s_serial": t["t_extract"], "t_fit_s_serial": t["t_fit"]}
+        # ... and the same with the extractor's linear layers as bf16x3 GEMMs (`--fp32_matmul high`: torch's float32 matmul
+        # precision "high", an opt-in the reference never sets -- reported beside value_fp32, never in its place)
+        st.extract_matmul = "high"
+        st.run(jobs(1))
+        n4, el4, _ = D.timed(lambda: st.run(jobs(3), on_result=write_pair), device)
+        st.process(lambda slot: None)
+        t = st.timings[-1]
+        full_fp32["matmul_high"] = {"images_per_s": n4 / el4, "images_timed": n4, "t_extract_s_serial": t["t_extract"],
+                                    "t_fit_s_serial": t["t_fit"],
+                                    "what": "--dtype float32 --fp32_matmul high: linear layers of the extractor as one bf16 "
+                                            "GEMM over split operands (bf16x3, ~1e-5 relative per product); LayerNorm, "
+                                            "attention, GELU, residual stream and the fit fp32"}
+        st.extract_matmul = "highest"
         st.extract_dtype = "bfloat16"
         set_fit_dtype(a.fit_dtype)
     if save_root is not None and a.save_root is None:
@@ -345,6 +358,7 @@ def main():
             out["config"][key + "_detail"] = second
         if full_fp32 is not None:
             out["value_fp32"] = full_fp32["images_per_s"]
+            out["value_fp32_matmul_high"] = full_fp32["matmul_high"]["images_per_s"]
             out["config"]["value_fp32_detail"] = full_fp32
 
         def kernel_table(pr, images):

@@ -63,7 +63,8 @@ constexpr int GBM = 128, GBN = 128, GBK = 64;
 int g_vit_gemm_variant = 4;
 constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
 
-enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4 };
+// EPI_F32: y = acc + bias written as fp32 into `x` (the bf16x3 GEMMs of the fp32 extractor, dvt_vit_f32.hip)
+enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4, EPI_F32 = 5 };
 
 struct GemmBArgs {
   const bf16_t* A;
@@ -72,7 +73,7 @@ struct GemmBArgs {
   const float* bias;  // [N]
   bf16_t* out;        // EPI_BIAS / EPI_GELU: [M, N]; EPI_QKV: qk [M, 2*dim]
   bf16_t* vt;         // EPI_QKV: [batch, heads, 64, s_pad]
-  float* x;           // EPI_RESID / EPI_EMBED: residual stream [M, N]
+  float* x;           // EPI_RESID / EPI_EMBED: residual stream [M, N]; EPI_F32: the fp32 output [M, N]
   const float* gamma; // EPI_RESID: LayerScale [N]
   const float* pos;   // EPI_EMBED: pos_embed [n_tokens, N]
   const float* cls;   // EPI_EMBED: prefix tokens [n_prefix, N] (cls, then register tokens)
@@ -209,6 +210,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4
             o = 0.f;
           p.x[(size_t)t * p.N + n] = o;
         }
+      } else if (EPI == EPI_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.x[(size_t)(mrow + r) * p.N + n] = v[r];
       } else if (EPI == EPI_QKV && n0 >= 2 * p.dim) {
         // V: transposed store vt[b][h][d][s], the lane's 4 rows are 4 consecutive tokens
         const int f = n - 2 * p.dim, h = f >> 6, d = f & 63;
@@ -331,7 +335,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   // each wave only re-reads its own block: no workgroup barrier needed, only LDS completion
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int mb = m0 + wm * 64;
-  if (EPI == EPI_RESID || EPI == EPI_EMBED) {
+  if (EPI == EPI_RESID || EPI == EPI_EMBED || EPI == EPI_F32) {
     const int c4 = lc * 4;  // 16 lanes x float4 = one 64-float row; 4 rows per pass
     float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
     if (EPI == EPI_RESID) gm = *reinterpret_cast<const float4*>(p.gamma + nb + c4);
@@ -348,6 +352,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
         o.z += gm.z * v.z;
         o.w += gm.w * v.w;
         *px = o;
+      } else if (EPI == EPI_F32) {
+        *px = v;
       } else {
         const int sidx = t % p.s_pad;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1590,7 +1596,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.mblock = g_vit_mblock > 0 ? g_vit_mblock : (g >= 6 ? 4 : 1);
     a.nt_store = g_vit_nt_store;
     const int nk = a.K / GBK;
-    if (g_vit_gemm_variant == 5 && EPI != EPI_EMBED && nk >= 4 && nk % 2 == 0) {
+    if (g_vit_gemm_variant == 5 && EPI != EPI_EMBED && EPI != EPI_F32 && nk >= 4 && nk % 2 == 0) {
       // tiles per workgroup: a workgroup should not live much longer than ~50 us (the fit's kernels on the other
       // stream start where a GEMM workgroup exits): 3 tiles at K = 768 (19 us each), 1 at K = 3072
       int tpw = g_vit_tpw > 0 ? g_vit_tpw : (nk <= 16 ? 3 : 1);
@@ -2409,6 +2415,15 @@ extern "C" int dvt_vit_gemm_residual(const void* a_in, const void* w, const floa
   a.A = (const bf16_t*)a_in; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
   a.bias = b; a.x = x; a.gamma = gamma;
   return launch_gemm<EPI_RESID>(a, (hipStream_t)stream);
+}
+
+extern "C" int dvt_vit_gemm_f32out(const void* a_in, const void* w, const float* b, float* y, int m, int n, int k,
+                                   void* stream) {
+  if (!a_in || !w || !y) return DVT_E_BADARG;
+  GemmBArgs a{};
+  a.A = (const bf16_t*)a_in; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
+  a.bias = b; a.x = y;
+  return launch_gemm<EPI_F32>(a, (hipStream_t)stream);
 }
 
 extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows,

@@ -16,8 +16,15 @@
 #include "dvt_common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned short bf16_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
 
 int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s);
+// bf16 GEMM kernels of dvt_vit.hip (fp32 accumulation), used by the bf16x3 mode below
+extern "C" int dvt_vit_gemm_f32out(const void* a, const void* w, const float* b, float* y, int m, int n, int k, void* stream);
+extern "C" int dvt_vit_gemm_residual(const void* a, const void* w, const float* b, const float* gamma, float* x, int m,
+                                     int n, int k, void* stream);
 
 namespace {
 
@@ -90,7 +97,59 @@ __global__ __launch_bounds__(256) void embed_f32_kernel(const float4* __restrict
   }
 }
 
-template <bool FINAL>
+// ---- bf16x3: an fp32 value as the sum of two bf16 -------------------------------------------------------------
+// x = hi + lo + e, hi = bf16_rn(x), lo = bf16_rn(x - hi), |e| <= 2^-17 |x| (x - hi is exact in fp32).  A GEMM over the
+// K-concatenated operands  A3 = [hi | hi | lo]  (activations)  and  W3 = [hi | lo | hi]  (weights)  accumulates
+// a_hi w_hi + a_hi w_lo + a_lo w_hi in the fp32 MFMA accumulators: everything of the fp32 product except a_lo w_lo
+// (2^-16 relative) and the two e terms.  This is what torch.set_float32_matmul_precision("high") allows for fp32
+// matmuls ("bfloat16_3x"); the reference never sets it, so it is an opt-in of this build, not what `--dtype float32`
+// means by default (include/dvt_vit.h).
+// fp32 -> bf16 round-to-nearest-even (v_cvt_pk_bf16_f32), low half = a
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const hw_bf16x2_t v = __builtin_convertvector((f32x2_t){a, b}, hw_bf16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void split2(float v, float& hi_f, uint32_t& hi_b, uint32_t& lo_b) {
+  hi_b = pack2(v, 0.f) & 0xffffu;
+  hi_f = __uint_as_float(hi_b << 16);
+  lo_b = pack2(v - hi_f, 0.f) & 0xffffu;
+}
+// four consecutive values -> their places in a [.. | .. | ..] row of width 3k (ORDER 0: hi hi lo, 1: hi lo hi)
+template <int ORDER>
+__device__ __forceinline__ void store_split4(bf16_t* row3, int k, int col, const float4& v) {
+  float hf;
+  uint32_t h[4], l[4];
+  split2(v.x, hf, h[0], l[0]);
+  split2(v.y, hf, h[1], l[1]);
+  split2(v.z, hf, h[2], l[2]);
+  split2(v.w, hf, h[3], l[3]);
+  const uint2 hh = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  const uint2 ll = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+  *reinterpret_cast<uint2*>(row3 + col) = hh;
+  *reinterpret_cast<uint2*>(row3 + k + col) = ORDER == 0 ? hh : ll;
+  *reinterpret_cast<uint2*>(row3 + 2 * k + col) = ORDER == 0 ? ll : hh;
+}
+
+// out3[r, :] = split of (GELU ? gelu(x[r, :]) : x[r, :]); x has `k` columns, out3 3k
+template <int ORDER, bool GELU>
+__global__ __launch_bounds__(256) void split3_kernel(const float4* __restrict__ x, bf16_t* __restrict__ out3,
+                                                     long long nq, int kq) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+    float4 v = x[q];
+    if (GELU) {  // nn.GELU(): exact erf form, as gelu_f32_kernel
+      v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f));
+      v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+      v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f));
+      v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+    }
+    const long long r = q / kq;
+    const int c = (int)(q - r * kq) * 4;
+    store_split4<ORDER>(out3 + r * (3LL * kq * 4), kq * 4, c, v);
+  }
+}
+
+// SPLIT: y is a bf16 [rows, 3 * dim] row of split values instead of fp32 [rows, dim]
+template <bool FINAL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y,
                                                             int rows, int dim, float eps, int s_pad, int n_tokens,
@@ -132,9 +191,12 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
     const int q = lane + 64 * i;
     if (q < nq) {
       const float4 ww = reinterpret_cast<const float4*>(w)[q], bb = reinterpret_cast<const float4*>(b)[q];
-      reinterpret_cast<float4*>(y + (size_t)row * dim)[q] =
-          make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
-                      (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+      const float4 o = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                                   (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+      if constexpr (SPLIT)
+        store_split4<0>(reinterpret_cast<bf16_t*>(y) + (size_t)row * 3 * dim, dim, q * 4, o);
+      else
+        reinterpret_cast<float4*>(y + (size_t)row * dim)[q] = o;
     }
   }
 }
@@ -273,6 +335,111 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 extern "C" int64_t dvt_vit_workspace_bytes_f32(const DvtVitConfig* c, int batch) {
   if (!c || batch <= 0 || c->s_pad % 128 || c->dim % 64 || c->heads * 64 != c->dim) return -1;
   return carve_f32(c, batch, nullptr, nullptr);
+}
+
+namespace {
+struct VitWorkX3 {
+  float *x, *qkv, *ao, *hid, *col;
+  bf16_t* a3;
+};
+inline int64_t rows256(const DvtVitConfig* c, int batch) { return ((int64_t)batch * c->s_pad + 255) / 256 * 256; }
+int64_t carve_x3(const DvtVitConfig* c, int batch, char* base, VitWorkX3* w) {
+  const int64_t T = rows256(c, batch);  // whole 256-row GEMM tiles; rows beyond batch * s_pad are computed and never read
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) {
+    char* p = base ? base + o : nullptr;
+    o += up256b(bytes);
+    return p;
+  };
+  VitWorkX3 t;
+  t.x = (float*)take(T * c->dim * 4);
+  t.qkv = (float*)take(T * 3 * c->dim * 4);
+  t.ao = (float*)take(T * c->dim * 4);
+  t.hid = (float*)take(T * c->mlp_dim * 4);
+  t.col = (float*)take(T * c->k_patch * 4);
+  const int64_t kmax = c->mlp_dim > c->k_patch ? c->mlp_dim : c->k_patch;
+  t.a3 = (bf16_t*)take(T * 3 * kmax * 2);
+  if (w) *w = t;
+  return o;
+}
+}  // namespace
+
+extern "C" int64_t dvt_vit_workspace_bytes_f32x3(const DvtVitConfig* c, int batch) {
+  if (!c || batch <= 0 || c->s_pad % 128 || c->dim % 128 || c->heads * 64 != c->dim || c->k_patch % 64) return -1;
+  return carve_x3(c, batch, nullptr, nullptr);
+}
+
+extern "C" int dvt_vit_split3(const float* x, void* out3, long long rows, int k, int weights, int gelu, void* stream) {
+  if (!x || !out3 || rows < 0 || k <= 0 || k % 4) return DVT_E_BADARG;
+  if (rows == 0) return 0;
+  const long long nq = rows * (k / 4);
+  const int blocks = (int)(nq / 256 + 1 < 256 * 16 ? nq / 256 + 1 : 256 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  if (weights)
+    hipLaunchKernelGGL((split3_kernel<1, false>), dim3(blocks), dim3(256), 0, s, (const float4*)x, (bf16_t*)out3, nq, k / 4);
+  else if (gelu)
+    hipLaunchKernelGGL((split3_kernel<0, true>), dim3(blocks), dim3(256), 0, s, (const float4*)x, (bf16_t*)out3, nq, k / 4);
+  else
+    hipLaunchKernelGGL((split3_kernel<0, false>), dim3(blocks), dim3(256), 0, s, (const float4*)x, (bf16_t*)out3, nq, k / 4);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+// fp32 in, fp32 out linear layer through the bf16x3 operands: y[m, n] = x[m, k] . W^T + b;  w3 = dvt_vit_split3(W, weights = 1)
+extern "C" int dvt_vit_linear_f32x3(const float* x, const void* w3, const float* b, float* y, void* scratch3, int m, int n,
+                                    int k, void* stream) {
+  if (!x || !w3 || !y || !scratch3) return DVT_E_BADARG;
+  int rc = dvt_vit_split3(x, scratch3, m, k, 0, 0, stream);
+  if (rc) return rc;
+  return dvt_vit_gemm_f32out(scratch3, w3, b, y, m, n, 3 * k, stream);
+}
+
+// The fp32 forward with every linear layer as ONE bf16 GEMM over the K-concatenated split operands (3 x the bf16 flops
+// on the 2.5 PF/s pipe instead of the 157 TF/s fp32 one); LayerNorm, attention (fp32 MFMA), GELU, residual stream fp32
+// as in dvt_vit_forward_f32.  `h_w`: matrices = bf16 [out, 3 * in] from dvt_vit_split3(weights = 1); vectors fp32.
+extern "C" int dvt_vit_forward_f32x3(const DvtVitConfig* c, const DvtVitWeights* w, const float* img, float* feat,
+                                     int batch, int n_blocks, void* workspace, void* stream) {
+  if (!c || !w || !img || !feat || !workspace || batch <= 0 || n_blocks < 0 || n_blocks > c->depth)
+    return DVT_E_BADARG;
+  if (c->s_pad % 128 || c->dim % 128 || c->heads * 64 != c->dim || c->k_patch % 64 || c->mlp_dim % 128) return DVT_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  VitWorkX3 k;
+  carve_x3(c, batch, (char*)workspace, &k);
+  const int T = batch * c->s_pad, D = c->dim, Tg = (int)rows256(c, batch);
+#define DVT_TRY(x)         \
+  do {                     \
+    int rc__ = (x);        \
+    if (rc__) return rc__; \
+  } while (0)
+  hipLaunchKernelGGL(im2col_f32_kernel, dim3(T), dim3(256), 0, s, img, k.col, *c);
+  DVT_CHECK_LAUNCH();
+  DVT_TRY(dvt_vit_split3(k.col, k.a3, T, c->k_patch, 0, 0, stream));
+  DVT_TRY(dvt_vit_gemm_f32out(k.a3, w->patch_w, w->patch_b, k.ao, Tg, D, 3 * c->k_patch, stream));
+  hipLaunchKernelGGL(embed_f32_kernel, dim3(T), dim3(256), 0, s, (const float4*)k.ao, (float4*)k.x,
+                     (const float4*)w->cls_token, (const float4*)w->pos_embed, *c);
+  DVT_CHECK_LAUNCH();
+  for (int l = 0; l < n_blocks; ++l) {
+    const DvtVitBlockWeights& bw = w->blocks[l];
+    hipLaunchKernelGGL((layernorm_f32_kernel<false, true>), dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm1_w,
+                       bw.norm1_b, (float*)k.a3, T, D, c->ln_eps, 0, 0, 0);
+    DVT_CHECK_LAUNCH();
+    DVT_TRY(dvt_vit_gemm_f32out(k.a3, bw.qkv_w, bw.qkv_b, k.qkv, Tg, 3 * D, 3 * D, stream));
+    DVT_TRY(dvt_vit_attention_f32(k.qkv, k.ao, batch, c->heads, c->s_pad, c->n_tokens, s));
+    DVT_TRY(dvt_vit_split3(k.ao, k.a3, T, D, 0, 0, stream));
+    DVT_TRY(dvt_vit_gemm_residual(k.a3, bw.proj_w, bw.proj_b, bw.ls1, k.x, Tg, D, 3 * D, stream));
+    hipLaunchKernelGGL((layernorm_f32_kernel<false, true>), dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm2_w,
+                       bw.norm2_b, (float*)k.a3, T, D, c->ln_eps, 0, 0, 0);
+    DVT_CHECK_LAUNCH();
+    DVT_TRY(dvt_vit_gemm_f32out(k.a3, bw.fc1_w, bw.fc1_b, k.hid, Tg, c->mlp_dim, 3 * D, stream));
+    DVT_TRY(dvt_vit_split3(k.hid, k.a3, T, c->mlp_dim, 0, 1, stream));
+    DVT_TRY(dvt_vit_gemm_residual(k.a3, bw.fc2_w, bw.fc2_b, bw.ls2, k.x, Tg, D, 3 * c->mlp_dim, stream));
+  }
+#undef DVT_TRY
+  const int out_rows = batch * (c->n_tokens - c->n_prefix);
+  hipLaunchKernelGGL(layernorm_f32_kernel<true>, dim3(dvt_cdiv(out_rows, 4)), dim3(256), 0, s, k.x, w->norm_w,
+                     w->norm_b, feat, out_rows, D, c->ln_eps, c->s_pad, c->n_tokens, c->n_prefix);
+  DVT_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int dvt_vit_attention_f32(const float* qkv, float* out, int batch, int heads, int s_pad, int n_valid,

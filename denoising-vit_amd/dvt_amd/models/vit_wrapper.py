@@ -169,24 +169,25 @@ class PretrainedViTWrapper(nn.Module):
     def last_layer_index(self) -> int:
         return self.num_blocks - 1
 
-    def _engine(self, device, dtype: str | None = None) -> "_vit.HipViT":
+    def _engine(self, device, dtype: str | None = None, matmul: str = "highest") -> "_vit.HipViT":
         dtype = dtype or self.dtype
         if not isinstance(self._hip, dict):
             self._hip = {}
-        key = (torch.device(device), dtype)
+        key = (torch.device(device), dtype, matmul)
         if key not in self._hip:
             self._hip[key] = _vit.HipViT(self._state_dict, self.patch_size, self.stride, self.img_size,
-                                         device, dtype=dtype)
+                                         device, dtype=dtype, matmul=matmul)
         return self._hip[key]
 
     def features_nhwc(self, x: torch.Tensor, layer_index: int | None = None,
                       out: torch.Tensor | None = None, max_batch: int = 128,
-                      dtype: str | None = None) -> torch.Tensor:
+                      dtype: str | None = None, matmul: str = "highest") -> torch.Tensor:
         """Fast path used by the stage-1 driver: NHWC fp32 patch-token map, optionally written
-        straight into a slice of the feature store (no NCHW round trip)."""
+        straight into a slice of the feature store (no NCHW round trip).  `matmul` "high" (float32 only): linear
+        layers through bf16x3 (dvt_amd.vit.HipViT)."""
         idx = self.last_layer_index if layer_index is None else layer_index
-        return self._engine(x.device, dtype).forward_features(x.float(), n_blocks=idx + 1, out=out,
-                                                              max_batch=max_batch)
+        return self._engine(x.device, dtype, matmul).forward_features(x.float(), n_blocks=idx + 1, out=out,
+                                                                      max_batch=max_batch)
 
     def get_intermediate_layers(
         self,

@@ -42,6 +42,11 @@ def get_args(argv=None):
     p.add_argument("--dtype", type=str, default="float32", choices=["float32", "bfloat16"],
                    help="float32 (reference default): fp32 extractor + fp32-operand fit, exact-fp32 matrix cores, "
                         "seconds per image; bfloat16: the reference's autocast mode, bf16 MFMA, ~10x faster")
+    p.add_argument("--fp32_matmul", type=str, default="highest", choices=["highest", "high"],
+                   help="with --dtype float32 only; torch.set_float32_matmul_precision's vocabulary.  highest (default, "
+                        "what the reference runs with): exact-fp32 matrix cores.  high: the extractor's linear layers as "
+                        "bf16x3 GEMMs (~1e-5 relative per product, ~3x faster extractor); LayerNorm, attention, GELU, the "
+                        "residual stream and the whole fit stay fp32")
     p.add_argument("--data_root", type=str, default=None)
     p.add_argument("--save_root", type=str, default=None)
     p.add_argument("--start_idx", type=int, default=0)
@@ -186,6 +191,11 @@ class Stage1:
         # extractor AND fp32-operand fit (autocast off, its default); bfloat16 = both under bf16 autocast
         self.extract_dtype = ("bfloat16" if str(getattr(args, "dtype", "float32")) in
                               ("bfloat16", "bf16", "torch.bfloat16") else "float32")
+        self.extract_matmul = str(getattr(args, "fp32_matmul", "highest") or "highest")
+        if self.extract_matmul not in ("highest", "high"):
+            raise DvtError(f"--fp32_matmul must be highest or high, not {self.extract_matmul!r}")
+        if self.extract_dtype != "float32":
+            self.extract_matmul = "highest"  # the switch only exists for fp32 operands
         # Everything above was allocated / zero-filled on the CURRENT stream; the first writers are the
         # side streams.  One device-wide sync here orders them for good (a zero-fill must never land
         # after set_views / reset).
@@ -200,7 +210,8 @@ class Stage1:
         NCHW round trip; batches of 128 views keep every GEMM at M = 128*1408 rows."""
         with torch.no_grad():
             self.vit.features_nhwc(slot.views, self.layer_index, out=slot.features,
-                                   max_batch=self.extract_bsz, dtype=self.extract_dtype)
+                                   max_batch=self.extract_bsz, dtype=self.extract_dtype,
+                                   matmul=self.extract_matmul)
 
     def fit(self, slot: _Slot, log_every: int = 1000) -> torch.Tensor:
         """denoise_an_image (:28-149): fresh models, the loop, then F on the original image's

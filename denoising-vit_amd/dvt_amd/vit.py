@@ -52,6 +52,11 @@ _lib.register_signatures({
     "dvt_vit_forward_f32": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
     "dvt_vit_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dvt_vit_debug_buffer": (_I, [_P]),
+    "dvt_vit_split3": (_I, [_P, _P, C.c_longlong, _I, _I, _I, _P]),
+    "dvt_vit_linear_f32x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dvt_vit_gemm_f32out": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dvt_vit_workspace_bytes_f32x3": (C.c_int64, [C.POINTER(VitConfig), _I]),
+    "dvt_vit_forward_f32x3": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
 })
 
 
@@ -152,12 +157,18 @@ class HipViT:
     """Device-resident weights + the forward launcher."""
 
     def __init__(self, state_dict: dict, patch: int, stride: int, img_size: tuple[int, int],
-                 device: torch.device | str = "cuda", dtype: str = "bfloat16"):
+                 device: torch.device | str = "cuda", dtype: str = "bfloat16", matmul: str = "highest"):
         """dtype "bfloat16": bf16 operands / fp32 accumulate (the reference's `--dtype bfloat16` autocast mode);
-        "float32": fp32 operands everywhere (its default, autocast off) -- 16x less matrix throughput."""
+        "float32": fp32 operands everywhere (its default, autocast off) -- 16x less matrix throughput.
+        `matmul` (float32 only) is torch.set_float32_matmul_precision's vocabulary: "highest" (default, what the reference
+        runs with) = exact-fp32 matrix cores; "high" = every linear layer as one bf16 GEMM over split operands
+        ("bfloat16_3x", ~1e-5 relative per product; include/dvt_vit.h) -- an opt-in, never implied by `--dtype float32`."""
         if dtype not in ("bfloat16", "float32"):
             raise _lib.DvtError(f"ViT dtype must be bfloat16 or float32, not {dtype!r}")
+        if matmul not in ("highest", "high") or (matmul == "high" and dtype != "float32"):
+            raise _lib.DvtError(f"matmul must be 'highest' or (with dtype float32) 'high', not {matmul!r}")
         self.dtype = dtype
+        self.x3 = matmul == "high"
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DvtError("HipViT needs a HIP device; there is no CPU fallback")
@@ -180,9 +191,16 @@ class HipViT:
             self._keep.append(t)
             return t.data_ptr()
 
-        def bf16(t):  # the matrix operands: bf16, or fp32 as they are in the fp32 mode
-            t = t.to(dev, torch.float32)
-            t = (t if dtype == "float32" else t.to(torch.bfloat16)).contiguous()
+        def bf16(t):  # the matrix operands: bf16, or fp32 as they are in the fp32 mode, or its [hi | lo | hi] split
+            t = t.to(dev, torch.float32).contiguous()
+            if self.x3:
+                t3 = torch.empty((t.shape[0], 3 * t.shape[1]), device=dev, dtype=torch.bfloat16)
+                _lib.check(_lib.lib().dvt_vit_split3(t.data_ptr(), t3.data_ptr(), t.shape[0], t.shape[1], 1, 0,
+                                                     _lib.stream()), "dvt_vit_split3")
+                torch.cuda.synchronize(dev)  # `t` may be freed on return
+                t = t3
+            elif dtype != "float32":
+                t = t.to(torch.bfloat16).contiguous()
             self._keep.append(t)
             return t.data_ptr()
 
@@ -222,7 +240,8 @@ class HipViT:
 
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch < batch:
-            size_fn = (_lib.lib().dvt_vit_workspace_bytes_f32 if self.dtype == "float32"
+            size_fn = (_lib.lib().dvt_vit_workspace_bytes_f32x3 if self.x3 else
+                       _lib.lib().dvt_vit_workspace_bytes_f32 if self.dtype == "float32"
                        else _lib.lib().dvt_vit_workspace_bytes)
             nbytes = int(size_fn(C.byref(self.cfg), batch))
             self._ws = torch.zeros(nbytes, device=self.device, dtype=torch.uint8)
@@ -245,7 +264,8 @@ class HipViT:
         if not out.is_contiguous() or tuple(out.shape) != (B, cfg.grid_h, cfg.grid_w, cfg.dim):
             raise _lib.DvtError("out must be a contiguous [B, grid_h, grid_w, dim] fp32 tensor")
         if self.dtype == "float32":
-            max_batch = min(max_batch, 32)  # fp32 activations: 32 views keep the scratch at ~1.3 GB
+            # fp32 activations: 32 views keep the scratch at ~1.3 GB (bf16x3: 64 views, 4.4 GB, for fuller GEMM launches)
+            max_batch = min(max_batch, 64 if self.x3 else 32)
         # equal-sized launches: 769 views at max_batch 128 would be 6 x 128 + ONE view whose GEMMs fill 6 of 256 CUs;
         # 7 x 110 (109) keeps every launch full (measured: within noise, 2.718 vs 2.712 images/s on one box).  Results do
         # not depend on the batching (tests/test_gpu_vit.py).
@@ -254,7 +274,7 @@ class HipViT:
             max_batch = -(-B // n_launch)
         ws = self._workspace(min(B, max_batch))
         L = _lib.lib()
-        fwd = L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward
+        fwd = L.dvt_vit_forward_f32x3 if self.x3 else L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward
         for b0 in range(0, B, max_batch):
             nb = min(max_batch, B - b0)
             _lib.check(fwd(C.byref(cfg), C.byref(self.weights), img[b0:].data_ptr(), out[b0:].data_ptr(), nb,

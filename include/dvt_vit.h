@@ -95,6 +95,26 @@ int dvt_vit_forward(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const f
 int64_t dvt_vit_workspace_bytes_f32(const DvtVitConfig* h_cfg, int batch);
 int dvt_vit_forward_f32(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img, float* feat,
                         int batch, int n_blocks, void* workspace, void* stream);
+/* Opt-in "bf16x3" arithmetic for the LINEAR layers of the fp32 forward -- what torch.set_float32_matmul_precision("high")
+ * permits for fp32 matmuls ("bfloat16_3x"); the reference never sets it, so `--dtype float32` keeps meaning
+ * dvt_vit_forward_f32 unless the caller asks for this.  Every fp32 operand is split into two bf16 (x = hi + lo, 2^-17
+ * relative), and ONE bf16 GEMM over the K-concatenated operands [hi | hi | lo] . [hi | lo | hi]^T accumulates
+ * a_hi w_hi + a_hi w_lo + a_lo w_hi in fp32: ~1e-5 relative per product instead of 6e-8, at 3 x the bf16 flops on the
+ * 2.5 PF/s pipe instead of the 157 TF/s fp32 one.  LayerNorm, attention, GELU (exact erf) and the residual stream stay
+ * fp32 exactly as in dvt_vit_forward_f32.
+ *   dvt_vit_split3: x fp32 [rows, k] -> out3 bf16 [rows, 3k]; weights = 1: [hi | lo | hi] (nn.Linear weights, once at
+ *     load time), else [hi | hi | lo] (activations; gelu = 1 applies nn.GELU() first).
+ *   dvt_vit_linear_f32x3: y = x . W^T + b with x, y fp32; scratch3 = bf16 [m, 3k]; m % 128 == n % 128 == k % 64 == 0.
+ *   dvt_vit_forward_f32x3: `h_w` matrices = bf16 [out, 3 * in] from dvt_vit_split3(weights = 1) (patch_w: [dim,
+ *     3 * k_patch], zero padded BEFORE the split); workspace dvt_vit_workspace_bytes_f32x3, zero-filled once.        */
+int dvt_vit_split3(const float* x, void* out3, long long rows, int k, int weights, int gelu, void* stream);
+int dvt_vit_linear_f32x3(const float* x, const void* w3, const float* b, float* y, void* scratch3, int m, int n, int k,
+                         void* stream);
+int dvt_vit_gemm_f32out(const void* a_bf16, const void* w_bf16, const float* b, float* y, int m, int n, int k,
+                        void* stream);
+int64_t dvt_vit_workspace_bytes_f32x3(const DvtVitConfig* h_cfg, int batch);
+int dvt_vit_forward_f32x3(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img, float* feat,
+                          int batch, int n_blocks, void* workspace, void* stream);
 /* fp32 attention on qkv [batch*s_pad, 3*heads*64] (q | k | v, head-major inside): out [batch*s_pad, heads*64] */
 int dvt_vit_attention_f32(const float* qkv, float* out, int batch, int heads, int s_pad, int n_valid, void* stream);
 

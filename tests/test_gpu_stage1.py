@@ -53,6 +53,43 @@ def test_stage1_driver_end_to_end(built_lib, tmp_path, capsys, fit_batch):
     assert "Skipping" in capsys.readouterr().out
 
 
+def test_stage1_driver_fp32_matmul_high_equals_highest(built_lib, tmp_path):
+    """`--dtype float32 --fp32_matmul high` (bf16x3 linear layers in the extractor, an opt-in) against the default
+    `--fp32_matmul highest` on the same image, same seeds: raw features to bf16x3 accuracy, denoised features inside the
+    fp32 chain bar; and the switch is ignored (not an error) under --dtype bfloat16."""
+    from dvt_amd import stage1
+    data_root = tmp_path / "data"
+    data_root.mkdir()
+    _make_image(str(data_root / "a.png"))
+    lst = tmp_path / "list.txt"
+    lst.write_text("a.png\n")
+    outs = {}
+    for mm in ("highest", "high"):
+        argv = ["--img_path", str(lst), "--data_root", str(data_root), "--save_root", str(tmp_path / mm),
+                "--output_dir", str(tmp_path / ("work_" + mm)), "--num_views", "15", "--num_iters", "60", "--warmup_iters", "6",
+                "--num_imgs", "1", "--allow_random_vit", "--dtype", "float32", "--fp32_matmul", mm]
+        args = stage1.get_args(argv)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert stage1.main(args) == 1
+        model = "vit_base_patch14_dinov2.lvd142m"
+        outs[mm] = (np.load(tmp_path / mm / "raw_features" / model / "a.npy"),
+                    np.load(tmp_path / mm / "denoised_features" / model / "a.npy")[0])
+    raw_a, raw_b = (torch.from_numpy(outs[m][0]).reshape(-1, 768) for m in ("highest", "high"))
+    den_a, den_b = (torch.from_numpy(outs[m][1]).reshape(-1, 768) for m in ("highest", "high"))
+    raw_err = float((raw_a - raw_b).norm() / raw_a.norm())
+    cos = torch.nn.functional.cosine_similarity(den_a, den_b, dim=-1)
+    print(f"[--fp32_matmul high vs highest] raw features rel-L2 {raw_err:.2e}; denoised cos mean {cos.mean():.6f} min {cos.min():.6f}")
+    assert 0 < raw_err < 1e-4
+    assert cos.mean() >= 0.9999 and cos.min() >= 0.999
+    args = stage1.get_args(["--img_path", str(lst), "--data_root", str(data_root), "--save_root", str(tmp_path / "bf"),
+                            "--num_views", "15", "--num_iters", "20", "--num_imgs", "1", "--allow_random_vit",
+                            "--dtype", "bfloat16", "--fp32_matmul", "high"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert stage1.main(args) == 1
+
+
 def test_render_views_vs_torch_antialias_bicubic(built_lib):
     """dvt_render_views against torch.nn.functional.interpolate(mode="bicubic", antialias=True) (the
     op SURVEY.md 8c names as the oracle for transform.py:50-52): up-sampled random crops, border

@@ -298,6 +298,66 @@ def test_vit_forward_f32_vs_oracle(L, dim, depth, img, stride, n_reg):
     assert err < 0.02 * err_bf
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 768, 768), (512, 2304, 768), (256, 768, 3072), (128, 384, 640)])
+def test_linear_f32x3_vs_fp64(L, m, n, k):
+    """The opt-in bf16x3 linear layer (torch's float32 matmul precision "high"; include/dvt_vit.h): operands with a wide
+    dynamic range, fp64 reference.  The split is exact to 2^-17 and the product keeps everything but a_lo w_lo, so the
+    result must sit ~1e-5 from fp64 -- three orders tighter than a plain bf16 GEMM, two above true fp32."""
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * torch.exp(2.0 * torch.randn(m, 1, generator=g))).float()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5 * torch.exp(torch.randn(n, 1, generator=g))).float()
+    b = torch.randn(n, generator=g)
+    want = x.double() @ w.double().T + b.double()
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    x3 = torch.empty(m, 3 * k, device=DEV, dtype=torch.bfloat16)
+    w3 = torch.empty(n, 3 * k, device=DEV, dtype=torch.bfloat16)
+    y = torch.empty(m, n, device=DEV)
+    assert L.dvt_vit_split3(wd.data_ptr(), w3.data_ptr(), n, k, 1, 0, _s()) == 0
+    assert L.dvt_vit_linear_f32x3(xd.data_ptr(), w3.data_ptr(), bd.data_ptr(), y.data_ptr(), x3.data_ptr(), m, n, k, _s()) == 0
+    torch.cuda.synchronize()
+    # the split itself: hi + lo == x to 2^-16 relative, layouts [hi | hi | lo] / [hi | lo | hi]
+    xs, ws = x3.float().cpu(), w3.float().cpu()
+    assert torch.equal(xs[:, :k], xs[:, k:2 * k]) and torch.equal(ws[:, :k], ws[:, 2 * k:])
+    assert torch.equal(xs[:, :k], x.bfloat16().float())
+    assert float(((xs[:, :k] + xs[:, 2 * k:]) - x).abs().max() / x.abs().max()) < 2 ** -16
+    assert float(((ws[:, :k] + ws[:, k:2 * k]) - w).abs().div(w.abs() + 1e-30).max()) < 2 ** -15
+    got = y.double().cpu()
+    err = float((got - want).norm() / want.norm())
+    err_bf = float(((x.bfloat16().double() @ w.bfloat16().double().T + b.double()) - want).norm() / want.norm())
+    err_f32 = float(((x @ w.T + b).double() - want).norm() / want.norm())
+    print(f"bf16x3 linear {m}x{n}x{k}: rel-L2 vs fp64 {err:.2e} (torch fp32 on the CPU {err_f32:.2e}, plain bf16 operands {err_bf:.2e})")
+    assert err < 2e-5 and err < 0.01 * err_bf
+    row = (got - want).norm(dim=1) / want.norm(dim=1)
+    assert float(row.max()) < 5e-5  # per row: the wide per-row scales do not leak into each other
+
+
+@pytest.mark.parametrize("dim,depth,img,stride,n_reg", [(128, 2, 56, 14, 0), (256, 2, 98, 7, 4), (768, 2, 518, 14, 0),
+                                                        (768, 12, 518, 14, 0)])
+def test_vit_forward_f32x3_vs_oracle(L, dim, depth, img, stride, n_reg):
+    """HipViT(dtype="float32", matmul="high"): linear layers through bf16x3, everything else fp32.  Held to the SAME
+    fp32-oracle bars as the exact-fp32 extractor except for the rel-L2 bound (1e-4 instead of 2e-5), with an odd batch
+    (3 views: 1.5 GEMM tiles of phantom rows at s_pad 1408) and the result of the exact path printed beside it."""
+    from dvt_amd.vit import HipViT, random_state_dict
+    g0 = img // 14
+    sd = random_state_dict(dim, depth, 14, (0 if n_reg else 1) + g0 * g0, seed=dim + 1, well_conditioned=True,
+                           n_reg=n_reg)
+    x = torch.randn(3, 3, img, img, generator=torch.Generator().manual_seed(3))
+    want = ovit.forward_features(sd, x, 14, stride)
+    got = HipViT(sd, 14, stride, (img, img), DEV, dtype="float32", matmul="high").forward_features(x.to(DEV)).cpu()
+    exact = HipViT(sd, 14, stride, (img, img), DEV, dtype="float32").forward_features(x.to(DEV)).cpu()
+    assert got.shape == want.shape and bool(torch.isfinite(got).all())
+    err, err_exact = float((got - want).norm() / want.norm()), float((exact - want).norm() / want.norm())
+    cos = F.cosine_similarity(got.reshape(-1, dim), want.reshape(-1, dim), dim=-1)
+    bf = HipViT(sd, 14, stride, (img, img), DEV).forward_features(x.to(DEV)).cpu()
+    err_bf = float((bf - want).norm() / want.norm())
+    print(f"fp32 ViT, bf16x3 linears, dim={dim} depth={depth} stride={stride} reg={n_reg}: rel-L2 {err:.2e} "
+          f"(exact fp32 {err_exact:.2e}, bf16 extractor {err_bf:.2e}), cos min {cos.min():.8f}")
+    assert err < 1e-4 and cos.min() > 0.999999
+    assert err < 0.05 * err_bf
+    with pytest.raises(Exception):
+        HipViT(sd, 14, stride, (img, img), DEV, dtype="bfloat16", matmul="high")
+
+
 @pytest.mark.parametrize("depth,batch", [(3, 2), (12, 4)])
 def test_layernorm_folded_into_gemms(L, depth, batch):
     """LayerNorm folded into the qkv / fc1 GEMMs and the proj / fc2 residual epilogues (dvt_vit.hip: ln_fold) against
