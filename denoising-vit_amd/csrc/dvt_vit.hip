@@ -39,6 +39,8 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
+extern int g_f32x3_exact_attention, g_f32x3_unfused;  // dvt_vit_f32.hip (dvt_tune_set(1, -520 ... -523))
+
 namespace {
 
 typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
@@ -64,7 +66,13 @@ int g_vit_gemm_variant = 4;
 constexpr int STAGE_BYTES = (GBM + GBN) * GBK * 2;  // 32 KB
 
 // EPI_F32: y = acc + bias written as fp32 into `x` (the bf16x3 GEMMs of the fp32 extractor, dvt_vit_f32.hip)
-enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4, EPI_F32 = 5 };
+// EPI_GELU_X3 / EPI_QKV_X3 (same mode): the outputs leave as (hi, lo) bf16 splits of the fp32 values -- GELU(h) as the
+// next GEMM's [hi | hi | lo] row (`out`, row stride 3 N), q | k as two [M, 2 dim] arrays (`out`, `out_lo`) and V^T as two
+// [batch, heads, 64, s_pad] arrays (`vt`, `vt_lo`): what the split kernels + the qkv prep kernels would write.
+enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_EMBED = 4, EPI_F32 = 5, EPI_GELU_X3 = 6, EPI_QKV_X3 = 7 };
+#define IS_QKV(E) ((E) == EPI_QKV || (E) == EPI_QKV_X3)
+#define IS_GELU(E) ((E) == EPI_GELU || (E) == EPI_GELU_X3)
+#define IS_X3(E) ((E) == EPI_GELU_X3 || (E) == EPI_QKV_X3)
 
 struct GemmBArgs {
   const bf16_t* A;
@@ -73,6 +81,8 @@ struct GemmBArgs {
   const float* bias;  // [N]
   bf16_t* out;        // EPI_BIAS / EPI_GELU: [M, N]; EPI_QKV: qk [M, 2*dim]
   bf16_t* vt;         // EPI_QKV: [batch, heads, 64, s_pad]
+  bf16_t* out_lo;     // EPI_QKV_X3: the lo parts of q | k ...
+  bf16_t* vt_lo;      // ... and of V^T
   float* x;           // EPI_RESID / EPI_EMBED: residual stream [M, N]; EPI_F32: the fp32 output [M, N]
   const float* gamma; // EPI_RESID: LayerScale [N]
   const float* pos;   // EPI_EMBED: pos_embed [n_tokens, N]
@@ -213,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4
       } else if (EPI == EPI_F32) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) p.x[(size_t)(mrow + r) * p.N + n] = v[r];
-      } else if (EPI == EPI_QKV && n0 >= 2 * p.dim) {
+      } else if (IS_QKV(EPI) && n0 >= 2 * p.dim) {
         // V: transposed store vt[b][h][d][s], the lane's 4 rows are 4 consecutive tokens
         const int f = n - 2 * p.dim, h = f >> 6, d = f & 63;
         const int b = mrow / p.s_pad, s = mrow - b * p.s_pad;
@@ -221,12 +231,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4
         pk.x = pack2(v[0], v[1]);
         pk.y = pack2(v[2], v[3]);
         *reinterpret_cast<uint2*>(p.vt + ((size_t)(b * p.heads + h) * 64 + d) * p.s_pad + s) = pk;
+        if (EPI == EPI_QKV_X3) {
+          uint2 pl;
+          pl.x = pack2(v[0] - __uint_as_float(pk.x << 16), v[1] - __uint_as_float(pk.x & 0xffff0000u));
+          pl.y = pack2(v[2] - __uint_as_float(pk.y << 16), v[3] - __uint_as_float(pk.y & 0xffff0000u));
+          *reinterpret_cast<uint2*>(p.vt_lo + ((size_t)(b * p.heads + h) * 64 + d) * p.s_pad + s) = pl;
+        }
       } else {
-        if (EPI == EPI_GELU) {
+        if (IS_GELU(EPI)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
-        const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
+        const int ldo = (IS_QKV(EPI)) ? 2 * p.dim : p.N;
         // pair adjacent columns across lanes (l, l^1): even lanes store rows r=0,1 of the
         // column pair, odd lanes rows r=2,3 -> 4-B stores instead of 2-B stores
         const bool odd = lane & 1;
@@ -310,8 +326,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
                                                   char* smem) {
   const int g = lane >> 4, lc = lane & 15;
   // LayerNorm folded into this GEMM (see ln_fold): the accumulators are x . W'^T of the UN-normalised rows
-  const bool ln = (EPI == EPI_QKV || EPI == EPI_GELU) && p.ln_stats != nullptr;
-  if (EPI == EPI_QKV && n0 >= 2 * p.dim) {  // V tiles keep the direct transposed store
+  const bool ln = (IS_QKV(EPI) || IS_GELU(EPI)) && p.ln_stats != nullptr;
+  if (IS_QKV(EPI) && n0 >= 2 * p.dim) {  // V tiles keep the direct transposed store
     if (ln) ln_fold<4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
     gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
     return;
@@ -372,7 +388,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
       }
     }
   } else {
-    const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
+    const int ldo = (IS_QKV(EPI)) ? 2 * p.dim : p.N;
     const int c8 = (lane & 7) * 8;  // 8 lanes x 8 columns = one row; 8 rows per pass
     // (GELU: one row at a time -- four rows of erf polynomials in flight took the fc1 kernel to 254 VGPRs,
     // and at 2 x 256 registers per SIMD no wave of the fit's streaming kernels can share the CU)
@@ -383,7 +399,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
       bf0 = *reinterpret_cast<const float4*>(p.bias + nb + c8);
       bf1 = *reinterpret_cast<const float4*>(p.bias + nb + c8 + 4);
     }
-#pragma unroll(EPI == EPI_GELU ? 1 : 4)
+#pragma unroll(IS_GELU(EPI) ? 1 : 4)
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3);
       float4 a = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8);
@@ -400,7 +416,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
         b.z = fmaf(rs, b.z - mu * cs1.z, bf1.z);
         b.w = fmaf(rs, b.w - mu * cs1.w, bf1.w);
       }
-      if (EPI == EPI_GELU) {
+      if (IS_GELU(EPI)) {
         a.x = gelu_erf(a.x);
         a.y = gelu_erf(a.y);
         a.z = gelu_erf(a.z);
@@ -416,8 +432,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
       pk.z = pack2(b.x, b.y);
       pk.w = pack2(b.z, b.w);
       typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-      u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out + (size_t)(mb + row) * ldo + nb + c8);
       const u32x4_t val = {pk.x, pk.y, pk.z, pk.w};
+      if constexpr (IS_X3(EPI)) {
+        u32x4_t vlo;
+        vlo.x = pack2(a.x - __uint_as_float(pk.x << 16), a.y - __uint_as_float(pk.x & 0xffff0000u));
+        vlo.y = pack2(a.z - __uint_as_float(pk.y << 16), a.w - __uint_as_float(pk.y & 0xffff0000u));
+        vlo.z = pack2(b.x - __uint_as_float(pk.z << 16), b.y - __uint_as_float(pk.z & 0xffff0000u));
+        vlo.w = pack2(b.z - __uint_as_float(pk.w << 16), b.w - __uint_as_float(pk.w & 0xffff0000u));
+        if constexpr (EPI == EPI_GELU_X3) {  // the next GEMM's A row: [hi | hi | lo], each N wide
+          bf16_t* r3 = p.out + (size_t)(mb + row) * (3 * p.N) + nb + c8;
+          *reinterpret_cast<u32x4_t*>(r3) = val;
+          *reinterpret_cast<u32x4_t*>(r3 + p.N) = val;
+          *reinterpret_cast<u32x4_t*>(r3 + 2 * p.N) = vlo;
+        } else {
+          *reinterpret_cast<u32x4_t*>(p.out + (size_t)(mb + row) * ldo + nb + c8) = val;
+          *reinterpret_cast<u32x4_t*>(p.out_lo + (size_t)(mb + row) * ldo + nb + c8) = vlo;
+        }
+        continue;
+      }
+      u32x4_t* dst = reinterpret_cast<u32x4_t*>(p.out + (size_t)(mb + row) * ldo + nb + c8);
       if (p.nt_store)
         __builtin_nontemporal_store(val, dst);  // streamed output: do not displace the operand panels in L2
       else
@@ -1284,13 +1317,13 @@ __device__ __forceinline__ void q_epilogue_swapped(const EpiArgs& p, f32x4 (&acc
       }
     }
   } else {
-    const bool ln = (EPI == EPI_QKV || EPI == EPI_GELU) && p.ln_stats != nullptr;
+    const bool ln = (IS_QKV(EPI) || IS_GELU(EPI)) && p.ln_stats != nullptr;
     float2 st[8];
     if (ln) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) st[i] = p.ln_stats[mb + i * 16 + lc];
     }
-    const int ldo = (EPI == EPI_QKV) ? 2 * p.dim : p.N;
+    const int ldo = (IS_QKV(EPI)) ? 2 * p.dim : p.N;
     bf16_t* orow = p.out + (size_t)(mb + lc) * ldo + nb + 8 * g;
     float4 cs[2][2], bs[2][2];
 #pragma unroll
@@ -1319,7 +1352,7 @@ __device__ __forceinline__ void q_epilogue_swapped(const EpiArgs& p, f32x4 (&acc
         for (int e = 0; e < 8; ++e) {
           if (ln) v[e] = fmaf(st[i].y, v[e] - st[i].x * cv[e], bv[e]);  // rstd * (acc - mean * cs) + b'
           else v[e] += bv[e];
-          if (EPI == EPI_GELU) v[e] = gelu_erf(v[e]);
+          if (IS_GELU(EPI)) v[e] = gelu_erf(v[e]);
         }
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         const u32x4_t pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
@@ -1530,7 +1563,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const QSrc nxt = src_of(first_tile + ti + 1, ti + 1 < count, m1, n1);
     const int mb = m0 + wm * 128, nb = n0 + wn * 64;
 #define Q_CALL(SW) q_tile<EPI, SW, ABL>(kp, acc, smem, ldsw, cur, nxt, ti == 0, nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1, mb, nb, lane, first_tile + ti)
-    if constexpr (EPI == EPI_QKV) {
+    if constexpr (IS_QKV(EPI)) {
       if (n0 >= 2 * p.dim) Q_CALL(false);
       else Q_CALL(true);
     } else {
@@ -1571,10 +1604,11 @@ int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 8q ker
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   if (a0.M % GBM || a0.N % GBN || a0.K % GBK || a0.M <= 0) return DVT_E_BADARG;
+  if (IS_X3(EPI) && a0.M % 256) return DVT_E_BADARG;  // written for the LDS-staged epilogues (256-row tiles) only
   GemmBArgs a = a0;
   if (!a.lda) a.lda = a.K;
   if (!a.ldw) a.ldw = a.K;
-  a.dim_ok_sq = (EPI != EPI_QKV) || (a.dim % 256 == 0);
+  a.dim_ok_sq = (!IS_QKV(EPI)) || (a.dim % 256 == 0);
   {
     const int nt = a.N / GBN;
     int g = g_vit_group_bytes / (GBN * a.K * 2);
@@ -1596,7 +1630,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.mblock = g_vit_mblock > 0 ? g_vit_mblock : (g >= 6 ? 4 : 1);
     a.nt_store = g_vit_nt_store;
     const int nk = a.K / GBK;
-    if (g_vit_gemm_variant == 5 && EPI != EPI_EMBED && EPI != EPI_F32 && nk >= 4 && nk % 2 == 0) {
+    if (g_vit_gemm_variant == 5 && EPI != EPI_EMBED && EPI != EPI_F32 && !IS_X3(EPI) && nk >= 4 && nk % 2 == 0) {
       // tiles per workgroup: a workgroup should not live much longer than ~50 us (the fit's kernels on the other
       // stream start where a GEMM workgroup exits): 3 tiles at K = 768 (19 us each), 1 at K = 3072
       int tpw = g_vit_tpw > 0 ? g_vit_tpw : (nk <= 16 ? 3 : 1);
@@ -1630,6 +1664,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     DVT_CHECK_LAUNCH();
     return 0;
   }
+  if (IS_X3(EPI)) return DVT_E_BADARG;  // the 128 x 128 kernel's register epilogue does not write the split outputs
   const int tiles = (a.M / GBM) * (a.N / GBN);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(tiles), dim3(256), 0, s, a);
   DVT_CHECK_LAUNCH();
@@ -1949,13 +1984,20 @@ constexpr int ATT2_KBUF = 3;
 //   8  tile loop unrolled by two (S / S-next swap roles instead of being copied)
 //   16 static priority for the second-dispatched half of the workgroup (waves 4-7)
 //   64 two barriers per tile, waves 4-7 one phase behind waves 0-3 (softmax of one group over P.V of the other)
-template <int VAR>
+// X3 (the fp32 extractor's opt-in "bf16x3" mode, include/dvt_vit.h): q, k, v arrive as (hi, lo) bf16 pairs of the fp32
+// values (qk / vt = hi, qk_lo / vt_lo = lo), S = K_lo.Q_hi + K_hi.Q_lo + K_hi.Q_hi and O += V_lo.P_hi + V_hi.P_lo + V_hi.P_hi
+// with P split in registers (3 x the MFMAs, fp32 accumulation, fp32 softmax as before) and `out` is fp32 [T, dim].
+template <int VAR, bool X3 = false>
 __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
-                                                           bf16_t* __restrict__ out, int heads, int s_pad, int n_valid) {
+                                                           bf16_t* __restrict__ out, int heads, int s_pad, int n_valid,
+                                                           const bf16_t* __restrict__ qk_lo, const bf16_t* __restrict__ vt_lo) {
   constexpr int NV = (VAR & 64) ? 3 : 2;  // V^T buffers: the half-tile offset of the two wave groups needs a third
-  __shared__ __attribute__((aligned(16))) char smem[ATT2_KBUF * KV_TILE * 128 + NV * 64 * VT_LD];
+  constexpr int KSET = ATT2_KBUF * KV_TILE * 128, VSET = NV * 64 * VT_LD;  // one precision part: 24 KB + 16 KB
+  __shared__ __attribute__((aligned(16))) char smem[(X3 ? 2 : 1) * (KSET + VSET)];
   char* const Kb = smem;
-  char* const Vb = smem + ATT2_KBUF * KV_TILE * 128;
+  char* const Vb = smem + KSET;
+  char* const Kbl = smem + KSET + VSET;  // X3: the lo parts
+  char* const Vbl = Kbl + KSET;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lc = lane & 15;
   const int nqb = s_pad / ATT_Q;
@@ -1968,9 +2010,9 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
   const int dim = heads * 64, ldq = 2 * dim;
   const size_t row0 = (size_t)b * s_pad;
 
-  bf16x8 qf[2];
-  {
-    const bf16_t* qrow = qk + (row0 + qb * ATT_Q + wave * 16 + lc) * ldq + h * 64;
+  bf16x8 qf[2], qfl[2];
+  auto load_q = [&](const bf16_t* base, bf16x8 (&dst)[2]) {  // * head_dim^-0.5 = 2^-3: exact in bf16
+    const bf16_t* qrow = base + (row0 + qb * ATT_Q + wave * 16 + lc) * ldq + h * 64;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       union { bf16x8 v; uint32_t u[4]; } raw;
@@ -1981,9 +2023,11 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
         const float hi = __uint_as_float(raw.u[j] & 0xffff0000u) * 0.125f;
         raw.u[j] = pack2(lo, hi);
       }
-      qf[ks] = raw.v;
+      dst[ks] = raw.v;
     }
-  }
+  };
+  load_q(qk, qf);
+  if constexpr (X3) load_q(qk_lo, qfl);
   const bf16_t* kbase = qk + row0 * ldq + dim + h * 64;
   const bf16_t* vbase = vt + ((size_t)(b * heads + h) * 64) * s_pad;
 
@@ -2002,21 +2046,56 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
   const int vks = sc >> 2, vc = sc & 3, vsw = (sr0 >> 1) & 7;
   const int vdo0 = sr0 * VT_LD + (((vks * 4 + 2 * (vc & 1)) ^ vsw) << 4) + (vc >> 1) * 8;
   const int vdo1 = sr0 * VT_LD + (((vks * 4 + 2 * (vc & 1) + 1) ^ vsw) << 4) + (vc >> 1) * 8;
-  uint4 kr0, vr0;
-#define A2_LOADK(kt) kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq)
-#define A2_LOADV(kt) vr0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * KV_TILE)
-#define A2_STOREK(kt) *reinterpret_cast<uint4*>(Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128) + kdo) = kr0
+  uint4 kr0, vr0, kr0l, vr0l;
+  const ptrdiff_t klo = X3 ? (qk_lo - qk) : 0, vlo = X3 ? (vt_lo - vt) : 0;  // element offsets hi -> lo arrays
+#define A2_LOADK(kt)                                                                                 \
+  do {                                                                                               \
+    kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq);                       \
+    if constexpr (X3) kr0l = *reinterpret_cast<const uint4*>(kp0 + klo + (size_t)(kt) * KV_TILE * ldq); \
+  } while (0)
+#define A2_LOADV(kt)                                                                   \
+  do {                                                                                 \
+    vr0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * KV_TILE);                       \
+    if constexpr (X3) vr0l = *reinterpret_cast<const uint4*>(vp0 + vlo + (kt) * KV_TILE); \
+  } while (0)
+#define A2_STOREK(kt)                                                                                   \
+  do {                                                                                                  \
+    *reinterpret_cast<uint4*>(Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128) + kdo) = kr0;                   \
+    if constexpr (X3) *reinterpret_cast<uint4*>(Kbl + ((kt) % ATT2_KBUF) * (KV_TILE * 128) + kdo) = kr0l; \
+  } while (0)
 #define A2_STOREV(kt)                                                                     \
   do {                                                                                    \
     char* vb_ = Vb + ((kt) % NV) * (64 * VT_LD);                                          \
     *reinterpret_cast<uint2*>(vb_ + vdo0) = make_uint2(vr0.x, vr0.y);                     \
     *reinterpret_cast<uint2*>(vb_ + vdo1) = make_uint2(vr0.z, vr0.w);                     \
+    if constexpr (X3) {                                                                   \
+      char* vl_ = Vbl + ((kt) % NV) * (64 * VT_LD);                                       \
+      *reinterpret_cast<uint2*>(vl_ + vdo0) = make_uint2(vr0l.x, vr0l.y);                 \
+      *reinterpret_cast<uint2*>(vl_ + vdo1) = make_uint2(vr0l.z, vr0l.w);                 \
+    }                                                                                     \
   } while (0)
   // S^T of tile kt: acc s[mt][r] <-> key = 16*mt + 4*g + r, q = lc
 #define A2_S(dst, kt)                                                                                              \
   do {                                                                                                             \
     const char* Ks_ = Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128);                                                   \
-    if constexpr (VAR & 1) {                                                                                       \
+    if constexpr (X3) {                                                                                            \
+      const char* Kl_ = Kbl + ((kt) % ATT2_KBUF) * (KV_TILE * 128);                                                \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+        bf16x8 kh_[4], kl_[4];                                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                         \
+          const int krow = mt * 16 + lc, ko_ = krow * 128 + (((ks * 4 + g) ^ (krow & 7)) << 4);                     \
+          kh_[mt] = *reinterpret_cast<const bf16x8*>(Ks_ + ko_);                                                   \
+          kl_[mt] = *reinterpret_cast<const bf16x8*>(Kl_ + ko_);                                                   \
+          if (ks == 0) dst[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                      \
+        }                                                                                                          \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
+          dst[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_[mt], qf[ks], dst[mt], 0, 0, 0);                    \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
+          dst[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_[mt], qfl[ks], dst[mt], 0, 0, 0);                   \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
+          dst[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_[mt], qf[ks], dst[mt], 0, 0, 0);                    \
+      }                                                                                                            \
+    } else if constexpr (VAR & 1) {                                                                                       \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                         \
           const int krow = mt * 16 + lc;                                                                           \
@@ -2162,20 +2241,29 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
     };
     softmax();
     float psum = ps2.x + ps2.y;
-    PF pf0, pf1;
+    PF pf0, pf1, pl0, pl1;
     auto pack = [&]() {
       pf0.u[0] = pack2(pv[0][0], pv[0][1]); pf0.u[1] = pack2(pv[0][2], pv[0][3]);
       pf0.u[2] = pack2(pv[1][0], pv[1][1]); pf0.u[3] = pack2(pv[1][2], pv[1][3]);
       pf1.u[0] = pack2(pv[2][0], pv[2][1]); pf1.u[1] = pack2(pv[2][2], pv[2][3]);
       pf1.u[2] = pack2(pv[3][0], pv[3][1]); pf1.u[3] = pack2(pv[3][2], pv[3][3]);
+      if constexpr (X3) {  // P = hi + lo: lo = bf16(p - float(hi)), the subtraction is exact
+        auto lo2 = [](uint32_t hb, float a, float b) {
+          return pack2(a - __uint_as_float(hb << 16), b - __uint_as_float(hb & 0xffff0000u));
+        };
+        pl0.u[0] = lo2(pf0.u[0], pv[0][0], pv[0][1]); pl0.u[1] = lo2(pf0.u[1], pv[0][2], pv[0][3]);
+        pl0.u[2] = lo2(pf0.u[2], pv[1][0], pv[1][1]); pl0.u[3] = lo2(pf0.u[3], pv[1][2], pv[1][3]);
+        pl1.u[0] = lo2(pf1.u[0], pv[2][0], pv[2][1]); pl1.u[1] = lo2(pf1.u[1], pv[2][2], pv[2][3]);
+        pl1.u[2] = lo2(pf1.u[2], pv[3][0], pv[3][1]); pl1.u[3] = lo2(pf1.u[3], pv[3][2], pv[3][3]);
+      }
     };
     pack();
     if constexpr (!LAST) {
       // scheduler shape for the block above: one S MFMA of the next tile per ~6 VALU of this tile's softmax
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < (X3 ? 24 : 8); ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, (VAR & 4) ? 5 : 6, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, X3 ? 4 : (VAR & 4) ? 5 : 6, 0);  // VALU
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -2192,7 +2280,22 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
     // ---- O^T[d][q] += V^T . P^T
     if constexpr (VAR & 64) __syncthreads();  // phase boundary: the other wave group starts its softmax phase here
     const char* Vs = Vb + (kt % NV) * (64 * VT_LD);
-    if constexpr (VAR & 2) {
+    if constexpr (X3) {
+      const char* Vl = Vbl + (kt % NV) * (64 * VT_LD);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+        const int o0_ = vr * VT_LD + ((g ^ vs_) << 4), o1_ = vr * VT_LD + (((4 + g) ^ vs_) << 4);
+        const bf16x8 vh0 = *reinterpret_cast<const bf16x8*>(Vs + o0_), vh1 = *reinterpret_cast<const bf16x8*>(Vs + o1_);
+        const bf16x8 vl0 = *reinterpret_cast<const bf16x8*>(Vl + o0_), vl1 = *reinterpret_cast<const bf16x8*>(Vl + o1_);
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl0, pf0.v, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl1, pf1.v, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh0, pl0.v, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh1, pl1.v, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh0, pf0.v, o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh1, pf1.v, o[mt], 0, 0, 0);
+      }
+    } else if constexpr (VAR & 2) {
       bf16x8 vf[8];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -2252,6 +2355,14 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
+  if constexpr (X3) {
+    float* orow = reinterpret_cast<float*>(out) + (row0 + qb * ATT_Q + wave * 16 + lc) * dim + h * 64;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      *reinterpret_cast<float4*>(orow + mt * 16 + 4 * g) =
+          make_float4(o[mt][0] * inv, o[mt][1] * inv, o[mt][2] * inv, o[mt][3] * inv);
+    return;
+  }
   bf16_t* orow = out + (row0 + qb * ATT_Q + wave * 16 + lc) * dim + h * 64;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
@@ -2314,6 +2425,14 @@ int dvt_vit_tune(int v) {
   }
   if (v == -50 || v == -51) {  // non-temporal bf16 output stores off / on
     g_vit_nt_store = v == -51;
+    return 0;
+  }
+  if (v == -520 || v == -521) {  // fp32 extractor, bf16x3 mode: exact-fp32 attention (-520) / bf16x3 attention (-521, default)
+    g_f32x3_exact_attention = v == -520;
+    return 0;
+  }
+  if (v == -522 || v == -523) {  // ... split kernels (-522) / split epilogues of the qkv and fc1 GEMMs (-523, default)
+    g_f32x3_unfused = v == -522;
     return 0;
   }
   if (v <= -510) {
@@ -2426,6 +2545,50 @@ extern "C" int dvt_vit_gemm_f32out(const void* a_in, const void* w, const float*
   return launch_gemm<EPI_F32>(a, (hipStream_t)stream);
 }
 
+// scratch of the bf16x3 attention (elements of bf16): q|k hi [m, 2 dim], q|k lo [m, 2 dim], V^T hi and lo
+// [batch + 1, heads, 64, s_pad] each; m = batch * s_pad rounded up to whole 256-row GEMM tiles (the fused qkv epilogue
+// writes those phantom rows, their V^T lands in image `batch`)
+struct X3Scratch {
+  long long m, ql, vh, vl, total;
+};
+static X3Scratch x3_scratch(int batch, int heads, int s_pad) {
+  X3Scratch r;
+  const long long dim = (long long)heads * 64;
+  r.m = ((long long)batch * s_pad + 255) / 256 * 256;
+  r.ql = r.m * 2 * dim;
+  r.vh = 2 * r.ql;
+  r.vl = r.vh + (long long)(batch + 1) * s_pad * dim;
+  r.total = r.vl + (long long)(batch + 1) * s_pad * dim;
+  return r;
+}
+// fc1 of the bf16x3 mode: out3 [m, 3 n] = split(GELU(a . w^T + b)) -- the next GEMM's A operand, no fp32 round trip
+extern "C" int dvt_vit_gemm_gelu_x3(const void* a_in, const void* w, const float* b, void* out3, int m, int n, int k,
+                                    void* stream) {
+  if (!a_in || !w || !out3) return DVT_E_BADARG;
+  GemmBArgs a{};
+  a.A = (const bf16_t*)a_in; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
+  a.bias = b; a.out = (bf16_t*)out3;
+  return launch_gemm<EPI_GELU_X3>(a, (hipStream_t)stream);
+}
+
+// qkv of the bf16x3 mode: q | k as (hi, lo) [m, 2 dim] and V^T as (hi, lo) [batch, heads, 64, s_pad] in `scratch`
+// (dvt_vit_attention_x3_scratch_bytes: the layout dvt_vit_attention_x3_presplit reads)
+extern "C" int dvt_vit_gemm_qkv_x3(const void* a_in, const void* w, const float* b, void* scratch, int m, int dim, int heads,
+                                   int s_pad, int batch, int k, void* stream) {
+  if (!a_in || !w || !scratch || batch <= 0 || dim != heads * 64) return DVT_E_BADARG;
+  const X3Scratch L = x3_scratch(batch, heads, s_pad);
+  if (m != L.m) return DVT_E_BADARG;  // whole 256-row tiles over batch * s_pad rows, exactly
+  GemmBArgs a{};
+  a.A = (const bf16_t*)a_in; a.W = (const bf16_t*)w; a.M = m; a.N = 3 * dim; a.K = k;
+  a.bias = b;
+  a.out = (bf16_t*)scratch;
+  a.out_lo = a.out + L.ql;
+  a.vt = a.out + L.vh;
+  a.vt_lo = a.out + L.vl;
+  a.dim = dim; a.heads = heads; a.s_pad = s_pad;
+  return launch_gemm<EPI_QKV_X3>(a, (hipStream_t)stream);
+}
+
 extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows,
                                  int dim, float eps, void* stream) {
   if (!x || !w || !b || !y || rows < 0 || dim <= 0 || dim % 4 || dim > 1024) return DVT_E_BADARG;
@@ -2448,7 +2611,8 @@ extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int 
 #define A2_VAR(n)                                                                                                     \
   if (g_vit_attn_mask == n) {                                                                                         \
     hipLaunchKernelGGL(attention_kernel_v2<n>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,            \
-                       (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);                                       \
+                       (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid, (const bf16_t*)nullptr,                \
+                       (const bf16_t*)nullptr);                                                                       \
     done = true;                                                                                                      \
   }
     A2_VAR(0) A2_VAR(1) A2_VAR(2) A2_VAR(4) A2_VAR(8) A2_VAR(16) A2_VAR(64) A2_VAR(3) A2_VAR(15) A2_VAR(31) A2_VAR(79)
@@ -2458,6 +2622,100 @@ extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int 
     hipLaunchKernelGGL(attention_kernel, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0,
                        (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt, (bf16_t*)out, heads,
                        s_pad, n_valid);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- bf16x3 attention for the fp32 extractor's `--fp32_matmul high` mode ---------------------------------------
+namespace {
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack2(a, b);
+  lo = pack2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+// q | k columns of the fp32 qkv rows -> (hi, lo) bf16 arrays [T, 2 dim]
+__global__ __launch_bounds__(256) void qk_split_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ hi,
+                                                       bf16_t* __restrict__ lo, long long nq, int dq2, int ld3) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+    const long long t = q / dq2;
+    const int c = (int)(q - t * dq2) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(qkv + t * ld3 + c);
+    uint2 h, l;
+    split_pair(v.x, v.y, h.x, l.x);
+    split_pair(v.z, v.w, h.y, l.y);
+    *reinterpret_cast<uint2*>(hi + t * (dq2 * 4) + c) = h;
+    *reinterpret_cast<uint2*>(lo + t * (dq2 * 4) + c) = l;
+  }
+}
+// v columns -> transposed (hi, lo) arrays vt[b][h][d][s]; one workgroup = 64 tokens of one (image, head)
+__global__ __launch_bounds__(256) void v_split_transpose_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ vth,
+                                                                bf16_t* __restrict__ vtl, int heads, int s_pad) {
+  __shared__ float tile[64 * 65];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int dim = heads * 64, ld3 = 3 * dim;
+  const float* src = qkv + ((size_t)b * s_pad + t0) * ld3 + 2 * dim + h * 64;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int f = tid + 256 * it, i = f >> 4, dq = f & 15;
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)i * ld3 + dq * 4);
+    float* d = tile + i * 65 + dq * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int d = tid >> 2, part = tid & 3;
+  uint32_t hw[8], lw[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+    split_pair(tile[(part * 16 + 2 * n) * 65 + d], tile[(part * 16 + 2 * n + 1) * 65 + d], hw[n], lw[n]);
+  const size_t o = ((size_t)(b * heads + h) * 64 + d) * s_pad + t0 + part * 16;
+  *reinterpret_cast<uint4*>(vth + o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  *reinterpret_cast<uint4*>(vth + o + 8) = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+  *reinterpret_cast<uint4*>(vtl + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+  *reinterpret_cast<uint4*>(vtl + o + 8) = make_uint4(lw[4], lw[5], lw[6], lw[7]);
+}
+}  // namespace
+
+extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
+                                             void* stream);
+extern "C" int64_t dvt_vit_attention_x3_scratch_bytes(int batch, int heads, int s_pad) {
+  if (batch <= 0 || heads <= 0 || s_pad <= 0) return -1;
+  return x3_scratch(batch, heads, s_pad).total * 2;
+}
+
+extern "C" int dvt_vit_attention_x3(const float* qkv, float* out, void* scratch, int batch, int heads, int s_pad,
+                                    int n_valid, void* stream) {
+  if (!qkv || !out || !scratch || batch <= 0 || heads <= 0 || s_pad % ATT_Q || n_valid <= 0 || n_valid > s_pad)
+    return DVT_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int dim = heads * 64;
+  const long long T = (long long)batch * s_pad;
+  const X3Scratch L = x3_scratch(batch, heads, s_pad);
+  bf16_t* qh = (bf16_t*)scratch;
+  bf16_t* ql = qh + L.ql;
+  bf16_t* vh = qh + L.vh;
+  bf16_t* vl = qh + L.vl;
+  const long long nq = T * (2 * dim / 4);
+  hipLaunchKernelGGL(qk_split_kernel, dim3((unsigned)(nq / 256 + 1 < 4096 ? nq / 256 + 1 : 4096)), dim3(256), 0, s, qkv, qh,
+                     ql, nq, 2 * dim / 4, 3 * dim);
+  DVT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(v_split_transpose_kernel, dim3(s_pad / 64, heads, batch), dim3(256), 0, s, qkv, vh, vl, heads, s_pad);
+  DVT_CHECK_LAUNCH();
+  return dvt_vit_attention_x3_presplit(scratch, out, batch, heads, s_pad, n_valid, stream);
+}
+
+extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
+                                             void* stream) {
+  if (!out || !scratch || batch <= 0 || heads <= 0 || s_pad % ATT_Q || n_valid <= 0 || n_valid > s_pad)
+    return DVT_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const X3Scratch L = x3_scratch(batch, heads, s_pad);
+  const bf16_t* qh = (const bf16_t*)scratch;
+  const bf16_t* ql = qh + L.ql;
+  const bf16_t* vh = qh + L.vh;
+  const bf16_t* vl = qh + L.vl;
+  DvtProbeScope probe(DVT_PROBE_VIT_ATTN, s, 3.0 * 4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
+  hipLaunchKernelGGL((attention_kernel_v2<12, true>), dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0, s,
+                     (const bf16_t*)qh, (const bf16_t*)vh, (bf16_t*)out, heads, s_pad, n_valid, (const bf16_t*)ql,
+                     (const bf16_t*)vl);
   DVT_CHECK_LAUNCH();
   return 0;
 }

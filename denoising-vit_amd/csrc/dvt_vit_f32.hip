@@ -25,6 +25,14 @@ int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y,
 extern "C" int dvt_vit_gemm_f32out(const void* a, const void* w, const float* b, float* y, int m, int n, int k, void* stream);
 extern "C" int dvt_vit_gemm_residual(const void* a, const void* w, const float* b, const float* gamma, float* x, int m,
                                      int n, int k, void* stream);
+extern "C" int dvt_vit_attention_x3(const float* qkv, float* out, void* scratch, int batch, int heads, int s_pad,
+                                    int n_valid, void* stream);
+extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
+                                             void* stream);
+extern "C" int64_t dvt_vit_attention_x3_scratch_bytes(int batch, int heads, int s_pad);
+extern "C" int dvt_vit_gemm_gelu_x3(const void* a, const void* w, const float* b, void* out3, int m, int n, int k, void* stream);
+extern "C" int dvt_vit_gemm_qkv_x3(const void* a, const void* w, const float* b, void* scratch, int m, int dim, int heads,
+                                   int s_pad, int batch, int k, void* stream);
 
 namespace {
 
@@ -337,10 +345,13 @@ extern "C" int64_t dvt_vit_workspace_bytes_f32(const DvtVitConfig* c, int batch)
   return carve_f32(c, batch, nullptr, nullptr);
 }
 
+int g_f32x3_exact_attention = 0;  // dvt_tune_set(1, -520 / -521): exact-fp32 attention inside the bf16x3 forward on / off
+int g_f32x3_unfused = 0;          // dvt_tune_set(1, -522 / -523): split kernels instead of the split epilogues on / off
+
 namespace {
 struct VitWorkX3 {
   float *x, *qkv, *ao, *hid, *col;
-  bf16_t* a3;
+  bf16_t *a3, *h3, *sc;  // split rows of the current GEMM input; split GELU(hidden) [T, 3 mlp]; attention scratch
 };
 inline int64_t rows256(const DvtVitConfig* c, int batch) { return ((int64_t)batch * c->s_pad + 255) / 256 * 256; }
 int64_t carve_x3(const DvtVitConfig* c, int batch, char* base, VitWorkX3* w) {
@@ -359,6 +370,8 @@ int64_t carve_x3(const DvtVitConfig* c, int batch, char* base, VitWorkX3* w) {
   t.col = (float*)take(T * c->k_patch * 4);
   const int64_t kmax = c->mlp_dim > c->k_patch ? c->mlp_dim : c->k_patch;
   t.a3 = (bf16_t*)take(T * 3 * kmax * 2);
+  t.h3 = (bf16_t*)take(T * 3 * c->mlp_dim * 2);
+  t.sc = (bf16_t*)take(dvt_vit_attention_x3_scratch_bytes(batch, c->heads, c->s_pad));
   if (w) *w = t;
   return o;
 }
@@ -423,16 +436,29 @@ extern "C" int dvt_vit_forward_f32x3(const DvtVitConfig* c, const DvtVitWeights*
     hipLaunchKernelGGL((layernorm_f32_kernel<false, true>), dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm1_w,
                        bw.norm1_b, (float*)k.a3, T, D, c->ln_eps, 0, 0, 0);
     DVT_CHECK_LAUNCH();
-    DVT_TRY(dvt_vit_gemm_f32out(k.a3, bw.qkv_w, bw.qkv_b, k.qkv, Tg, 3 * D, 3 * D, stream));
-    DVT_TRY(dvt_vit_attention_f32(k.qkv, k.ao, batch, c->heads, c->s_pad, c->n_tokens, s));
+    // dvt_tune_set(1, -520): exact-fp32 attention; -522: unfused epilogues (fp32 qkv / hidden + split kernels), for A/B
+    if (g_f32x3_exact_attention) {
+      DVT_TRY(dvt_vit_gemm_f32out(k.a3, bw.qkv_w, bw.qkv_b, k.qkv, Tg, 3 * D, 3 * D, stream));
+      DVT_TRY(dvt_vit_attention_f32(k.qkv, k.ao, batch, c->heads, c->s_pad, c->n_tokens, s));
+    } else if (g_f32x3_unfused) {
+      DVT_TRY(dvt_vit_gemm_f32out(k.a3, bw.qkv_w, bw.qkv_b, k.qkv, Tg, 3 * D, 3 * D, stream));
+      DVT_TRY(dvt_vit_attention_x3(k.qkv, k.ao, k.sc, batch, c->heads, c->s_pad, c->n_tokens, stream));
+    } else {  // q | k | V^T leave the qkv GEMM already split
+      DVT_TRY(dvt_vit_gemm_qkv_x3(k.a3, bw.qkv_w, bw.qkv_b, k.sc, Tg, D, c->heads, c->s_pad, batch, 3 * D, stream));
+      DVT_TRY(dvt_vit_attention_x3_presplit(k.sc, k.ao, batch, c->heads, c->s_pad, c->n_tokens, stream));
+    }
     DVT_TRY(dvt_vit_split3(k.ao, k.a3, T, D, 0, 0, stream));
     DVT_TRY(dvt_vit_gemm_residual(k.a3, bw.proj_w, bw.proj_b, bw.ls1, k.x, Tg, D, 3 * D, stream));
     hipLaunchKernelGGL((layernorm_f32_kernel<false, true>), dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm2_w,
                        bw.norm2_b, (float*)k.a3, T, D, c->ln_eps, 0, 0, 0);
     DVT_CHECK_LAUNCH();
-    DVT_TRY(dvt_vit_gemm_f32out(k.a3, bw.fc1_w, bw.fc1_b, k.hid, Tg, c->mlp_dim, 3 * D, stream));
-    DVT_TRY(dvt_vit_split3(k.hid, k.a3, T, c->mlp_dim, 0, 1, stream));
-    DVT_TRY(dvt_vit_gemm_residual(k.a3, bw.fc2_w, bw.fc2_b, bw.ls2, k.x, Tg, D, 3 * c->mlp_dim, stream));
+    if (g_f32x3_unfused) {
+      DVT_TRY(dvt_vit_gemm_f32out(k.a3, bw.fc1_w, bw.fc1_b, k.hid, Tg, c->mlp_dim, 3 * D, stream));
+      DVT_TRY(dvt_vit_split3(k.hid, k.h3, T, c->mlp_dim, 0, 1, stream));
+    } else {  // GELU + split in the fc1 epilogue
+      DVT_TRY(dvt_vit_gemm_gelu_x3(k.a3, bw.fc1_w, bw.fc1_b, k.h3, Tg, c->mlp_dim, 3 * D, stream));
+    }
+    DVT_TRY(dvt_vit_gemm_residual(k.h3, bw.fc2_w, bw.fc2_b, bw.ls2, k.x, Tg, D, 3 * c->mlp_dim, stream));
   }
 #undef DVT_TRY
   const int out_rows = batch * (c->n_tokens - c->n_prefix);

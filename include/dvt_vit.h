@@ -112,6 +112,24 @@ int dvt_vit_linear_f32x3(const float* x, const void* w3, const float* b, float* 
                          void* stream);
 int dvt_vit_gemm_f32out(const void* a_bf16, const void* w_bf16, const float* b, float* y, int m, int n, int k,
                         void* stream);
+/* Attention of the same mode: qkv fp32 [batch*s_pad, 3*heads*64] -> out fp32 [batch*s_pad, heads*64].  q, k, v are split
+ * into (hi, lo) bf16 pairs (v transposed per head) in `scratch` (dvt_vit_attention_x3_scratch_bytes), then
+ * S = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi and O += V_lo P_hi + V_hi P_lo + V_hi P_hi on the bf16 matrix pipe with the
+ * probabilities split in registers; softmax statistics and accumulation fp32.  dvt_vit_forward_f32x3 uses it unless
+ * dvt_tune_set(1, -520) selects the exact-fp32 attention kernel (dvt_vit_attention_f32).                                */
+int64_t dvt_vit_attention_x3_scratch_bytes(int batch, int heads, int s_pad);
+int dvt_vit_attention_x3(const float* qkv, float* out, void* scratch, int batch, int heads, int s_pad, int n_valid,
+                         void* stream);
+/* The split-output epilogues dvt_vit_forward_f32x3 uses by default (dvt_tune_set(1, -522): fp32 outputs + split kernels):
+ *   dvt_vit_gemm_gelu_x3: out3 bf16 [m, 3n] = [hi | hi | lo] of GELU(a . w^T + b), the next linear layer's A operand;
+ *   dvt_vit_gemm_qkv_x3:  q | k (hi, lo) and V^T (hi, lo) written straight into the attention scratch; m must be
+ *     batch * s_pad rounded up to 256;  dvt_vit_attention_x3_presplit then runs the attention kernel on that scratch. */
+int dvt_vit_gemm_gelu_x3(const void* a_bf16, const void* w_bf16, const float* b, void* out3, int m, int n, int k,
+                         void* stream);
+int dvt_vit_gemm_qkv_x3(const void* a_bf16, const void* w_bf16, const float* b, void* scratch, int m, int dim, int heads,
+                        int s_pad, int batch, int k, void* stream);
+int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
+                                  void* stream);
 int64_t dvt_vit_workspace_bytes_f32x3(const DvtVitConfig* h_cfg, int batch);
 int dvt_vit_forward_f32x3(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img, float* feat,
                           int batch, int n_blocks, void* workspace, void* stream);

@@ -331,9 +331,45 @@ def test_linear_f32x3_vs_fp64(L, m, n, k):
     assert float(row.max()) < 5e-5  # per row: the wide per-row scales do not leak into each other
 
 
+@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370), (1, 1, 128, 1),
+                                                        (3, 12, 1408, 1370)])
+@pytest.mark.parametrize("spike", [0.0, 1.5])
+def test_attention_f32x3_vs_fp64(L, batch, heads, s_pad, n_valid, spike):
+    """bf16x3 attention of the `--fp32_matmul high` extractor: fp32 q, k, v with a wide range, fp64 reference, and (spike)
+    one key row aligned with a few queries so that the running max jumps late (the rescale branch).  Must sit within 1e-4
+    of fp64 -- the exact-fp32 kernel is printed beside it."""
+    torch.manual_seed(s_pad + heads)
+    dim = heads * 64
+    q = torch.randn(batch, s_pad, heads, 64) * 1.5
+    k = torch.randn(batch, s_pad, heads, 64) + torch.linspace(-1, 1, 64)
+    v = torch.randn(batch, s_pad, heads, 64) * torch.linspace(0.5, 1.5, 64) * torch.exp(torch.randn(batch, s_pad, 1, 1))
+    if spike and n_valid > 70:
+        key = min(n_valid - 1, 64 * 3 + 17)
+        k[:, key] = 0.0
+        for qi in (3, 50, n_valid - 1):
+            k[:, key] += q[:, qi] * spike / 2.25
+    att = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double() * 0.125, k.double()[:, :n_valid]), -1)
+    want = torch.einsum("bhqk,bkhd->bqhd", att, v.double()[:, :n_valid]).reshape(batch, s_pad, dim)
+    qkv = torch.cat([q.reshape(batch * s_pad, dim), k.reshape(batch * s_pad, dim), v.reshape(batch * s_pad, dim)],
+                    1).contiguous().to(DEV)
+    out = torch.empty((batch * s_pad, dim), device=DEV, dtype=torch.float32)
+    exact = torch.empty_like(out)
+    scratch = torch.zeros(int(L.dvt_vit_attention_x3_scratch_bytes(batch, heads, s_pad)), device=DEV, dtype=torch.uint8)
+    assert L.dvt_vit_attention_x3(qkv.data_ptr(), out.data_ptr(), scratch.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
+    assert L.dvt_vit_attention_f32(qkv.data_ptr(), exact.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
+    torch.cuda.synchronize()
+    got, ex = out.double().reshape(batch, s_pad, dim).cpu(), exact.double().reshape(batch, s_pad, dim).cpu()
+    e, e_ex = rel(got[:, :n_valid], want[:, :n_valid]), rel(ex[:, :n_valid], want[:, :n_valid])
+    rows = ((got - want)[:, :n_valid].norm(dim=-1) / want[:, :n_valid].norm(dim=-1)).max()
+    print(f"bf16x3 attention b{batch} h{heads} n{n_valid} spike {spike}: rel-L2 {e:.2e} (exact-fp32 kernel {e_ex:.2e}), worst row {rows:.2e}")
+    assert e < 5e-5 and float(rows) < 2e-4
+    assert bool(torch.isfinite(out[: batch * s_pad].reshape(batch, s_pad, dim)[:, :n_valid]).all())
+
+
+@pytest.mark.parametrize("knob", [None, -520, -522])  # default | exact-fp32 attention | split kernels instead of split epilogues
 @pytest.mark.parametrize("dim,depth,img,stride,n_reg", [(128, 2, 56, 14, 0), (256, 2, 98, 7, 4), (768, 2, 518, 14, 0),
                                                         (768, 12, 518, 14, 0)])
-def test_vit_forward_f32x3_vs_oracle(L, dim, depth, img, stride, n_reg):
+def test_vit_forward_f32x3_vs_oracle(L, dim, depth, img, stride, n_reg, knob):
     """HipViT(dtype="float32", matmul="high"): linear layers through bf16x3, everything else fp32.  Held to the SAME
     fp32-oracle bars as the exact-fp32 extractor except for the rel-L2 bound (1e-4 instead of 2e-5), with an odd batch
     (3 views: 1.5 GEMM tiles of phantom rows at s_pad 1408) and the result of the exact path printed beside it."""
@@ -343,14 +379,20 @@ def test_vit_forward_f32x3_vs_oracle(L, dim, depth, img, stride, n_reg):
                            n_reg=n_reg)
     x = torch.randn(3, 3, img, img, generator=torch.Generator().manual_seed(3))
     want = ovit.forward_features(sd, x, 14, stride)
-    got = HipViT(sd, 14, stride, (img, img), DEV, dtype="float32", matmul="high").forward_features(x.to(DEV)).cpu()
+    try:
+        if knob is not None:
+            assert L.dvt_tune_set(1, knob) == 0
+        got = HipViT(sd, 14, stride, (img, img), DEV, dtype="float32", matmul="high").forward_features(x.to(DEV)).cpu()
+    finally:
+        L.dvt_tune_set(1, -521)
+        L.dvt_tune_set(1, -523)
     exact = HipViT(sd, 14, stride, (img, img), DEV, dtype="float32").forward_features(x.to(DEV)).cpu()
     assert got.shape == want.shape and bool(torch.isfinite(got).all())
     err, err_exact = float((got - want).norm() / want.norm()), float((exact - want).norm() / want.norm())
     cos = F.cosine_similarity(got.reshape(-1, dim), want.reshape(-1, dim), dim=-1)
     bf = HipViT(sd, 14, stride, (img, img), DEV).forward_features(x.to(DEV)).cpu()
     err_bf = float((bf - want).norm() / want.norm())
-    print(f"fp32 ViT, bf16x3 linears, dim={dim} depth={depth} stride={stride} reg={n_reg}: rel-L2 {err:.2e} "
+    print(f"fp32 ViT, bf16x3 (knob {knob}), dim={dim} depth={depth} stride={stride} reg={n_reg}: rel-L2 {err:.2e} "
           f"(exact fp32 {err_exact:.2e}, bf16 extractor {err_bf:.2e}), cos min {cos.min():.8f}")
     assert err < 1e-4 and cos.min() > 0.999999
     assert err < 0.05 * err_bf
