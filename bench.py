@@ -298,7 +298,7 @@ def main():
         t = st.timings[-1]
         full_fp32 = {"images_per_s": n3 / el3, "images_timed": n3, "flow": f"pipelined (depth {a.pipeline_depth})",
                      "t_extract_s_serial": t["t_extract"], "t_fit_s_serial": t["t_fit"]}
-        # ... and the same with the extractor's linear layers as bf16x3 GEMMs (`--fp32_matmul high`: torch's float32 matmul
+        # ... and the same with the extractor's matrix products as bf16x3 (`--fp32_matmul high`: torch's float32 matmul
         # precision "high", an opt-in the reference never sets -- reported beside value_fp32, never in its place)
         st.extract_matmul = "high"
         st.run(jobs(1))
@@ -307,9 +307,10 @@ def main():
         t = st.timings[-1]
         full_fp32["matmul_high"] = {"images_per_s": n4 / el4, "images_timed": n4, "t_extract_s_serial": t["t_extract"],
                                     "t_fit_s_serial": t["t_fit"],
-                                    "what": "--dtype float32 --fp32_matmul high: linear layers of the extractor as one bf16 "
-                                            "GEMM over split operands (bf16x3, ~1e-5 relative per product); LayerNorm, "
-                                            "attention, GELU, residual stream and the fit fp32"}
+                                    "what": "--dtype float32 --fp32_matmul high: every matrix product of the extractor (linear "
+                                            "layers, q.k^T, p.v) on the bf16 pipe over split operands (bf16x3, ~1e-5 relative per "
+                                            "product, fp32 accumulation); LayerNorm, softmax, GELU, residual stream and the whole "
+                                            "fit fp32"}
         st.extract_matmul = "highest"
         st.extract_dtype = "bfloat16"
         set_fit_dtype(a.fit_dtype)

@@ -44,9 +44,10 @@ def get_args(argv=None):
                         "seconds per image; bfloat16: the reference's autocast mode, bf16 MFMA, ~10x faster")
     p.add_argument("--fp32_matmul", type=str, default="highest", choices=["highest", "high"],
                    help="with --dtype float32 only; torch.set_float32_matmul_precision's vocabulary.  highest (default, "
-                        "what the reference runs with): exact-fp32 matrix cores.  high: the extractor's linear layers as "
-                        "bf16x3 GEMMs (~1e-5 relative per product, ~3x faster extractor); LayerNorm, attention, GELU, the "
-                        "residual stream and the whole fit stay fp32")
+                        "what the reference runs with): exact-fp32 matrix cores.  high: the extractor's matrix products "
+                        "(linear layers, q.k^T, p.v) as bf16x3 on the bf16 pipe (~1e-5 relative per product, fp32 "
+                        "accumulation, 3x faster extractor); LayerNorm, softmax, GELU, the residual stream and the whole fit "
+                        "stay fp32")
     p.add_argument("--data_root", type=str, default=None)
     p.add_argument("--save_root", type=str, default=None)
     p.add_argument("--start_idx", type=int, default=0)

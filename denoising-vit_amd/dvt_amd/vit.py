@@ -163,8 +163,9 @@ class HipViT:
         """dtype "bfloat16": bf16 operands / fp32 accumulate (the reference's `--dtype bfloat16` autocast mode);
         "float32": fp32 operands everywhere (its default, autocast off) -- 16x less matrix throughput.
         `matmul` (float32 only) is torch.set_float32_matmul_precision's vocabulary: "highest" (default, what the reference
-        runs with) = exact-fp32 matrix cores; "high" = every linear layer as one bf16 GEMM over split operands
-        ("bfloat16_3x", ~1e-5 relative per product; include/dvt_vit.h) -- an opt-in, never implied by `--dtype float32`."""
+        runs with) = exact-fp32 matrix cores; "high" = every matrix product (linear layers, q.k^T, p.v) on the bf16 pipe over
+        split operands ("bfloat16_3x", ~1e-5 relative per product; include/dvt_vit.h) -- an opt-in, never implied by
+        `--dtype float32`."""
         if dtype not in ("bfloat16", "float32"):
             raise _lib.DvtError(f"ViT dtype must be bfloat16 or float32, not {dtype!r}")
         if matmul not in ("highest", "high") or (matmul == "high" and dtype != "float32"):

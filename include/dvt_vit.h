@@ -100,8 +100,8 @@ int dvt_vit_forward_f32(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, con
  * dvt_vit_forward_f32 unless the caller asks for this.  Every fp32 operand is split into two bf16 (x = hi + lo, 2^-17
  * relative), and ONE bf16 GEMM over the K-concatenated operands [hi | hi | lo] . [hi | lo | hi]^T accumulates
  * a_hi w_hi + a_hi w_lo + a_lo w_hi in fp32: ~1e-5 relative per product instead of 6e-8, at 3 x the bf16 flops on the
- * 2.5 PF/s pipe instead of the 157 TF/s fp32 one.  LayerNorm, attention, GELU (exact erf) and the residual stream stay
- * fp32 exactly as in dvt_vit_forward_f32.
+ * 2.5 PF/s pipe instead of the 157 TF/s fp32 one.  The attention products go the same way (dvt_vit_attention_x3).
+ * LayerNorm, softmax, GELU and the residual stream stay fp32 as in dvt_vit_forward_f32.
  *   dvt_vit_split3: x fp32 [rows, k] -> out3 bf16 [rows, 3k]; weights = 1: [hi | lo | hi] (nn.Linear weights, once at
  *     load time), else [hi | hi | lo] (activations; gelu = 1 applies nn.GELU() first).
  *   dvt_vit_linear_f32x3: y = x . W^T + b with x, y fp32; scratch3 = bf16 [m, 3k]; m % 128 == n % 128 == k % 64 == 0.
