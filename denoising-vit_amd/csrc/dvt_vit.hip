@@ -966,8 +966,8 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
 
-// 224 VGPRs, not the 256 that two waves per SIMD would allow: 2 x 224 leaves 64 registers per SIMD, room
-// for one wave of the fit's streaming kernels (Adam: 56) beside the two GEMM waves.  With 228-254 registers
+// 226-232 VGPRs (hipcc 7.2, per epilogue), not the 256 that two waves per SIMD would allow: 2 x 232 leaves 48
+// registers per SIMD, room for one wave of the fit's leanest streaming kernels beside the two GEMM waves; at 254
 // nothing else fitted and the HBM-bound fit could only time-slice whole CUs with the MFMA-bound extractor.
 template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
