@@ -10,7 +10,10 @@ N>1: one rank per GPU, images are independent units -> weak scaling, no collecti
 
 `value` is the reference's `--dtype bfloat16` mode end to end (bf16 ViT, bf16-operand fit MLP);
 `value_fp32_fit` repeats the timed region with fp32-operand fit GEMMs (the reference's default
-precision for the fit; the extractor of this line stays bf16).  `parity` is measured in the same
+precision for the fit; the extractor of this line stays bf16); `value_fp32` is the reference's DEFAULT precision end to
+end (`--dtype float32`: exact-fp32 matrix cores in extractor and fit) and `value_fp32_matmul_high` the same with the opt-in
+`--fp32_matmul high` (torch's float32 matmul precision "high": the extractor's matrix products as bf16x3, ~1e-5 relative,
+fp32 accumulation), three pipelined images each inside the same timed bracket.  `parity` is measured in the same
 process: the HIP chain against the CPU oracle chain on the sample the CPU baseline is timed on.
 
     python bench.py --gpus 1 --steps 3 --warmup 1

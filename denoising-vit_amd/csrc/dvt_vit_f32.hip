@@ -246,8 +246,11 @@ constexpr int FA_Q = 128, FA_K = 32, FA_LD = 65;  // odd pitch: the 32 rows of a
 
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int heads, int s_pad, int n_valid) {
-  __shared__ float Ks[FA_K * FA_LD];
-  __shared__ float Vs[FA_K * FA_LD];
+  // two K / V tile buffers: tile kt+1 is fetched into registers before tile kt is multiplied and parked in the other
+  // buffer afterwards -- one barrier per tile, the global latency hides behind the 96 MFMAs (round 3; the first version
+  // staged and multiplied in sequence with two barriers per tile: 4.42 ms per 64 views)
+  __shared__ float Ks[2][FA_K * FA_LD];
+  __shared__ float Vs[2][FA_K * FA_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h2 = lane >> 5;
   const int nqb = s_pad / FA_Q;
@@ -256,12 +259,13 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   const int dim = heads * 64, ld = 3 * dim;
   const size_t row0 = (size_t)b * s_pad;
   const int qrow = qb * FA_Q + wave * 32 + j;
-  // Q fragment values of this lane: Q[q][d = 2 s + h2], scaled by head_dim^-0.5
+  const float LOG2E = 1.4426950408889634f;
+  // Q fragment values of this lane: Q[q][d = 2 s + h2], scaled by head_dim^-0.5 and log2(e) (softmax in base 2)
   float qf[32];
   {
     const float* qp = qkv + (row0 + qrow) * ld + hd * 64 + h2;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) qf[s] = qp[2 * s] * 0.125f;
+    for (int s = 0; s < 32; ++s) qf[s] = qp[2 * s] * (0.125f * LOG2E);
   }
   const float* kbase = qkv + row0 * ld + dim + hd * 64;
   const float* vbase = qkv + row0 * ld + 2 * dim + hd * 64;
@@ -273,29 +277,42 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   }
   float m_run = -1e30f, l_run = 0.f;
   const int ntiles = (n_valid + FA_K - 1) / FA_K;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();  // everyone is done with the previous tile
-    {  // stage K / V tile: 32 keys x 64 d each, 256 threads x 2 float4 per operand
+  // staging: 32 keys x 64 d per operand = 512 float4, two per thread
+  const int key0 = tid >> 4, dq0 = tid & 15;  // second float4: key0 + 16
+  float4 kr[2], vr[2];
+  auto fetch = [&](int kt) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int f = tid + 256 * it, key = f >> 4, dq = f & 15;
-        const size_t g = (size_t)(kt * FA_K + key) * ld + dq * 4;
-        const float4 kv = *reinterpret_cast<const float4*>(kbase + g);
-        const float4 vv = *reinterpret_cast<const float4*>(vbase + g);
-        float* kd = Ks + key * FA_LD + dq * 4;
-        float* vd = Vs + key * FA_LD + dq * 4;
-        kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-        vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
-      }
+    for (int it = 0; it < 2; ++it) {
+      const size_t g = (size_t)(kt * FA_K + key0 + 16 * it) * ld + dq0 * 4;
+      kr[it] = *reinterpret_cast<const float4*>(kbase + g);
+      vr[it] = *reinterpret_cast<const float4*>(vbase + g);
     }
-    __syncthreads();
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float* kd = Ks[buf] + (key0 + 16 * it) * FA_LD + dq0 * 4;
+      float* vd = Vs[buf] + (key0 + 16 * it) * FA_LD + dq0 * 4;
+      kd[0] = kr[it].x; kd[1] = kr[it].y; kd[2] = kr[it].z; kd[3] = kr[it].w;
+      vd[0] = vr[it].x; vd[1] = vr[it].y; vd[2] = vr[it].z; vd[3] = vr[it].w;
+    }
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) fetch(kt + 1);
+    const float* K = Ks[cur];
+    const float* V = Vs[cur];
     floatx16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 32; ++t)  // d = 2 t + h2
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[j * FA_LD + 2 * t + h2], qf[t], s, 0, 0, 0);
-    // s[r] = S^T[key = kappa(r) + 4 h2][query j]
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(K[j * FA_LD + 2 * t + h2], qf[t], s, 0, 0, 0);
+    // s[r] = log2(e) * S^T[key = kappa(r) + 4 h2][query j]
     float tmax = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -305,36 +322,40 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // v_exp_f32: 1 ulp
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = expf(s[r] - m_new);
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
       psum += s[r];
     }
     l_run = l_run * alpha + psum;
-    m_run = m_new;
+    if (!__all(m_new == m_run)) {  // wave-uniform: the running max rarely moves after the first tiles (alpha == 1 exactly)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] *= alpha;
-      o1[r] *= alpha;
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
     }
+    m_run = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // contract keys kappa(r) + 4 h2: A = V[key][d = j (+32)], B = P register r
       const int key = (r & 3) + 8 * (r >> 2) + 4 * h2;
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * FA_LD + j], s[r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * FA_LD + 32 + j], s[r], o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(V[key * FA_LD + j], s[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(V[key * FA_LD + 32 + j], s[r], o1, 0, 0, 0);
     }
+    if (more) park(cur ^ 1);  // that buffer was last read in iteration kt - 1, a barrier ago
+    __syncthreads();
   }
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
   // o0[r] = O^T[d = kappa(r) + 4 h2][query j], o1: d + 32
   float* op = out + (row0 + qrow) * dim + hd * 64;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int d = (r & 3) + 8 * (r >> 2) + 4 * h2;
-    op[d] = o0[r] * inv;
-    op[32 + d] = o1[r] * inv;
+  for (int r = 0; r < 16; r += 4) {  // kappa(r .. r+3) are 4 consecutive d: one float4 per group
+    const int d = 8 * (r >> 2) + 4 * h2;
+    *reinterpret_cast<float4*>(op + d) = make_float4(o0[r] * inv, o0[r + 1] * inv, o0[r + 2] * inv, o0[r + 3] * inv);
+    *reinterpret_cast<float4*>(op + 32 + d) = make_float4(o1[r] * inv, o1[r + 1] * inv, o1[r + 2] * inv, o1[r + 3] * inv);
   }
 }
 
