@@ -327,6 +327,11 @@ def test_linear_f32x3_vs_fp64(L, m, n, k):
     err_f32 = float(((x @ w.T + b).double() - want).norm() / want.norm())
     print(f"bf16x3 linear {m}x{n}x{k}: rel-L2 vs fp64 {err:.2e} (torch fp32 on the CPU {err_f32:.2e}, plain bf16 operands {err_bf:.2e})")
     assert err < 2e-5 and err < 0.01 * err_bf
+    # ... and against the CPU restatement of the SAME arithmetic (oracle/bf16x3.py): only the accumulation order differs
+    from oracle import bf16x3
+    ref3 = bf16x3.linear_x3(x, w, b).double()
+    assert torch.equal(x3.cpu(), bf16x3.split3_activation(x)) and torch.equal(w3.cpu(), bf16x3.split3_weight(w))
+    assert float((got - ref3).norm() / ref3.norm()) < 2e-6
     row = (got - want).norm(dim=1) / want.norm(dim=1)
     assert float(row.max()) < 5e-5  # per row: the wide per-row scales do not leak into each other
 
@@ -362,6 +367,11 @@ def test_attention_f32x3_vs_fp64(L, batch, heads, s_pad, n_valid, spike):
     e, e_ex = rel(got[:, :n_valid], want[:, :n_valid]), rel(ex[:, :n_valid], want[:, :n_valid])
     rows = ((got - want)[:, :n_valid].norm(dim=-1) / want[:, :n_valid].norm(dim=-1)).max()
     print(f"bf16x3 attention b{batch} h{heads} n{n_valid} spike {spike}: rel-L2 {e:.2e} (exact-fp32 kernel {e_ex:.2e}), worst row {rows:.2e}")
+    # the CPU restatement of the same three-term arithmetic (one head): agreement an order tighter than either is to fp64
+    from oracle import bf16x3
+    ref3 = bf16x3.attention_x3(q[0, :n_valid, 0], k[0, :n_valid, 0], v[0, :n_valid, 0], 0.125).double()
+    e3 = float((got[0, :n_valid, :64] - ref3).abs().max() / ref3.abs().max())
+    assert e3 < 5e-6, e3
     assert e < 5e-5 and float(rows) < 2e-4
     assert bool(torch.isfinite(out[: batch * s_pad].reshape(batch, s_pad, dim)[:, :n_valid]).all())
 
