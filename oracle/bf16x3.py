@@ -43,7 +43,8 @@ def attention_x3(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float
     qh, ql = split(q * scale)   # scale = 2^-3 for head_dim 64: exact
     kh, kl = split(k)
     s = qh.float() @ kl.float().T + ql.float() @ kh.float().T + qh.float() @ kh.float().T
-    p = torch.softmax(s, -1)
-    ph, pl = split(p)
+    p = torch.exp(s - s.max(-1, keepdim=True).values)  # unnormalised, as the kernel holds it (its running max may lag the
+    ph, pl = split(p)                                   # true one by up to 8, which moves the split's rounding, not its size)
     vh, vl = split(v)
-    return ph.float() @ vl.float() + pl.float() @ vh.float() + ph.float() @ vh.float()
+    o = ph.float() @ vl.float() + pl.float() @ vh.float() + ph.float() @ vh.float()
+    return o / p.sum(-1, keepdim=True)
