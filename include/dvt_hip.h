@@ -268,7 +268,10 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation;
  *         -100 - b: b M panels per block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output
  *         stores off / on; -501 / -502: attention kernel of the bf16 extractor, round-2 loop / software-pipelined loop
- *         with deferred running max [default]; developer instrumentation of schedule 5: -300 - mask ablations [timing
+ *         with deferred running max [default]; -510 - mask: schedule mask of that kernel (default 15; csrc/dvt_vit.hip,
+ *         attention_kernel_v2: every mask computes the same function); -520 / -521 and -522 / -523: inside
+ *         dvt_vit_forward_f32x3, exact-fp32 attention on / off [off] and split kernels instead of split epilogues
+ *         on / off [off]; developer instrumentation of schedule 5: -300 - mask ablations [timing
  *         only, EPI_BIAS entry point, results wrong by construction], -400 - n staggered workgroup start).  No other
  *         value changes the result beyond the summation order of the folded-LayerNorm row statistics (fp32, ~1e-7
  *         relative) and, between the two attention kernels, the bf16 rounding of P (different running max);
