@@ -101,3 +101,22 @@ def test_wrapper_loads_a_timm_layout_checkpoint(tmp_path):
     # the reference's list, entry for entry (dvt/models/vit_wrapper.py:15-56)
     assert len(MODEL_LIST) == 20 and "vit_base_patch16_clip_224.openai" in MODEL_LIST
     assert not any(m.startswith("samvit") for m in MODEL_LIST)
+
+
+def test_stage1_flag_table_keeps_the_reference_defaults():
+    """The reference's argparse table (main_img_denoising.py:152-208) with its defaults, plus this build's
+    extras, whose defaults must not change what the reference's flags mean: --fp32_matmul highest (exact fp32),
+    --fit_batch 0 (auto)."""
+    from dvt_amd import stage1
+    a = stage1.get_args([])
+    ref = {"model": "vit_base_patch14_dinov2.lvd142m", "stride_size": 14, "layer_depth_ratio": 1.0, "dtype": "float32",
+           "start_idx": 0, "num_imgs": 100, "num_views": 768, "num_iters": 25000, "warmup_iters": 2500, "n_levels": 16,
+           "freeze_shared_artifacts_after": 0.5, "lr": 0.01, "min_lr": 0.001, "weight_decay": 1e-5, "pixel_bsz": 2048}
+    for k, v in ref.items():
+        assert getattr(a, k) == v, (k, getattr(a, k), v)
+    assert tuple(a.input_size) == (518, 518)
+    assert a.fp32_matmul == "highest" and a.fit_batch == 0
+    assert stage1.get_args(["--dtype", "float32", "--fp32_matmul", "high"]).fp32_matmul == "high"
+    import pytest
+    with pytest.raises(SystemExit):
+        stage1.get_args(["--fp32_matmul", "medium"])
