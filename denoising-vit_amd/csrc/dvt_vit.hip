@@ -1987,10 +1987,10 @@ constexpr int ATT2_KBUF = 3;
 // X3 (the fp32 extractor's opt-in "bf16x3" mode, include/dvt_vit.h): q, k, v arrive as (hi, lo) bf16 pairs of the fp32
 // values (qk / vt = hi, qk_lo / vt_lo = lo), S = K_lo.Q_hi + K_hi.Q_lo + K_hi.Q_hi and O += V_lo.P_hi + V_hi.P_lo + V_hi.P_hi
 // with P split in registers (3 x the MFMAs, fp32 accumulation, fp32 softmax as before) and `out` is fp32 [T, dim].
-template <int VAR, bool X3 = false>
-__global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
-                                                           bf16_t* __restrict__ out, int heads, int s_pad, int n_valid,
-                                                           const bf16_t* __restrict__ qk_lo, const bf16_t* __restrict__ vt_lo) {
+template <int VAR, bool X3>
+__device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                  bf16_t* __restrict__ out, int heads, int s_pad, int n_valid,
+                                                  const bf16_t* __restrict__ qk_lo, const bf16_t* __restrict__ vt_lo) {
   constexpr int NV = (VAR & 64) ? 3 : 2;  // V^T buffers: the half-tile offset of the two wave groups needs a third
   constexpr int KSET = ATT2_KBUF * KV_TILE * 128, VSET = NV * 64 * VT_LD;  // one precision part: 24 KB + 16 KB
   __shared__ __attribute__((aligned(16))) char smem[(X3 ? 2 : 1) * (KSET + VSET)];
@@ -2373,6 +2373,20 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
   }
 }
 
+template <int VAR>
+__global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                           bf16_t* __restrict__ out, int heads, int s_pad, int n_valid) {
+  attention_v2_body<VAR, false>(qk, vt, out, heads, s_pad, n_valid, nullptr, nullptr);
+}
+// the split-operand build: 156 registers, one 80-KB workgroup per CU (capped at 128 registers -- 24 dwords of scratch,
+// two workgroups per CU -- it measured 1.71-1.76 ms per 64 views against 1.30-1.53: dropped)
+__global__ __launch_bounds__(512) void attention_kernel_v2_x3(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                              bf16_t* __restrict__ out, int heads, int s_pad, int n_valid,
+                                                              const bf16_t* __restrict__ qk_lo,
+                                                              const bf16_t* __restrict__ vt_lo) {
+  attention_v2_body<12, true>(qk, vt, out, heads, s_pad, n_valid, qk_lo, vt_lo);
+}
+
 inline int64_t up256b(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct VitWork {
@@ -2611,8 +2625,7 @@ extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int 
 #define A2_VAR(n)                                                                                                     \
   if (g_vit_attn_mask == n) {                                                                                         \
     hipLaunchKernelGGL(attention_kernel_v2<n>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,            \
-                       (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid, (const bf16_t*)nullptr,                \
-                       (const bf16_t*)nullptr);                                                                       \
+                       (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);                                       \
     done = true;                                                                                                      \
   }
     A2_VAR(0) A2_VAR(1) A2_VAR(2) A2_VAR(4) A2_VAR(8) A2_VAR(16) A2_VAR(64) A2_VAR(3) A2_VAR(15) A2_VAR(31) A2_VAR(79)
@@ -2713,7 +2726,7 @@ extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, in
   const bf16_t* vh = qh + L.vh;
   const bf16_t* vl = qh + L.vl;
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, s, 3.0 * 4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
-  hipLaunchKernelGGL((attention_kernel_v2<12, true>), dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0, s,
+  hipLaunchKernelGGL(attention_kernel_v2_x3, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0, s,
                      (const bf16_t*)qh, (const bf16_t*)vh, (bf16_t*)out, heads, s_pad, n_valid, (const bf16_t*)ql,
                      (const bf16_t*)vl);
   DVT_CHECK_LAUNCH();
