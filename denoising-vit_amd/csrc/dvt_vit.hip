@@ -1990,7 +1990,8 @@ constexpr int ATT2_KBUF = 3;
 template <int VAR, bool X3>
 __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                   bf16_t* __restrict__ out, int heads, int s_pad, int n_valid,
-                                                  const bf16_t* __restrict__ qk_lo, const bf16_t* __restrict__ vt_lo) {
+                                                  const bf16_t* __restrict__ qk_lo, const bf16_t* __restrict__ vt_lo,
+                                                  int split_out = 0) {
   constexpr int NV = (VAR & 64) ? 3 : 2;  // V^T buffers: the half-tile offset of the two wave groups needs a third
   constexpr int KSET = ATT2_KBUF * KV_TILE * 128, VSET = NV * 64 * VT_LD;  // one precision part: 24 KB + 16 KB
   __shared__ __attribute__((aligned(16))) char smem[(X3 ? 2 : 1) * (KSET + VSET)];
@@ -2356,6 +2357,23 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
   if constexpr (X3) {
+    if (split_out) {  // the proj GEMM's A row [hi | hi | lo] (3 dim wide) instead of fp32: no split pass in between
+      bf16_t* r3 = out + (row0 + qb * ATT_Q + wave * 16 + lc) * (3 * dim) + h * 64;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float a0 = o[mt][0] * inv, a1 = o[mt][1] * inv, a2 = o[mt][2] * inv, a3 = o[mt][3] * inv;
+        uint2 hh, ll;
+        hh.x = pack2(a0, a1);
+        hh.y = pack2(a2, a3);
+        ll.x = pack2(a0 - __uint_as_float(hh.x << 16), a1 - __uint_as_float(hh.x & 0xffff0000u));
+        ll.y = pack2(a2 - __uint_as_float(hh.y << 16), a3 - __uint_as_float(hh.y & 0xffff0000u));
+        bf16_t* c = r3 + mt * 16 + 4 * g;
+        *reinterpret_cast<uint2*>(c) = hh;
+        *reinterpret_cast<uint2*>(c + dim) = hh;
+        *reinterpret_cast<uint2*>(c + 2 * dim) = ll;
+      }
+      return;
+    }
     float* orow = reinterpret_cast<float*>(out) + (row0 + qb * ATT_Q + wave * 16 + lc) * dim + h * 64;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -2383,8 +2401,8 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
 __global__ __launch_bounds__(512) void attention_kernel_v2_x3(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                               bf16_t* __restrict__ out, int heads, int s_pad, int n_valid,
                                                               const bf16_t* __restrict__ qk_lo,
-                                                              const bf16_t* __restrict__ vt_lo) {
-  attention_v2_body<12, true>(qk, vt, out, heads, s_pad, n_valid, qk_lo, vt_lo);
+                                                              const bf16_t* __restrict__ vt_lo, int split_out) {
+  attention_v2_body<12, true>(qk, vt, out, heads, s_pad, n_valid, qk_lo, vt_lo, split_out);
 }
 
 inline int64_t up256b(int64_t x) { return (x + 255) / 256 * 256; }
@@ -2687,8 +2705,8 @@ __global__ __launch_bounds__(256) void v_split_transpose_kernel(const float* __r
 }
 }  // namespace
 
-extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
-                                             void* stream);
+extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, void* out, int batch, int heads, int s_pad, int n_valid,
+                                             int split_out, void* stream);
 extern "C" int64_t dvt_vit_attention_x3_scratch_bytes(int batch, int heads, int s_pad) {
   if (batch <= 0 || heads <= 0 || s_pad <= 0) return -1;
   return x3_scratch(batch, heads, s_pad).total * 2;
@@ -2712,11 +2730,11 @@ extern "C" int dvt_vit_attention_x3(const float* qkv, float* out, void* scratch,
   DVT_CHECK_LAUNCH();
   hipLaunchKernelGGL(v_split_transpose_kernel, dim3(s_pad / 64, heads, batch), dim3(256), 0, s, qkv, vh, vl, heads, s_pad);
   DVT_CHECK_LAUNCH();
-  return dvt_vit_attention_x3_presplit(scratch, out, batch, heads, s_pad, n_valid, stream);
+  return dvt_vit_attention_x3_presplit(scratch, out, batch, heads, s_pad, n_valid, 0, stream);
 }
 
-extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
-                                             void* stream) {
+extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, void* out, int batch, int heads, int s_pad, int n_valid,
+                                             int split_out, void* stream) {
   if (!out || !scratch || batch <= 0 || heads <= 0 || s_pad % ATT_Q || n_valid <= 0 || n_valid > s_pad)
     return DVT_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
@@ -2728,7 +2746,7 @@ extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, in
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, s, 3.0 * 4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
   hipLaunchKernelGGL(attention_kernel_v2_x3, dim3((s_pad / ATT_Q) * heads * batch), dim3(512), 0, s,
                      (const bf16_t*)qh, (const bf16_t*)vh, (bf16_t*)out, heads, s_pad, n_valid, (const bf16_t*)ql,
-                     (const bf16_t*)vl);
+                     (const bf16_t*)vl, split_out);
   DVT_CHECK_LAUNCH();
   return 0;
 }

@@ -27,8 +27,8 @@ extern "C" int dvt_vit_gemm_residual(const void* a, const void* w, const float* 
                                      int n, int k, void* stream);
 extern "C" int dvt_vit_attention_x3(const float* qkv, float* out, void* scratch, int batch, int heads, int s_pad,
                                     int n_valid, void* stream);
-extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
-                                             void* stream);
+extern "C" int dvt_vit_attention_x3_presplit(const void* scratch, void* out, int batch, int heads, int s_pad, int n_valid,
+                                             int split_out, void* stream);
 extern "C" int64_t dvt_vit_attention_x3_scratch_bytes(int batch, int heads, int s_pad);
 extern "C" int dvt_vit_gemm_gelu_x3(const void* a, const void* w, const float* b, void* out3, int m, int n, int k, void* stream);
 extern "C" int dvt_vit_gemm_qkv_x3(const void* a, const void* w, const float* b, void* scratch, int m, int dim, int heads,
@@ -466,9 +466,10 @@ extern "C" int dvt_vit_forward_f32x3(const DvtVitConfig* c, const DvtVitWeights*
       DVT_TRY(dvt_vit_attention_x3(k.qkv, k.ao, k.sc, batch, c->heads, c->s_pad, c->n_tokens, stream));
     } else {  // q | k | V^T leave the qkv GEMM already split
       DVT_TRY(dvt_vit_gemm_qkv_x3(k.a3, bw.qkv_w, bw.qkv_b, k.sc, Tg, D, c->heads, c->s_pad, batch, 3 * D, stream));
-      DVT_TRY(dvt_vit_attention_x3_presplit(k.sc, k.ao, batch, c->heads, c->s_pad, c->n_tokens, stream));
+      // ... and the attention output leaves as the proj GEMM's split A rows (a3 is free: the qkv GEMM has read it)
+      DVT_TRY(dvt_vit_attention_x3_presplit(k.sc, k.a3, batch, c->heads, c->s_pad, c->n_tokens, 1, stream));
     }
-    DVT_TRY(dvt_vit_split3(k.ao, k.a3, T, D, 0, 0, stream));
+    if (g_f32x3_exact_attention || g_f32x3_unfused) DVT_TRY(dvt_vit_split3(k.ao, k.a3, T, D, 0, 0, stream));
     DVT_TRY(dvt_vit_gemm_residual(k.a3, bw.proj_w, bw.proj_b, bw.ls1, k.x, Tg, D, 3 * D, stream));
     hipLaunchKernelGGL((layernorm_f32_kernel<false, true>), dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm2_w,
                        bw.norm2_b, (float*)k.a3, T, D, c->ln_eps, 0, 0, 0);

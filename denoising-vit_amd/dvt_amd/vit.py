@@ -58,7 +58,7 @@ _lib.register_signatures({
     "dvt_vit_workspace_bytes_f32x3": (C.c_int64, [C.POINTER(VitConfig), _I]),
     "dvt_vit_attention_x3_scratch_bytes": (C.c_int64, [_I, _I, _I]),
     "dvt_vit_attention_x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "dvt_vit_attention_x3_presplit": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dvt_vit_attention_x3_presplit": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dvt_vit_gemm_gelu_x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "dvt_vit_gemm_qkv_x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dvt_vit_forward_f32x3": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),

@@ -128,8 +128,8 @@ int dvt_vit_gemm_gelu_x3(const void* a_bf16, const void* w_bf16, const float* b,
                          void* stream);
 int dvt_vit_gemm_qkv_x3(const void* a_bf16, const void* w_bf16, const float* b, void* scratch, int m, int dim, int heads,
                         int s_pad, int batch, int k, void* stream);
-int dvt_vit_attention_x3_presplit(const void* scratch, float* out, int batch, int heads, int s_pad, int n_valid,
-                                  void* stream);
+int dvt_vit_attention_x3_presplit(const void* scratch, void* out, int batch, int heads, int s_pad, int n_valid,
+                                  int split_out /* 0: out fp32 [T, dim]; 1: out bf16 [T, 3 dim] = [hi | hi | lo] */, void* stream);
 int64_t dvt_vit_workspace_bytes_f32x3(const DvtVitConfig* h_cfg, int batch);
 int dvt_vit_forward_f32x3(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img, float* feat,
                           int batch, int n_blocks, void* workspace, void* stream);

@@ -367,6 +367,18 @@ def test_attention_f32x3_vs_fp64(L, batch, heads, s_pad, n_valid, spike):
     e, e_ex = rel(got[:, :n_valid], want[:, :n_valid]), rel(ex[:, :n_valid], want[:, :n_valid])
     rows = ((got - want)[:, :n_valid].norm(dim=-1) / want[:, :n_valid].norm(dim=-1)).max()
     print(f"bf16x3 attention b{batch} h{heads} n{n_valid} spike {spike}: rel-L2 {e:.2e} (exact-fp32 kernel {e_ex:.2e}), worst row {rows:.2e}")
+    # split_out = 1: the same result as the next GEMM's [hi | hi | lo] rows.  hi is bit for bit bf16(out); lo may differ from
+    # bf16(out - hi) in its last bit (the compiler contracts o * inv - hi into one fma, i.e. lo is formed from the unrounded
+    # product): hi + lo must reproduce out to the split's 2^-16
+    out3 = torch.empty((batch * s_pad, 3 * dim), device=DEV, dtype=torch.bfloat16)
+    assert L.dvt_vit_attention_x3_presplit(scratch.data_ptr(), out3.data_ptr(), batch, heads, s_pad, n_valid, 1, _s()) == 0
+    torch.cuda.synchronize()
+    from oracle import bf16x3 as _x3
+    rows_valid = torch.arange(batch * s_pad).reshape(batch, s_pad)[:, :n_valid].reshape(-1)
+    o3, of = out3.cpu()[rows_valid].float(), out.cpu()[rows_valid]
+    assert torch.equal(o3[:, :dim], of.bfloat16().float()) and torch.equal(o3[:, :dim], o3[:, dim:2 * dim])
+    assert float(((o3[:, :dim] + o3[:, 2 * dim:]) - of).abs().max() / of.abs().max()) < 2.0 ** -16
+    assert _x3.split3_activation(of).shape == o3.shape
     # the CPU restatement of the same three-term arithmetic (one head).  The two differ in WHICH bits the splits of P round
     # away (online softmax against a lagging running max vs the true row max), so they agree to the error class of
     # the method, not tighter: 0.9-1.1e-5 measured
