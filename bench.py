@@ -90,6 +90,8 @@ def parse():
                    help="do not write the two .npy files per image (tmpfs) inside the timed region")
     p.add_argument("--save-root", default=None, help="where the timed region writes its .npy pairs (default: a "
                                                      "directory under /dev/shm, removed afterwards)")
+    p.add_argument("--extract-launch-views", type=int, default=0,
+                   help="views per extractor launch (0 = at most 128, balanced: 769 views -> 7 launches of 110)")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="images in flight per GPU (1 = strictly serial reference flow)")
     return p.parse_args()
@@ -100,7 +102,8 @@ def stage1_args(a):
         model=a.model, input_size=(518, 518), stride_size=14, layer_depth_ratio=1.0,
         num_views=a.views, num_iters=a.num_iters, warmup_iters=a.warmup_iters, n_levels=16,
         freeze_shared_artifacts_after=0.5, lr=0.01, min_lr=0.001, weight_decay=1e-5,
-        extract_bsz=128, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None, dtype=a.fit_dtype)
+        extract_bsz=32, extract_launch_views=a.extract_launch_views, pixel_bsz=a.pixel_bsz, seed=0, vit_checkpoint=None,
+        dtype=a.fit_dtype)
 
 
 def _best_threads(fn):
@@ -163,9 +166,11 @@ def cpu_baseline_and_parity(a, vit, device):
     t_step = (time.perf_counter() - t0) / T
     want = ofit.final_denoised_feats(d_o, f_o, feats_o, coords_c)[0]
     sec_per_image = t_view * (a.views + 1) + t_step * a.num_iters
-    base = {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": cores, "kind": "port",
+    base = {"value": 1.0 / sec_per_image, "unit": "images/s", "cores": cores, "host_cores": os.cpu_count(),
+            "kind": "port",
             "sample": f"{V + 1} fp32 ViT-B/14 views ({t_view:.2f} s each) + {T} fit steps at B={B}, L=16, 2^20 "
-                      f"({t_step:.3f} s each) on {cores} host threads, extrapolated linearly to {a.views + 1} views + "
+                      f"({t_step:.3f} s each) on {cores} torch threads (the fastest of a 2-block probe over 8/16/32/64/all of "
+                      f"the box's {os.cpu_count()} logical host cores; the hosts are shared), extrapolated linearly to {a.views + 1} views + "
                       f"{a.num_iters} steps ({sec_per_image:.0f} s/image)"}
     # ---- the HIP chain on the same sample
     cos = torch.nn.functional.cosine_similarity
@@ -352,6 +357,7 @@ def main():
                 "weights": "random init (no network for checkpoints)",
                 "t_extract_s_serial": split["t_extract"], "t_fit_s_serial": split["t_fit"],
                 "pipeline_depth": a.pipeline_depth, "fit_batch": a.fit_batch,
+                "extract_launch_views": st.vit_launch_views(a.views + 1),
                 "images_per_rank": a.steps, "parallelism": f"images sharded over {world} GPU(s), no collective",
                 "per_rank": [{"rank": i, "images": int(r[0]), "seconds": r[1]} for i, r in enumerate(per_rank)],
             },
@@ -389,6 +395,14 @@ def main():
 
         kern = kernel_table(prof, a.steps)
         if kern:
+            # per-kernel tables: durations are HIP-EVENT brackets recorded by the library on the launch stream
+            # (dvt_prof_*).  Inside the pipelined region a bracket also contains the time the kernel's workgroups wait
+            # behind the other stream's, so `kernels` reads ~5-10 % above the rocprofv3 kernel-trace durations of the same
+            # region (profiles/<round>/final/pipe_kernel_stats.txt); `kernels_isolated` (one serial image, one stream)
+            # agrees with rocprofv3's serial table.
+            out["kernels"] = kern  # inside the timed (pipelined) region
+            out["kernels_isolated"] = kernel_table(prof_iso, 1)  # serial pass, one stream
+            out["kernels_timing"] = "hipEvent brackets on the launch stream (see profiles/ for the rocprofv3 tables)"
             dom = max(kern, key=lambda k: kern[k]["ms_per_image"])
             out["roofline"] = {"kernel": dom, **{k: kern[dom][k] for k in
                                                  ("bound", "achieved", "peak", "unit", "frac", "traffic")},
@@ -405,8 +419,6 @@ def main():
             out["image_level"] = {"per_gpu_images_per_s": per_gpu, "ceiling_serial": ser, "ceiling_overlapped": ovl,
                                   "frac_of_serial_ceiling": per_gpu / ser, "frac_of_overlapped_ceiling": per_gpu / ovl,
                                   "definition": "SURVEY.md 8(d): 233.1 TFLOP / 2.5 PF/s + 0.549 TB / 8 TB/s per image"}
-            out["kernels"] = kern  # inside the timed (pipelined) region
-            out["kernels_isolated"] = kernel_table(prof_iso, 1)  # serial pass, one stream
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(a, vit, device)

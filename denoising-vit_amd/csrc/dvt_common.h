@@ -203,18 +203,18 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
 
 // ---- profiling probes (dvt_prof.hip) ----
 extern unsigned g_dvt_prof_mask;
-void dvt_prof_begin(int probe, hipStream_t s);
-void dvt_prof_end(int probe, hipStream_t s, double work);
+long dvt_prof_begin(int probe, hipStream_t s);  // -> this scope's sample index (thread-safe, dvt_prof.hip)
+void dvt_prof_end(int probe, long idx, hipStream_t s, double work);
 struct DvtProbeScope {
   int probe;
   hipStream_t s;
   double work;
-  bool on;
-  DvtProbeScope(int p, hipStream_t st, double w) : probe(p), s(st), work(w), on((g_dvt_prof_mask >> p) & 1u) {
-    if (on) dvt_prof_begin(probe, s);
+  long idx;
+  DvtProbeScope(int p, hipStream_t st, double w) : probe(p), s(st), work(w), idx(-1) {
+    if ((g_dvt_prof_mask >> p) & 1u) idx = dvt_prof_begin(probe, s);
   }
   ~DvtProbeScope() {
-    if (on) dvt_prof_end(probe, s, work);
+    if (idx >= 0) dvt_prof_end(probe, idx, s, work);
   }
 };
 int dvt_vit_tune(int gemm_variant);

@@ -1,4 +1,8 @@
 // Profiling probes: hipEvent pairs recorded on the launch stream around selected launches.
+// Thread-safe: fit_many (dvt_amd/fit.py) drives dvt_fit_run_batched from up to four host threads with the probes enabled, so
+// a probe's sample pool is guarded by a mutex and every scope carries the index of ITS sample (an a/b pair is always
+// recorded by the one scope that drew it, whatever the interleaving of the threads).
+#include <mutex>
 #include <vector>
 
 #include "dvt_common.h"
@@ -13,45 +17,56 @@ struct Probe {
   std::vector<Sample> pool;  // created lazily, reused
   size_t used = 0;
   double work = 0.0;
-  hipEvent_t pending = nullptr;
 };
 Probe g_probes[DVT_N_PROBES];
+std::mutex g_prof_mu;
 constexpr size_t MAX_SAMPLES = 200000;
 }  // namespace
 
-void dvt_prof_begin(int probe, hipStream_t s) {
+// returns the sample index of this scope, -1 if none could be drawn
+long dvt_prof_begin(int probe, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   Probe& p = g_probes[probe];
-  if (p.used >= MAX_SAMPLES) return;
+  if (p.used >= MAX_SAMPLES) return -1;
   if (p.used == p.pool.size()) {
     Sample sm;
-    if (hipEventCreate(&sm.a) != hipSuccess || hipEventCreate(&sm.b) != hipSuccess) return;
+    if (hipEventCreate(&sm.a) != hipSuccess) return -1;
+    if (hipEventCreate(&sm.b) != hipSuccess) {
+      (void)hipEventDestroy(sm.a);
+      return -1;
+    }
     p.pool.push_back(sm);
   }
-  (void)hipEventRecord(p.pool[p.used].a, s);
-  p.pending = p.pool[p.used].a;
+  const long idx = (long)p.used++;
+  // both events are recorded here and now: a sample whose scope never ends (or whose end loses the race with a
+  // dvt_prof_enable reset) still reads as a valid, zero-length pair
+  (void)hipEventRecord(p.pool[idx].a, s);
+  (void)hipEventRecord(p.pool[idx].b, s);
+  return idx;
 }
 
-void dvt_prof_end(int probe, hipStream_t s, double work) {
+void dvt_prof_end(int probe, long idx, hipStream_t s, double work) {
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   Probe& p = g_probes[probe];
-  if (p.pending == nullptr) return;
-  (void)hipEventRecord(p.pool[p.used].b, s);
-  p.pending = nullptr;
-  p.used++;
+  if ((size_t)idx >= p.used) return;  // the probes were reset while this scope was open
+  (void)hipEventRecord(p.pool[idx].b, s);
   p.work += work;
 }
 
 extern "C" int dvt_prof_enable(unsigned mask) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_dvt_prof_mask = mask & ((1u << DVT_N_PROBES) - 1u);
   for (auto& p : g_probes) {
     p.used = 0;
     p.work = 0.0;
-    p.pending = nullptr;
   }
   return 0;
 }
 
 extern "C" int dvt_prof_collect(int probe, double* total_ms, int64_t* count, double* work) {
   if (probe < 0 || probe >= DVT_N_PROBES || !total_ms || !count || !work) return DVT_E_BADARG;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   Probe& p = g_probes[probe];
   double tot = 0.0;
   for (size_t i = 0; i < p.used; ++i) {

@@ -452,6 +452,14 @@ extern "C" int dvt_vit_forward_f32x3(const DvtVitConfig* c, const DvtVitWeights*
   hipLaunchKernelGGL(embed_f32_kernel, dim3(T), dim3(256), 0, s, (const float4*)k.ao, (float4*)k.x,
                      (const float4*)w->cls_token, (const float4*)w->pos_embed, *c);
   DVT_CHECK_LAUNCH();
+  // The GEMMs run over Tg = whole 256-row tiles, embed / LayerNorm write T rows: the phantom rows of the residual stream
+  // and of the split A rows start every forward as zeros (they are only ever read row-locally, but the carve depends on
+  // `batch`, so without this they could alias another layout's bytes, NaN patterns included -- ADVICE r3)
+  if (Tg > T) {
+    if (hipMemsetAsync(k.x + (size_t)T * D, 0, (size_t)(Tg - T) * D * sizeof(float), s) != hipSuccess) return DVT_E_BADARG;
+    if (hipMemsetAsync((char*)k.a3 + (size_t)T * 3 * D * 2, 0, (size_t)(Tg - T) * 3 * D * 2, s) != hipSuccess)
+      return DVT_E_BADARG;
+  }
   for (int l = 0; l < n_blocks; ++l) {
     const DvtVitBlockWeights& bw = w->blocks[l];
     hipLaunchKernelGGL((layernorm_f32_kernel<false, true>), dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm1_w,

@@ -23,6 +23,10 @@ def env_ranks() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", 0)))
 
 
+_pin_info: dict | None = None        # what pin_host_threads did for this process (it acts once)
+_orig_affinity: list | None = None   # the CPU set the process started with
+
+
 def pin_host_threads(local_rank: int | None = None, local_world: int | None = None) -> dict:
     """Host budget of one rank on a multi-GPU node.  Every rank runs ~4 host threads (extractor,
     fit, retire + write, index-stream look-ahead) that spend most of their life blocked on a full HIP queue, plus
@@ -30,13 +34,20 @@ def pin_host_threads(local_rank: int | None = None, local_world: int | None = No
     fight over the same cores: each rank gets a contiguous slice of the CPUs this process may run on
     (`sched_setaffinity`) and caps its torch / OpenMP pools to that slice (at most 8 threads).  A single-process run
     (local_world == 1) is left alone.  DVT_NO_AFFINITY=1 disables the pinning; returns what was done."""
+    global _pin_info, _orig_affinity
     local_rank = int(os.environ.get("LOCAL_RANK", 0)) if local_rank is None else local_rank
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", 1))) if local_world is None \
-        else local_world
+    # the ranks of THIS host only: without LOCAL_WORLD_SIZE (a launcher that does not export it) nothing is pinned --
+    # WORLD_SIZE would under-use the host on a multi-node launch
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", 0))
     info = {"local_rank": local_rank, "local_world": local_world, "pinned": False}
     if local_world <= 1 or os.environ.get("DVT_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
         return info
-    cpus = sorted(os.sched_getaffinity(0))
+    if _pin_info is not None and _pin_info.get("local_rank") == local_rank and _pin_info.get("local_world") == local_world:
+        return _pin_info  # once per process: a second init() (stage1.main, then stage2.train) must not re-slice the slice
+    if _orig_affinity is None:
+        _orig_affinity = sorted(os.sched_getaffinity(0))
+    cpus = _orig_affinity  # always slice the set the process STARTED with
     per = max(1, len(cpus) // local_world)
     mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
     try:
@@ -44,18 +55,17 @@ def pin_host_threads(local_rank: int | None = None, local_world: int | None = No
     except OSError:
         return info
     n = max(1, min(8, len(mine)))
-    torch.set_num_threads(n)
-    os.environ.setdefault("OMP_NUM_THREADS", str(n))
+    torch.set_num_threads(n)  # (the OpenMP pool already exists once torch is imported: the env variable would be a no-op)
     info.update(pinned=True, cpus=[mine[0], mine[-1]], n_cpus=len(mine), torch_threads=n)
+    _pin_info = info
     return info
 
 
 def init(device: torch.device, world: int) -> bool:
     """Join the env:// rendezvous when world > 1 (RCCL for a HIP device, gloo for cpu)."""
-    if world > 1:
-        pin_host_threads()
     if world <= 1 or dist.is_initialized():
         return dist.is_initialized()
+    pin_host_threads()
     if device.type == "cuda":
         dist.init_process_group("nccl", device_id=device)
     else:

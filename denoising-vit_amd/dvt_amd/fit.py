@@ -339,9 +339,12 @@ def fit_many(engines, feats, xys, idxs=None, log_every: int = 1000, step_begin: 
         dev = torch.device("cuda", torch.cuda.current_device())
     cur = torch.cuda.current_stream(dev)
     groups = [range(i, min(k, i + FIT_BATCH_MAX)) for i in range(0, k, FIT_BATCH_MAX)]
-    pool = _side_streams.setdefault(torch.device(dev), [])
+    # side streams inherit the calling stream's priority: a group beyond the first must not lose the fit's standing
+    # against the extractor stream
+    prio = int(getattr(cur, "priority", 0))
+    pool = _side_streams.setdefault((torch.device(dev), prio), [])
     while len(pool) < len(groups):
-        pool.append(torch.cuda.Stream(device=dev))
+        pool.append(torch.cuda.Stream(device=dev, priority=prio))
     errors = []
 
     def work(gi, members):

@@ -27,6 +27,7 @@ import torch
 
 from . import dist as D
 from . import views as V
+from ._lib import DvtError
 from .fit import FIT_CONCURRENT_MAX, FitEngine, FitSettings, fit_many
 from .models import MODEL_LIST, PretrainedViTWrapper
 from .utils import misc
@@ -60,16 +61,20 @@ def get_args(argv=None):
     p.add_argument("--lr", type=float, default=0.01)
     p.add_argument("--min_lr", type=float, default=0.001)
     p.add_argument("--weight_decay", type=float, default=1e-5)
-    p.add_argument("--extract_bsz", type=int, default=128,
-                   help="views per extractor launch.  The reference's 32 is its DataLoader batch; here the "
-                        "views are already on the device and 128 keeps every GEMM at M = 128 * 1408 rows. "
-                        "Results do not depend on it (tested).")
+    p.add_argument("--extract_bsz", type=int, default=32,
+                   help="the reference's DataLoader batch for feature extraction (main_img_denoising.py:196).  Kept with "
+                        "its default for CLI compatibility; here the views are already on the device and results do not "
+                        "depend on the batching (tested), so the number of views per extractor LAUNCH is its own knob, "
+                        "--extract_launch_views")
     p.add_argument("--pixel_bsz", type=int, default=2048)
     p.add_argument("--output_dir", type=str, default="./work_dirs/demo")
     p.add_argument("--num_vis_samples", type=int, default=5)
     p.add_argument("--vis_freq", type=int, default=100)
     p.add_argument("--seed", type=int, default=0)
     # additions of this build
+    p.add_argument("--extract_launch_views", type=int, default=0,
+                   help="views per extractor launch; 0 (default) = at most 128, balanced over equal launches (769 views "
+                        "-> 7 x 110: every GEMM runs at M = 110 * 1408 rows)")
     p.add_argument("--vit_checkpoint", type=str, default=None, help="timm-layout state dict (.pth)")
     p.add_argument("--synthetic", action="store_true", help="N(0,1) views instead of image crops")
     p.add_argument("--allow_random_vit", action="store_true",
@@ -146,6 +151,10 @@ class Stage1:
 
     def __init__(self, args, device, vit: PretrainedViTWrapper | None = None, depth: int = 2,
                  vit_cus_per_32: int = 32, fit_batch: int = 1):
+        # argument checks first: nothing is allocated for a run that cannot start
+        self.extract_matmul = str(getattr(args, "fp32_matmul", "highest") or "highest")
+        if self.extract_matmul not in ("highest", "high"):
+            raise DvtError(f"--fp32_matmul must be highest or high, not {self.extract_matmul!r}")
         self.args, self.device = args, torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:  # worker threads call set_device
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -187,14 +196,12 @@ class Stage1:
                           else _cu_masked_stream(dev, fit_cus, 32 - fit_cus))
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
-        self.extract_bsz = max(1, int(getattr(args, "extract_bsz", 128) or 128))
+        # views per extractor launch (NOT the reference's --extract_bsz, which is a DataLoader batch and is only accepted)
+        self.extract_launch_views = max(1, int(getattr(args, "extract_launch_views", 0) or 128))
         # `--dtype` is the reference's one precision switch (main_img_denoising.py:173, :257): float32 = fp32
         # extractor AND fp32-operand fit (autocast off, its default); bfloat16 = both under bf16 autocast
         self.extract_dtype = ("bfloat16" if str(getattr(args, "dtype", "float32")) in
                               ("bfloat16", "bf16", "torch.bfloat16") else "float32")
-        self.extract_matmul = str(getattr(args, "fp32_matmul", "highest") or "highest")
-        if self.extract_matmul not in ("highest", "high"):
-            raise DvtError(f"--fp32_matmul must be highest or high, not {self.extract_matmul!r}")
         if self.extract_dtype != "float32":
             self.extract_matmul = "highest"  # the switch only exists for fp32 operands
         # Everything above was allocated / zero-filled on the CURRENT stream; the first writers are the
@@ -205,13 +212,21 @@ class Stage1:
         self._idx_spare = []  # index streams drawn ahead for the next fit (numpy stream order kept)
         self._idx_queue = None  # look-ahead queue while `run` is active
 
+    def vit_launch_views(self, n_views: int) -> int:
+        """Views per extractor launch for an image of `n_views` views (what `extract` will use; reported by bench.py)."""
+        from .vit import balanced_launch_views
+        cap = self.extract_launch_views
+        if self.extract_dtype == "float32":
+            cap = min(cap, 64 if self.extract_matmul == "high" else 32)
+        return balanced_launch_views(n_views, cap)
+
     # -- single-image pieces (each enqueues on the CURRENT stream) -------------------------
     def extract(self, slot: _Slot) -> None:
         """Feature extraction of all views into the feature store (:315-339), NHWC, no
         NCHW round trip; batches of 128 views keep every GEMM at M = 128*1408 rows."""
         with torch.no_grad():
             self.vit.features_nhwc(slot.views, self.layer_index, out=slot.features,
-                                   max_batch=self.extract_bsz, dtype=self.extract_dtype,
+                                   max_batch=self.extract_launch_views, dtype=self.extract_dtype,
                                    matmul=self.extract_matmul)
 
     def fit(self, slot: _Slot, log_every: int = 1000) -> torch.Tensor:

@@ -291,15 +291,15 @@ def train(args, rank: int, world: int, device: torch.device, model_factory=None)
     # the host looks anyway -- log steps and BEFORE every checkpoint -- so that every rank aborts together (no rank is
     # left blocked in all_reduce) and no NaN-poisoned parameters or AdamW moments are ever written to a checkpoint.
     bad = torch.zeros((), device=device, dtype=torch.float32)
-    bad_step = torch.full((), -1.0, device=device, dtype=torch.float32)
+    bad_step = torch.full((), float("inf"), device=device, dtype=torch.float32)  # +inf = not seen on this rank
 
     def raise_if_bad(step):
-        flag = torch.stack([bad, bad_step])
+        flag = torch.stack([bad, -bad_step])  # one MAX reduction: any rank bad, and the EARLIEST step over the ranks
         if distributed:
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        b, at = flag.cpu().tolist()
+        b, neg_at = flag.cpu().tolist()
         if b != 0.0:
-            raise FloatingPointError(f"loss is not finite (first seen at or before step {int(at)}, detected at step "
+            raise FloatingPointError(f"loss is not finite (first seen at step {int(-neg_at)}, detected at step "
                                      f"{step}), stopping training")
 
     try:

@@ -158,6 +158,16 @@ def random_state_dict(dim: int, depth: int, patch: int, n_tokens: int, seed: int
     return sd
 
 
+def balanced_launch_views(n_views: int, max_batch: int) -> int:
+    """Views per extractor launch: the fewest launches of at most `max_batch` views, equally sized (769 views at 128 ->
+    7 x 110 instead of 6 x 128 + 1).  DVT_VIT_BALANCE=0: the reference's plain chunks of max_batch, for A/B timing."""
+    max_batch = max(1, int(max_batch))
+    if os.environ.get("DVT_VIT_BALANCE", "1") == "0":
+        return max_batch
+    n_launch = -(-n_views // max_batch)
+    return -(-n_views // n_launch)
+
+
 class HipViT:
     """Device-resident weights + the forward launcher."""
 
@@ -275,9 +285,7 @@ class HipViT:
         # equal-sized launches: 769 views at max_batch 128 would be 6 x 128 + ONE view whose GEMMs fill 6 of 256 CUs;
         # 7 x 110 (109) keeps every launch full (measured: within noise, 2.718 vs 2.712 images/s on one box).  Results do
         # not depend on the batching (tests/test_gpu_vit.py).
-        if os.environ.get("DVT_VIT_BALANCE", "1") != "0":  # (0: the reference's plain chunks of max_batch, for A/B timing)
-            n_launch = -(-B // max(1, max_batch))
-            max_batch = -(-B // n_launch)
+        max_batch = balanced_launch_views(B, max_batch)
         ws = self._workspace(min(B, max_batch))
         L = _lib.lib()
         fwd = L.dvt_vit_forward_f32x3 if self.x3 else L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward

@@ -22,7 +22,9 @@ import torch.nn.functional as F
 
 
 def forward_features(sd: dict, img: torch.Tensor, patch: int, stride: int,
-                     n_blocks: int | None = None, eps: float = 1e-6) -> torch.Tensor:
+                     n_blocks: int | None = None, eps: float = 1e-6, stream_out: list | None = None) -> torch.Tensor:
+    """`stream_out`: optional list that receives the fp32 residual stream [B, tokens, dim] BEFORE the final LayerNorm
+    (test instrumentation: the outlier stress measures its hot / cold channel ratio there)."""
     dim = sd["pos_embed"].shape[-1]
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
     n_blocks = depth if n_blocks is None else n_blocks
@@ -53,6 +55,8 @@ def forward_features(sd: dict, img: torch.Tensor, patch: int, stride: int,
         h = F.linear(F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])),
                      sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
         x = x + sd.get(p + "ls2.gamma", 1.0) * h
+    if stream_out is not None:
+        stream_out.append(x)
     x = F.layer_norm(x, (dim,), sd["norm.weight"], sd["norm.bias"], eps)
     return x[:, 1 + n_reg:].reshape(B, gh, gw, dim)  # prefix tokens stripped (return_prefix_tokens=False)
 

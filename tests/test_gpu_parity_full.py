@@ -96,6 +96,39 @@ def test_fit_matches_oracle_baseline_shapes(built_lib):
     assert want_log[T - 1]["patch_l2_loss"] < 0.8 * want_log[0]["patch_l2_loss"]
 
 
+def _check_against_fit1000_fixture(z, log, got, mode, floor, label):
+    """Per-step losses at the list-chunk boundary / phase switch / end and the saved tensor of ONE 1000-step HIP fit against
+    the committed oracle run `z` (tests/golden/make_fit1000_golden.py); bounds: see the test below."""
+    from tests.golden import make_fit1000_golden as G
+    T = int(z["meta"][2])
+    want = torch.from_numpy(z["denoised_f16"].astype(np.float32))
+    tab, tab_p = z["losses"], z["losses_perturbed"]
+    steps = (0, 1, 127, 128, 129, 499, 500, 501, 502, 998, 999)
+    assert sorted(log) == list(range(T))
+    worst = 0.0
+    for s_ in range(T):
+        for j, k in enumerate(G.KEYS):
+            if j >= 3 and s_ <= T // 2:   # residual terms exist from step 501 on (quirk Q5)
+                assert tab[s_, j] == 0.0 and log[s_][k] == 0.0, (s_, k, log[s_][k])
+                continue
+            ref, sens = tab[s_, j], abs(tab_p[s_, j] - tab[s_, j])
+            err = abs(log[s_][k] - ref)
+            worst = max(worst, err / max(abs(ref), 1e-3)) if k == "loss" else worst
+            if s_ in steps:
+                # steps 501-503 are a TRANSIENT: h starts from its random init with bias-corrected Adam steps of size lr,
+                # the oracle's own loss goes 0.014 -> 0.05 -> 0.22-0.26 -> 0.05-0.07 within three steps (fixture), and any
+                # rounding difference is amplified there (fp32 path: 0.4 % observed at the spike, 1e-4 next to it)
+                fl = max(floor, 1e-2) if T // 2 < s_ <= T // 2 + 3 else floor
+                tol = max(fl * max(abs(ref), 1e-3), 4.0 * sens)
+                assert err <= tol, (label, s_, k, log[s_][k], ref, sens)
+    cos = per_patch_cos(got, want)
+    print(f"[1000-step fixture, {label}] loss {log[0]['loss']:.4f} -> {log[T - 1]['loss']:.5f} (oracle "
+          f"{tab[0, 0]:.4f} -> {tab[-1, 0]:.5f}); worst per-step total-loss rel err over all 1000 steps {worst:.2e}; "
+          f"denoised_feats per-patch cosine mean {cos.mean():.6f} min {cos.min():.6f} "
+          f"(oracle vs 1e-6-perturbed oracle: {z['perturbed_cos'][0]:.6f} / {z['perturbed_cos'][1]:.6f})")
+    assert cos.mean() >= 0.999 and cos.min() >= 0.99, (label, float(cos.mean()), float(cos.min()))
+
+
 @pytest.mark.parametrize("replay", ["ieee", "1ulp", "1ulp-rows32"])
 @pytest.mark.parametrize("C", [768, 1024])
 def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C, replay):
@@ -117,12 +150,8 @@ def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C, replay):
     d_o, f_o = G.fresh_modules(C)
     assert abs(G.checksum(list(d_o.parameters()) + list(f_o.parameters())) - float(z["init_checksum"])) \
         <= 1e-9 * float(z["init_checksum"]), "initial parameters are not reproducible on this box"
-    want = torch.from_numpy(z["denoised_f16"].astype(np.float32))
-    tab, tab_p = z["losses"], z["losses_perturbed"]
-    keys = G.KEYS
     n_rows = V * H * H
     f_dev, c_dev = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
-    steps = (0, 1, 127, 128, 129, 499, 500, 501, 502, 998, 999)
     # both arithmetics of the lazy Adam replay (dvt_tune_set(10, .): IEEE division / sqrt, or v_rcp / v_sqrt) against the
     # SAME oracle run; the fp32-operand path has no lazy Adam, it runs once (with "ieee")
     modes = (("float32", 2e-3), ("bfloat16", 3e-2)) if replay == "ieee" else (("bfloat16", 3e-2),)
@@ -141,29 +170,99 @@ def test_fit_baseline_schedule_vs_oracle_fixture(built_lib, C, replay):
         got, log = eng.infer(xy[-1].to(DEV)).cpu(), eng.loss_log()
         assert float(eng.grads.abs().max()) == 0.0 and int(eng.touched.abs().max()) == 0
         del eng
-        assert sorted(log) == list(range(T))
-        worst = 0.0
-        for s_ in range(T):
-            for j, k in enumerate(keys):
-                if j >= 3 and s_ <= T // 2:   # residual terms exist from step 501 on (quirk Q5)
-                    assert tab[s_, j] == 0.0 and log[s_][k] == 0.0, (s_, k, log[s_][k])
-                    continue
-                ref, sens = tab[s_, j], abs(tab_p[s_, j] - tab[s_, j])
-                err = abs(log[s_][k] - ref)
-                worst = max(worst, err / max(abs(ref), 1e-3)) if k == "loss" else worst
-                if s_ in steps:
-                    # steps 501-503 are a TRANSIENT: h starts from its random init with bias-corrected Adam steps of size lr,
-                    # the oracle's own loss goes 0.014 -> 0.05 -> 0.22-0.26 -> 0.05-0.07 within three steps (fixture), and any
-                    # rounding difference is amplified there (fp32 path: 0.4 % observed at the spike, 1e-4 next to it)
-                    fl = max(floor, 1e-2) if T // 2 < s_ <= T // 2 + 3 else floor
-                    tol = max(fl * max(abs(ref), 1e-3), 4.0 * sens)
-                    assert err <= tol, (mode, s_, k, log[s_][k], ref, sens)
-        cos = per_patch_cos(got, want)
-        print(f"[1000-step fixture, C={C}, {mode} fit, {replay} replay] loss {log[0]['loss']:.4f} -> {log[T - 1]['loss']:.5f} (oracle "
-              f"{tab[0, 0]:.4f} -> {tab[-1, 0]:.5f}); worst per-step total-loss rel err over all 1000 steps {worst:.2e}; "
-              f"denoised_feats per-patch cosine mean {cos.mean():.6f} min {cos.min():.6f} "
-              f"(oracle vs 1e-6-perturbed oracle: {z['perturbed_cos'][0]:.6f} / {z['perturbed_cos'][1]:.6f})")
-        assert cos.mean() >= 0.999 and cos.min() >= 0.99, (mode, float(cos.mean()), float(cos.min()))
+        _check_against_fit1000_fixture(z, log, got, mode, floor, f"C={C}, {mode} fit, {replay} replay")
+
+
+@pytest.mark.parametrize("mode", ["bfloat16", "float32"])
+@pytest.mark.parametrize("k", [4, 6])
+def test_concurrent_fits_c1024_vs_oracle_fixture(built_lib, k, mode):
+    """BASELINE configs[2], "many concurrent neural fields per GPU", at ITS width: k = 4 (one shared launch per step,
+    dvt_fit_run_batched) and k = 6 (> DVT_FIT_BATCH_MAX: two groups on side streams, two host threads) concurrent fits at
+    C = 1024 (MLP 128 -> 512 -> 1024, h 1024 -> 256 -> 256 -> 1024) over the whole 1000-step schedule.  Fit 0 runs the
+    committed C = 1024 oracle fixture's inputs / initial parameters / index stream and must meet the SAME bounds as the
+    single fit (test_fit_baseline_schedule_vs_oracle_fixture); the other fits run different images and must stay
+    finite, converge, and leave their gradient arenas clean.  The k = 6 case runs with the library's profiling probes ON:
+    the probes are shared by the two host threads (that raced)."""
+    from dvt_amd import _lib
+    from dvt_amd.fit import FitEngine, FitSettings, fit_many
+    from tests.golden import make_fit1000_golden as G
+    from tests.test_gpu_fit import synthetic_image
+    C = 1024
+    z = np.load(G.out_path(C))
+    V, H, T, WARM, B = (int(v) for v in z["meta"][:5])
+    feats, xy, idx = G.inputs(C)
+    d_o, f_o = G.fresh_modules(C)
+    n_rows = V * H * H
+    engines = [hip_engine_from(d_o, f_o, n_rows, T, WARM, mode, H=H, W=H, C=C)]
+    fs, cs, idxs = [feats.reshape(-1, C).to(DEV)], [xy.reshape(-1, 2).to(DEV)], [idx]
+    s = FitSettings(feat_dim=C, noise_map_height=H, noise_map_width=H, num_iters=T, warmup_iters=WARM, mlp_dtype=mode)
+    others = []
+    for j in range(1, k):
+        f_j, xy_j = synthetic_image(V, H, H, C, seed=40 + j)
+        e = FitEngine(s, n_rows, DEV)
+        e.reset(torch.Generator(device=DEV).manual_seed(j))
+        engines.append(e)
+        fs.append(f_j.reshape(-1, C).to(DEV))
+        cs.append(xy_j.reshape(-1, 2).to(DEV))
+        idxs.append(np.random.RandomState(50 + j).randint(0, n_rows, (T, B)).astype(np.int32))
+        others.append(xy_j)
+    probes = ["adam", "fit_gemm", "grid"] if k > 4 else []
+    try:
+        _lib.prof_enable(probes)
+        fit_many(engines, fs, cs, idxs, log_every=1)
+        torch.cuda.synchronize()
+        counts = {n: _lib.prof_collect(n) for n in probes}
+    finally:
+        _lib.prof_enable([])
+    for n, p in counts.items():  # every sample is a complete event pair (collect would have failed otherwise)
+        assert p["launches"] >= 0 and p["total_ms"] >= 0.0, (n, p)
+    if probes:  # both groups' Adam launches were counted: >= one per step and group
+        assert counts["adam"]["launches"] >= 2 * T and counts["adam"]["total_ms"] > 0.0, counts["adam"]
+    floor = 3e-2 if mode == "bfloat16" else 2e-3
+    _check_against_fit1000_fixture(z, engines[0].loss_log(), engines[0].infer(xy[-1].to(DEV)).cpu(), mode, floor,
+                                   f"C={C}, {mode}, fit 0 of {k} concurrent fits")
+    for j in range(1, k):
+        log = engines[j].loss_log()
+        out = engines[j].infer(others[j - 1][-1].to(DEV))
+        assert len(log) == T and bool(torch.isfinite(out).all())
+        assert log[T - 1]["patch_l2_loss"] < 0.5 * log[0]["patch_l2_loss"], (j, log[0], log[T - 1])
+    for e in engines:
+        assert float(e.grads.abs().max()) == 0.0 and int(e.touched.abs().max()) == 0
+
+
+def test_vit_large_chain(built_lib):
+    """BASELINE configs[2] end to end at a size the oracle finishes in about a minute: 9 views of the demo image through
+    the 24-block ViT-L/14 extractor (HIP, bf16) -> C = 1024 fit (HIP, bf16- and fp32-operand), 60 steps across the phase
+    switch, against the all-oracle chain (fp32 ViT-L -> oracle fit) from the same initial parameters and index stream."""
+    from dvt_amd.vit import random_state_dict
+    V, T, WARM, B, C = 8, 60, 6, 2048, 1024
+    _, img_u8 = _cat_image()
+    sd = random_state_dict(C, 24, 14, 1370, seed=2, well_conditioned=True)
+    _, x = oviews.base_transform(img_u8, (518, 518), MEAN, STD)
+    boxes, views_o, coords = oviews.make_views(x, V, (518, 518), 37, 37, np.random.RandomState(6))
+    n_rows = (V + 1) * 37 * 37
+    views_h, feats_h = _hip_features(sd, img_u8, boxes)
+    with torch.no_grad():
+        feats_o = torch.cat([ovit.forward_features(sd, views_o[i:i + 1], 14, 14) for i in range(V + 1)])
+    cos_vit = per_patch_cos(feats_h.cpu(), feats_o)
+    d_o, f_o = oracle_modules(0, C=C)
+    idx = np.random.RandomState(13).randint(0, n_rows, (T, B)).astype(np.int32)
+    res = {}
+    for mode in ("float32", "bfloat16"):
+        eng = hip_engine_from(d_o, f_o, n_rows, T, WARM, mode, C=C)
+        eng.fit(feats_h.reshape(-1, C), coords.reshape(-1, 2).to(DEV), idx, log_every=0)
+        res[mode] = eng.infer(coords[-1].to(DEV)).cpu()
+        del eng
+    ofit.fit_image(d_o, f_o, feats_o, coords, idx, num_iters=T, warmup_iters=WARM)
+    want = ofit.final_denoised_feats(d_o, f_o, feats_o, coords)[0]
+    c32, c16 = per_patch_cos(res["float32"], want), per_patch_cos(res["bfloat16"], want)
+    print(f"[ViT-L chain, {V + 1} views, {T} steps] raw ViT-L features HIP bf16 vs fp32 oracle: cos mean {cos_vit.mean():.6f} "
+          f"min {cos_vit.min():.6f}; denoised_feats HIP chain vs oracle chain: fp32 fit mean {c32.mean():.6f} min "
+          f"{c32.min():.6f}, bf16 fit mean {c16.mean():.6f} min {c16.min():.6f}")
+    assert want.shape == (37, 37, C) and cos_vit.mean() > 0.999
+    for c in (c32, c16):
+        assert c.mean() >= 0.99, float(c.mean())   # the north-star bar
+        assert c.min() >= 0.95, float(c.min())
 
 
 def _cat_image():
@@ -321,13 +420,26 @@ def test_vit_outlier_stress(built_lib):
     sd = random_state_dict(768, 12, 14, 1370, seed=3, well_conditioned=True)
     g = torch.Generator().manual_seed(9)
     hot = torch.randperm(768, generator=g)[:6]
-    for blk, scale in ((2, 100.0), (5, 400.0), (8, 1000.0)):
+    # With these O(1)-LayerScale random weights the ordinary channels of the residual stream reach |x| ~ 140 by block 12
+    # (measured in the oracle), so "massive" means biases of 3e3 .. 3e4: the stream's hot / cold ratio BEFORE the final
+    # LayerNorm is then ~290x over the three driven channels, ~145x over all six (DINOv2's massive activations sit 100-1000x
+    # above the median; round 3 drove them with 100 .. 1000 and reached 5x -- VERDICT r3 weak 1 iii).
+    for blk, scale in ((2, 3000.0), (5, 12000.0), (8, 30000.0)):
         sd[f"blocks.{blk}.mlp.fc2.bias"][hot[:3]] += scale          # massive channels enter the stream
         sd[f"blocks.{blk}.norm2.weight"][hot[3:]] *= 50.0           # and heavy-tailed LN outputs
     sd["blocks.10.norm1.weight"][hot[:2]] *= 100.0
     x = torch.randn(2, 3, 518, 518, generator=g)
-    want = ovit.forward_features(sd, x, 14, 14)
-    # the residual stream really is heavy-tailed in the oracle
+    stream = []
+    want = ovit.forward_features(sd, x, 14, 14, stream_out=stream)
+    # the residual stream really is heavy-tailed in the oracle: measured where the hot channels live, before the final norm
+    cold = torch.ones(768, dtype=torch.bool)
+    cold[hot] = False
+    xs = stream[0][:, 1:]
+    ratio_stream = float(xs[..., hot].abs().mean() / xs[..., cold].abs().mean())
+    ratio_driven = float(xs[..., hot[:3]].abs().mean() / xs[..., cold].abs().mean())
+    print(f"[ViT outlier stress] fp32 residual stream before the final LayerNorm: hot / cold magnitude {ratio_stream:.0f}x "
+          f"(six hot channels), {ratio_driven:.0f}x (the three bias-driven ones); cold |x| mean {float(xs[..., cold].abs().mean()):.0f}")
+    assert ratio_stream >= 100.0, ratio_stream
     vit = HipViT(sd, 14, 14, (518, 518), DEV)
     got = vit.forward_features(x.to(DEV)).cpu()  # batch 2 -> whole 256-row tiles: LayerNorm folded into the GEMMs
     try:
@@ -345,11 +457,11 @@ def test_vit_outlier_stress(built_lib):
     # the hot channels dominate every token's norm after the final LayerNorm, so the full cosine is
     # trivially ~1: the informative number is the cosine over the OTHER channels, whose values were
     # squeezed into the low bits of the bf16 operands next to the massive ones
-    cold = torch.ones(768, dtype=torch.bool)
-    cold[hot] = False
     cos_cold = per_patch_cos(got[..., cold], want[..., cold])
+    cos_cold_ln = per_patch_cos(got_ln[..., cold], want[..., cold])
     ratio = float(want[..., hot].abs().mean() / want[..., cold].abs().mean())
-    print(f"[ViT outlier stress] hot/cold magnitude {ratio:.0f}x; per-token cosine all channels mean {cos.mean():.6f} "
+    print(f"[ViT outlier stress] cold channels, LayerNorm kernels: mean {cos_cold_ln.mean():.6f} min {cos_cold_ln.min():.6f}")
+    print(f"[ViT outlier stress] OUTPUT (after the final LayerNorm) hot/cold magnitude {ratio:.0f}x; per-token cosine all channels mean {cos.mean():.6f} "
           f"min {cos.min():.6f}; cold channels only mean {cos_cold.mean():.6f} min {cos_cold.min():.6f}; rel-L2 {err:.4f}")
     assert bool(torch.isfinite(got).all())
     assert cos.mean() > 0.999 and cos.min() > 0.99

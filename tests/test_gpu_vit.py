@@ -251,7 +251,7 @@ def test_wrapper_api_full_depth(L):
     want = ovit.forward_features(vit._state_dict, x, 14, 14)
     cos = F.cosine_similarity(nhwc.reshape(-1, 768).cpu(), want.reshape(-1, 768), dim=-1)
     print(f"ViT-B/14 full depth vs oracle: cos mean {cos.mean():.6f} min {cos.min():.6f}")
-    assert cos.min() > 0.99
+    assert cos.min() > 0.999  # observed 0.9996 (profiles/r03/final/gpu_suite.txt)
     with pytest.raises(NotImplementedError):
         PretrainedViTWrapper("vit_base_patch16_224.mae", stride=16)
 
@@ -458,3 +458,34 @@ def test_layernorm_folded_into_gemms(L, depth, batch):
     assert torch.equal(one, folded[:1])
     three = vit.forward_features(x[:3].to(DEV), max_batch=3).cpu()
     assert torch.equal(three, folded[:3])
+
+
+def test_vit_large_full_depth(L):
+    """BASELINE configs[2] as a configuration: the DINOv2 ViT-L/14 geometry at FULL depth -- 24 blocks, dim 1024, 16
+    heads, mlp 4096, 518 x 518 (1370 tokens) -- through the wrapper's own constructor (`vit_large_patch14_dinov2.lvd142m`,
+    vit_wrapper.py:15-56), well-conditioned random weights in the timm layout, 2 views, against the fp32 oracle: the bf16
+    extractor (per-token cosine) and the fp32 extractor (rel-L2).  Round 3 held 2 of the 24 blocks against the oracle."""
+    import warnings
+
+    from dvt_amd.models import PretrainedViTWrapper
+    from dvt_amd.vit import HipViT, random_state_dict
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w = PretrainedViTWrapper("vit_large_patch14_dinov2.lvd142m", stride=14, allow_random_init=True)
+    assert (w.n_output_dims, w.num_blocks, w.last_layer_index, w.patch_size) == (1024, 24, 23, 14)
+    sd = random_state_dict(1024, 24, 14, 1370, seed=24, well_conditioned=True)
+    x = torch.randn(2, 3, 518, 518, generator=torch.Generator().manual_seed(5))
+    stream = []
+    want = ovit.forward_features(sd, x, 14, 14, stream_out=stream)
+    assert want.shape == (2, 37, 37, 1024) and bool(torch.isfinite(want).all())
+    got = HipViT(sd, 14, 14, (518, 518), DEV).forward_features(x.to(DEV)).cpu()
+    cos = F.cosine_similarity(got.reshape(-1, 1024), want.reshape(-1, 1024), dim=-1)
+    err = float((got - want).norm() / want.norm())
+    print(f"ViT-L/14 FULL depth (24 blocks) bf16 extractor vs fp32 oracle: cos mean {cos.mean():.6f} min {cos.min():.6f} "
+          f"rel-L2 {err:.4f}; residual stream |x| mean before the final norm {float(stream[0].abs().mean()):.0f}")
+    assert got.shape == want.shape and cos.min() > 0.999 and err < 3e-2
+    got32 = HipViT(sd, 14, 14, (518, 518), DEV, dtype="float32").forward_features(x.to(DEV)).cpu()
+    err32 = float((got32 - want).norm() / want.norm())
+    cos32 = F.cosine_similarity(got32.reshape(-1, 1024), want.reshape(-1, 1024), dim=-1)
+    print(f"ViT-L/14 FULL depth fp32 extractor vs fp32 oracle: rel-L2 {err32:.2e}, cos min {cos32.min():.8f}")
+    assert err32 <= 1e-5 and cos32.min() > 0.999999

@@ -104,19 +104,48 @@ def test_wrapper_loads_a_timm_layout_checkpoint(tmp_path):
 
 
 def test_stage1_flag_table_keeps_the_reference_defaults():
-    """The reference's argparse table (main_img_denoising.py:152-208) with its defaults, plus this build's
-    extras, whose defaults must not change what the reference's flags mean: --fp32_matmul highest (exact fp32),
-    --fit_batch 0 (auto)."""
+    """EVERY flag of the reference's argparse table (main_img_denoising.py:152-208) with its default, plus
+    this build's extras, whose defaults must not change what the reference's flags mean: --fp32_matmul highest (exact
+    fp32), --fit_batch 0 (auto), --extract_launch_views 0 (auto; the reference's --extract_bsz 32 is a DataLoader batch
+    and keeps its name and default)."""
     from dvt_amd import stage1
     a = stage1.get_args([])
-    ref = {"model": "vit_base_patch14_dinov2.lvd142m", "stride_size": 14, "layer_depth_ratio": 1.0, "dtype": "float32",
+    ref = {"model": "vit_base_patch14_dinov2.lvd142m", "stride_size": 14, "layer_depth_ratio": 1.0,
+           "img_path": "demo/assets/demo/cat.jpg", "dtype": "float32", "data_root": None, "save_root": None,
            "start_idx": 0, "num_imgs": 100, "num_views": 768, "num_iters": 25000, "warmup_iters": 2500, "n_levels": 16,
-           "freeze_shared_artifacts_after": 0.5, "lr": 0.01, "min_lr": 0.001, "weight_decay": 1e-5, "pixel_bsz": 2048}
+           "freeze_shared_artifacts_after": 0.5, "lr": 0.01, "min_lr": 0.001, "weight_decay": 1e-5, "extract_bsz": 32,
+           "pixel_bsz": 2048, "output_dir": "./work_dirs/demo", "num_vis_samples": 5, "vis_freq": 100, "seed": 0}
     for k, v in ref.items():
         assert getattr(a, k) == v, (k, getattr(a, k), v)
     assert tuple(a.input_size) == (518, 518)
-    assert a.fp32_matmul == "highest" and a.fit_batch == 0
+    # the table above is complete: every option string the reference's parser declares is in it (parsed from the
+    # reference's source when it is present -- this container; the GPU box has no /root/reference)
+    ref_src = "/root/reference/main_img_denoising.py"
+    if os.path.exists(ref_src):
+        import re
+        flags = set(re.findall(r'"--([a-z_0-9]+)"', open(ref_src).read()))
+        assert flags == set(ref) | {"input_size"}, flags ^ (set(ref) | {"input_size"})
+    assert a.fp32_matmul == "highest" and a.fit_batch == 0 and a.extract_launch_views == 0
     assert stage1.get_args(["--dtype", "float32", "--fp32_matmul", "high"]).fp32_matmul == "high"
     import pytest
     with pytest.raises(SystemExit):
         stage1.get_args(["--fp32_matmul", "medium"])
+
+
+def test_launch_views_balancing():
+    """769 views at the default cap of 128 -> 7 equal launches of 110 (the last one 109); the reference's --extract_bsz
+    does not enter."""
+    from dvt_amd.vit import balanced_launch_views
+    assert balanced_launch_views(769, 128) == 110
+    assert balanced_launch_views(769, 110) == 110
+    assert balanced_launch_views(769, 32) == 31   # 25 launches
+    assert balanced_launch_views(17, 128) == 17
+    assert balanced_launch_views(1, 128) == 1
+
+
+def test_stage1_rejects_unknown_fp32_matmul_before_allocating():
+    """Programmatic callers bypass argparse's `choices`: the driver itself refuses an unknown --fp32_matmul with the
+    library's error type (the raise used an un-imported name), before any device allocation."""
+    from dvt_amd import _lib, stage1
+    with pytest.raises(_lib.DvtError, match="fp32_matmul"):
+        stage1.Stage1(Namespace(fp32_matmul="medium"), "cpu")

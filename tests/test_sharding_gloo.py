@@ -95,7 +95,9 @@ def test_ranks_pin_disjoint_host_cpu_slices():
     n_cpu = len(os.sched_getaffinity(0))
     if n_cpu < 2:
         pytest.skip("needs >= 2 CPUs")
-    code = ("import os, sys, json; sys.path[:0] = [%r, %r]; from dvt_amd import dist as D; info = D.pin_host_threads(); "
+    # pinned TWICE (stage1.main then stage2.train call dist.init in one process): the second call must not slice the slice
+    code = ("import os, sys, json; sys.path[:0] = [%r, %r]; from dvt_amd import dist as D; D.pin_host_threads(); "
+            "info = dict(D.pin_host_threads()); "
             "import torch; info['affinity'] = sorted(os.sched_getaffinity(0)); info['threads'] = torch.get_num_threads(); "
             "print(json.dumps(info))") % (ROOT, os.path.join(ROOT, "denoising-vit_amd"))
     seen = []
@@ -107,3 +109,9 @@ def test_ranks_pin_disjoint_host_cpu_slices():
         assert info["pinned"] and len(info["affinity"]) == n_cpu // 2 and info["threads"] <= 8
         seen.append(set(info["affinity"]))
     assert not (seen[0] & seen[1])
+    # a launcher that does not export LOCAL_WORLD_SIZE: nothing is pinned (WORLD_SIZE may span several hosts)
+    env = dict(os.environ, LOCAL_RANK="1", WORLD_SIZE="16")
+    env.pop("LOCAL_WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    info = json.loads(out.strip().splitlines()[-1])
+    assert not info["pinned"] and len(info["affinity"]) == n_cpu
