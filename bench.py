@@ -91,7 +91,7 @@ def parse():
     p.add_argument("--save-root", default=None, help="where the timed region writes its .npy pairs (default: a "
                                                      "directory under /dev/shm, removed afterwards)")
     p.add_argument("--extract-launch-views", type=int, default=0,
-                   help="views per extractor launch (0 = at most 128, balanced: 769 views -> 7 launches of 110)")
+                   help="cap on the views per extractor launch (0 = 400: 769 views -> 398 + 371)")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="images in flight per GPU (1 = strictly serial reference flow)")
     return p.parse_args()

@@ -1578,6 +1578,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
 }
 
+#include "dvt_vit_gemm4w.inc"
+
 // W bytes kept L2-resident per N-tile group.  4800 KiB = every N tile of a K = 768 GEMM in ONE group (qkv: 9
 // tiles, fc1: 12): each 393-KB A panel is then fetched once instead of once per group (measured: GEMMs 907 ->
 // 931 TF/s in the extractor; 9600 KiB the same, 1200 KiB 900).
@@ -1600,6 +1602,7 @@ int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = softwar
 int g_vit_stagger = 0;  // dvt_tune_set(1, -400 - n): n half-microseconds per phase slot (0 off); -399: auto
 unsigned long long* g_vit_dbg = nullptr;  // dvt_vit_debug_buffer(): device buffer of the 8q timing build
 int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 8q kernel (EPI_BIAS only)
+int g_vit_w4_grid = 0;  // dvt_tune_set(1, -600 - n): workgroups of the 4w kernel (0 = auto: a whole number per CU)
 
 template <int EPI>
 int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
@@ -1618,7 +1621,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
   }
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, a.work > 0.0 ? a.work : 2.0 * a.M * a.N * a.K);
   if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK &&
-      (g_vit_gemm_variant == 0 || g_vit_gemm_variant >= 4)) {
+      (g_vit_gemm_variant == 0 || g_vit_gemm_variant >= 4)) {  // (>= 6: the 4w kernel where it applies, else 8p)
     const int nt = a.N / 256;
     // N tiles per group: W slices of a group stay L2-resident, but never fewer than 3 tiles share
     // an A panel (K = 3072: one tile per group re-read A three times from HBM, 1.03 -> 1.23 PF/s)
@@ -1630,6 +1633,32 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.mblock = g_vit_mblock > 0 ? g_vit_mblock : (g >= 6 ? 4 : 1);
     a.nt_store = g_vit_nt_store;
     const int nk = a.K / GBK;
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU) {
+      if (g_vit_gemm_variant >= 6 && a.K >= W4_MIN_K) {
+        // 4w: persistent runs of ~`tpw` tiles; the grid is a whole number of workgroups per CU
+        const int tiles = (a.M / 256) * nt;
+        const int tpw = g_vit_tpw > 0 ? g_vit_tpw : (nk <= 16 ? 3 : 1);
+        int per_cu = (tiles + 256 * tpw - 1) / (256 * tpw);
+        int nwg = 256 * (per_cu < 1 ? 1 : per_cu);
+        if (g_vit_w4_grid > 0) nwg = g_vit_w4_grid;
+        if (nwg > tiles) nwg = tiles;
+        const dim3 grid(nwg);
+        const int var = g_vit_gemm_variant - 6;  // 6: flush per tile, 7: deferred, 8: flush + fast GELU, 9: deferred + fast GELU
+        bool abl_done = false;
+        if constexpr (EPI == EPI_BIAS) {  // developer ablations (timing only, results are wrong): dvt_tune_set(1, -300 - mask)
+#define W4_ABL(n) if (g_vit_abl == n) { hipLaunchKernelGGL((gemm_bf16_kernel_4w<EPI, 1, n>), grid, dim3(256), 0, s, a); abl_done = true; }
+          W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(3) W4_ABL(5) W4_ABL(6) W4_ABL(7) W4_ABL(9) W4_ABL(14) W4_ABL(15)
+#undef W4_ABL
+        }
+        if (abl_done) {
+        } else if (var == 0) hipLaunchKernelGGL((gemm_bf16_kernel_4w<EPI, 0>), grid, dim3(256), 0, s, a);
+        else if (var == 1) hipLaunchKernelGGL((gemm_bf16_kernel_4w<EPI, 1>), grid, dim3(256), 0, s, a);
+        else if (var == 2) hipLaunchKernelGGL((gemm_bf16_kernel_4w<EPI, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_bf16_kernel_4w<EPI, 3>), grid, dim3(256), 0, s, a);
+        DVT_CHECK_LAUNCH();
+        return 0;
+      }
+    }
     if (g_vit_gemm_variant == 5 && EPI != EPI_EMBED && EPI != EPI_F32 && !IS_X3(EPI) && nk >= 4 && nk % 2 == 0) {
       // tiles per workgroup: a workgroup should not live much longer than ~50 us (the fit's kernels on the other
       // stream start where a GEMM workgroup exits): 3 tiles at K = 768 (19 us each), 1 at K = 3072
@@ -2467,6 +2496,10 @@ int dvt_vit_tune(int v) {
     g_f32x3_unfused = v == -522;
     return 0;
   }
+  if (v <= -600) {  // -600 - n: the 4w GEMM's grid forced to n workgroups (0 = auto); small problems then run multi-tile runs
+    g_vit_w4_grid = -600 - v;
+    return 0;
+  }
   if (v <= -510) {
     g_vit_attn_mask = -510 - v;
     return 0;
@@ -2496,7 +2529,7 @@ int dvt_vit_tune(int v) {
     g_vit_group_bytes = v * 1024;
     return 0;
   }
-  if (v < 0 || v > 5) return DVT_E_BADARG;
+  if (v < 0 || v > 9) return DVT_E_BADARG;
   g_vit_gemm_variant = v;
   return 0;
 }
@@ -2556,6 +2589,22 @@ extern "C" int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, v
   a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
   a.bias = b; a.out = (bf16_t*)y;
   a.lda = a.ldw = k;
+  return launch_gemm<EPI_BIAS>(a, (hipStream_t)stream);
+}
+
+// fc1-type GEMM as the extractor launches it: y (bf16) = [GELU]( rstd * (x . w'^T - mean * cs) + b' ) with the LayerNorm folded
+// (ln_stats [m] (mean, rstd), ln_cs [n]; both null: y = [GELU](x . w^T + b))
+extern "C" int dvt_vit_gemm_lnfold(const void* x, const void* w, const float* b, void* y, int m, int n, int k,
+                                   const void* ln_stats, const float* ln_cs, int gelu, void* stream) {
+  if (!x || !w || !y || (ln_stats == nullptr) != (ln_cs == nullptr)) return DVT_E_BADARG;
+  GemmBArgs a{};
+  a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.M = m; a.N = n; a.K = k;
+  a.bias = b; a.out = (bf16_t*)y;
+  a.lda = a.ldw = k;
+  a.ln_stats = (const float2*)ln_stats;
+  a.ln_cs = ln_cs;
+  if (gelu) return launch_gemm<EPI_GELU>(a, (hipStream_t)stream);
+  if (ln_stats != nullptr) return DVT_E_BADARG;  // the bias epilogue has no folded form
   return launch_gemm<EPI_BIAS>(a, (hipStream_t)stream);
 }
 

@@ -191,7 +191,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP source for gfx950 into csrc/libdvt_hip.so (hipcc cross-compiles
     without a GPU).  Rebuilds only when a source/header is newer than the library."""
     srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
-    deps = srcs + list(CSRC.glob("*.h")) + list((CSRC.parent.parent / "include").glob("*.h"))
+    deps = srcs + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list((CSRC.parent.parent / "include").glob("*.h"))
     deps = [d for d in deps if d.exists()]
     if (not force and LIB_PATH.exists()
             and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps)):

@@ -73,8 +73,9 @@ def get_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     # additions of this build
     p.add_argument("--extract_launch_views", type=int, default=0,
-                   help="views per extractor launch; 0 (default) = at most 128, balanced over equal launches (769 views "
-                        "-> 7 x 110: every GEMM runs at M = 110 * 1408 rows)")
+                   help="cap on the views per extractor launch; 0 (default) = 400: 769 views -> 398 + 371 (two launches; "
+                        "profiles/r04/r04g_*: 3 %% faster than 7 x 110, the tails of the GEMMs' tile rounds weigh less).  "
+                        "The split below the cap is tile-round aware (dvt_amd.vit.plan_launches)")
     p.add_argument("--vit_checkpoint", type=str, default=None, help="timm-layout state dict (.pth)")
     p.add_argument("--synthetic", action="store_true", help="N(0,1) views instead of image crops")
     p.add_argument("--allow_random_vit", action="store_true",
@@ -197,7 +198,7 @@ class Stage1:
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
         # views per extractor launch (NOT the reference's --extract_bsz, which is a DataLoader batch and is only accepted)
-        self.extract_launch_views = max(1, int(getattr(args, "extract_launch_views", 0) or 128))
+        self.extract_launch_views = max(1, int(getattr(args, "extract_launch_views", 0) or 400))
         # `--dtype` is the reference's one precision switch (main_img_denoising.py:173, :257): float32 = fp32
         # extractor AND fp32-operand fit (autocast off, its default); bfloat16 = both under bf16 autocast
         self.extract_dtype = ("bfloat16" if str(getattr(args, "dtype", "float32")) in
@@ -212,13 +213,10 @@ class Stage1:
         self._idx_spare = []  # index streams drawn ahead for the next fit (numpy stream order kept)
         self._idx_queue = None  # look-ahead queue while `run` is active
 
-    def vit_launch_views(self, n_views: int) -> int:
-        """Views per extractor launch for an image of `n_views` views (what `extract` will use; reported by bench.py)."""
-        from .vit import balanced_launch_views
-        cap = self.extract_launch_views
-        if self.extract_dtype == "float32":
-            cap = min(cap, 64 if self.extract_matmul == "high" else 32)
-        return balanced_launch_views(n_views, cap)
+    def vit_launch_views(self, n_views: int) -> list:
+        """Views of each extractor launch for an image of `n_views` views (what `extract` will do; reported by bench.py)."""
+        eng = self.vit._engine(self.device, self.extract_dtype, self.extract_matmul)
+        return eng.launch_plan(n_views, self.extract_launch_views)
 
     # -- single-image pieces (each enqueues on the CURRENT stream) -------------------------
     def extract(self, slot: _Slot) -> None:

@@ -46,6 +46,7 @@ _lib.register_signatures({
     "dvt_vit_struct_sizes": (_I, [C.POINTER(C.c_int64)]),
     "dvt_vit_forward": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
     "dvt_vit_gemm_bias": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dvt_vit_gemm_lnfold": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "dvt_vit_layernorm": (_I, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "dvt_vit_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dvt_vit_workspace_bytes_f32": (C.c_int64, [C.POINTER(VitConfig), _I]),
@@ -159,13 +160,56 @@ def random_state_dict(dim: int, depth: int, patch: int, n_tokens: int, seed: int
 
 
 def balanced_launch_views(n_views: int, max_batch: int) -> int:
-    """Views per extractor launch: the fewest launches of at most `max_batch` views, equally sized (769 views at 128 ->
-    7 x 110 instead of 6 x 128 + 1).  DVT_VIT_BALANCE=0: the reference's plain chunks of max_batch, for A/B timing."""
+    """Views per extractor launch, equal launches: the fewest launches of at most `max_batch` views, equally sized (769
+    views at 128 -> 7 x 110 instead of 6 x 128 + 1).  DVT_VIT_BALANCE=0: the reference's plain chunks of max_batch."""
     max_batch = max(1, int(max_batch))
-    if os.environ.get("DVT_VIT_BALANCE", "1") == "0":
+    if os.environ.get("DVT_VIT_BALANCE", "2") == "0":
         return max_batch
     n_launch = -(-n_views // max_batch)
     return -(-n_views // n_launch)
+
+
+_PLAN_CACHE: dict = {}
+
+
+def plan_launches(n_views: int, max_batch: int, s_pad: int = 1408, dim: int = 768, mlp_dim: int = 3072) -> list[int]:
+    """Views per extractor launch, TILE-ROUND aware (round 4).  Every GEMM of a launch runs (M / 256) x (N / 256) tiles of
+    256 x 256 on 256 CUs, so its time is ceil(tiles / 256) ROUNDS: 110 views = 605 M panels give the N = 768 GEMMs (proj,
+    fc2) 7.09 -> 8 rounds, 11 % of them idle, while 124 views (682 panels) give 23.98 / 31.97 / 7.99 / 7.99 rounds for qkv /
+    fc1 / proj / fc2.  The split of `n_views` into launches of at most `max_batch` views is chosen by dynamic programming
+    over a cost model in microseconds per tile round (k-loop 1.68 us per 64 k + the epilogue's 5.6 / 10.5 / 20 us: the
+    measured 8p figures) plus the per-view kernels (attention, im2col): 769 views at 128 -> 124 x 4 + 108 + 103 + 62,
+    modelled 4 % below 7 x 110.  Results do not depend on the split (tests).  DVT_VIT_BALANCE=1: equal launches (round 3),
+    0: plain chunks."""
+    max_batch = max(1, int(max_batch))
+    mode = os.environ.get("DVT_VIT_BALANCE", "2")
+    if mode != "2":
+        step = balanced_launch_views(n_views, max_batch)
+        return [min(step, n_views - b0) for b0 in range(0, n_views, step)]
+    key = (n_views, max_batch, s_pad, dim, mlp_dim)
+    if key in _PLAN_CACHE:
+        return list(_PLAN_CACHE[key])
+    kt = lambda k: 1.68 * (k / 64.0)  # noqa: E731
+    gemms = [(3 * dim // 256, kt(dim) + 5.6), (mlp_dim // 256, kt(dim) + 10.5), (dim // 256, kt(dim) + 20.0),
+             (dim // 256, kt(mlp_dim) + 10.0)]  # (N tiles, us per tile round): qkv, fc1, proj, fc2
+    per_view = 8.8 * (s_pad / 1408.0) ** 2 * (dim / 768.0)  # attention + the row-local kernels
+
+    def cost(v):
+        mt = -(-v * s_pad // 256)
+        return per_view * v + sum(-(-mt * nt // 256) * w for nt, w in gemms) + 9.0  # + launch boundaries
+
+    costs = [0.0] + [cost(v) for v in range(1, min(n_views, max_batch) + 1)]
+    best = [(0.0, ())] + [None] * n_views
+    for n in range(1, n_views + 1):
+        c_best, p_best = float("inf"), ()
+        for v in range(1, min(n, max_batch) + 1):
+            c = costs[v] + best[n - v][0]
+            if c < c_best:
+                c_best, p_best = c, best[n - v][1] + (v,)
+        best[n] = (c_best, p_best)
+    plan = sorted(best[n_views][1], reverse=True)
+    _PLAN_CACHE[key] = tuple(plan)
+    return plan
 
 
 class HipViT:
@@ -279,19 +323,23 @@ class HipViT:
             out = torch.empty((B, cfg.grid_h, cfg.grid_w, cfg.dim), device=self.device, dtype=torch.float32)
         if not out.is_contiguous() or tuple(out.shape) != (B, cfg.grid_h, cfg.grid_w, cfg.dim):
             raise _lib.DvtError("out must be a contiguous [B, grid_h, grid_w, dim] fp32 tensor")
+        # launches: see plan_launches (tile-round aware).  Results do not depend on the batching (tests/test_gpu_vit.py).
+        plan = self.launch_plan(B, max_batch)
+        ws = self._workspace(max(plan))
+        L = _lib.lib()
+        fwd = L.dvt_vit_forward_f32x3 if self.x3 else L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward
+        b0 = 0
+        for nb in plan:
+            _lib.check(fwd(C.byref(cfg), C.byref(self.weights), img[b0:].data_ptr(), out[b0:].data_ptr(), nb,
+                           n_blocks, ws.data_ptr(), _lib.stream()), "dvt_vit_forward")
+            b0 += nb
+        return out
+
+    def launch_plan(self, n_views: int, max_batch: int = 128) -> list[int]:
+        """Views of each extractor launch for `n_views` views (what forward_features will do)."""
+        cfg = self.cfg
         if self.dtype == "float32":
             # fp32 activations: 32 views keep the scratch at ~1.3 GB (bf16x3: 64 views, 4.4 GB, for fuller GEMM launches)
             max_batch = min(max_batch, 64 if self.x3 else 32)
-        # equal-sized launches: 769 views at max_batch 128 would be 6 x 128 + ONE view whose GEMMs fill 6 of 256 CUs;
-        # 7 x 110 (109) keeps every launch full (measured: within noise, 2.718 vs 2.712 images/s on one box).  Results do
-        # not depend on the batching (tests/test_gpu_vit.py).
-        max_batch = balanced_launch_views(B, max_batch)
-        ws = self._workspace(min(B, max_batch))
-        L = _lib.lib()
-        fwd = L.dvt_vit_forward_f32x3 if self.x3 else L.dvt_vit_forward_f32 if self.dtype == "float32" else L.dvt_vit_forward
-        for b0 in range(0, B, max_batch):
-            nb = min(max_batch, B - b0)
-            _lib.check(fwd(C.byref(cfg), C.byref(self.weights), img[b0:].data_ptr(), out[b0:].data_ptr(), nb,
-                           n_blocks, ws.data_ptr(), _lib.stream()), "dvt_vit_forward")
-        return out
+        return plan_launches(n_views, max_batch, cfg.s_pad, cfg.dim, cfg.mlp_dim)
 

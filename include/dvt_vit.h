@@ -140,6 +140,11 @@ int dvt_vit_attention_f32(const float* qkv, float* out, int batch, int heads, in
 /* y[m, n] (bf16) = x[m, k] (bf16) . w[n, k]^T (bf16) + b[n]; m % 128 == n % 128 == k % 64 == 0 */
 int dvt_vit_gemm_bias(const void* x, const void* w, const float* b, void* y, int m, int n, int k,
                       void* stream);
+/* the fc1 GEMM as the extractor launches it: y[m, n] (bf16) = GELU(rstd[m] * (x[m, :] . w'[n, :] - mean[m] * cs[n]) + b'[n]),
+ * LayerNorm folded into the weights (ln_stats [m] float2 (mean, rstd), ln_cs [n]; both NULL: plain x . w^T + b);
+ * gelu = 0 (and no fold): the bias epilogue.  m % 256 == n % 256 == k % 64 == 0 for the folded form. */
+int dvt_vit_gemm_lnfold(const void* x, const void* w, const float* b, void* y, int m, int n, int k,
+                        const void* ln_stats, const float* ln_cs, int gelu, void* stream);
 /* x[m, n] (fp32, in place) += gamma[n] * (a[m, k] (bf16) . w[n, k]^T (bf16) + b[n]): the attention-proj /
  * fc2 GEMM with the LayerScale + residual epilogue (timm Block.forward: x = x + ls(f(norm(x)))) */
 int dvt_vit_gemm_residual(const void* a, const void* w, const float* b, const float* gamma, float* x,

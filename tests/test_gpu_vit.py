@@ -88,9 +88,10 @@ def test_gemm_residual_vs_torch(L, m, n, k, variant):
     assert float(err.max()) < 2e-3 * float(want.abs().max()), (variant, (m, n, k), float(err.max()))
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7])
 def test_gemm_bias_variants(L, variant):
-    """the non-default GEMM schedules against torch on the four ViT-B shapes (one M panel pair each)"""
+    """the non-default GEMM schedules against torch on the four ViT-B shapes (one M panel pair each); 6 / 7: the 4-wave
+    persistent kernel (csrc/dvt_vit_gemm4w.inc; flush per tile / deferred epilogue) where K >= 640, else 8p"""
     for n, k in [(2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 640)]:
         torch.manual_seed(n + k)
         m = 512
@@ -489,3 +490,48 @@ def test_vit_large_full_depth(L):
     cos32 = F.cosine_similarity(got32.reshape(-1, 1024), want.reshape(-1, 1024), dim=-1)
     print(f"ViT-L/14 FULL depth fp32 extractor vs fp32 oracle: rel-L2 {err32:.2e}, cos min {cos32.min():.8f}")
     assert err32 <= 1e-5 and cos32.min() > 0.999999
+
+
+@pytest.mark.parametrize("variant,grid", [(4, 0), (6, 0), (7, 0), (7, 1), (7, 3), (7, 5), (9, 2)])
+@pytest.mark.parametrize("m,n,k,gelu,fold", [(2048, 1024, 768, 1, 1), (1280, 3072, 768, 1, 1), (1536, 2304, 768, 0, 0),
+                                             (1024, 512, 1024, 0, 0), (768, 768, 3072, 0, 0)])
+def test_gemm_4w_persistent_vs_fp64(L, m, n, k, gelu, fold, variant, grid):
+    """The 4-wave persistent GEMM with the deferred epilogue (dvt_tune_set(1, 6 .. 9), csrc/dvt_vit_gemm4w.inc) through the
+    fc1-type entry point dvt_vit_gemm_lnfold -- folded LayerNorm + GELU, or the bias epilogue -- against fp64, next to the
+    default 8p kernel (variant 4) on the same operands.  `grid` forces the number of workgroups (dvt_tune_set(1, -600 - n)),
+    so that a workgroup runs SEVERAL tiles: the parked tile drains under the next tile's k-loop, the ring runs through the
+    tile boundary, the last tile is flushed after the loop.  Every element is compared; a second launch must reproduce the
+    first bit for bit (the kernel has no atomics and no data-dependent order).  Variant 9 uses the opt-in cheaper GELU
+    (2.7e-4 max abs deviation from erf-GELU before the bf16 rounding): looser bound."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    x = (torch.rand(m, k, device=DEV, generator=g) * 2 - 1 +
+         torch.linspace(-1, 1, k, device=DEV)[None, :] * torch.linspace(0.5, 2, m, device=DEV)[:, None]).bfloat16()
+    w = ((torch.rand(n, k, device=DEV, generator=g) * 2 - 1) / k ** 0.5 * 1.7 +
+         torch.linspace(-0.02, 0.03, n, device=DEV)[:, None]).bfloat16()
+    b = torch.randn(n, device=DEV, generator=g)
+    stats = cs = None
+    acc = x.double() @ w.double().t()
+    if fold:
+        stats = torch.stack([torch.randn(m, device=DEV, generator=g) * 0.3, torch.rand(m, device=DEV, generator=g) + 0.5], 1).contiguous()
+        cs = w.float().sum(1).contiguous()
+        acc = stats[:, 1:2].double() * (acc - stats[:, 0:1].double() * cs.double()[None, :])
+    want = acc + b.double()
+    if gelu:
+        want = F.gelu(want.float().bfloat16().double())  # the reference's autocast semantics: GELU of the bf16 linear output
+    outs = []
+    try:
+        assert L.dvt_tune_set(1, variant) == 0 and L.dvt_tune_set(1, -600 - grid) == 0
+        for _ in range(2):
+            y = torch.full((m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
+            assert L.dvt_vit_gemm_lnfold(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k,
+                                         stats.data_ptr() if fold else None, cs.data_ptr() if fold else None, gelu, _s()) == 0
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        L.dvt_tune_set(1, GEMM_DEFAULT)
+        L.dvt_tune_set(1, -600)
+    y = outs[0]
+    assert bool(torch.isfinite(y.float()).all())
+    err = float((y.double() - want).abs().max() / want.abs().max())
+    assert err < (8e-3 if variant >= 8 else 6e-3), (variant, grid, (m, n, k), err)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))

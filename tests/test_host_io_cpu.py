@@ -132,15 +132,27 @@ def test_stage1_flag_table_keeps_the_reference_defaults():
         stage1.get_args(["--fp32_matmul", "medium"])
 
 
-def test_launch_views_balancing():
-    """769 views at the default cap of 128 -> 7 equal launches of 110 (the last one 109); the reference's --extract_bsz
-    does not enter."""
-    from dvt_amd.vit import balanced_launch_views
-    assert balanced_launch_views(769, 128) == 110
-    assert balanced_launch_views(769, 110) == 110
-    assert balanced_launch_views(769, 32) == 31   # 25 launches
-    assert balanced_launch_views(17, 128) == 17
-    assert balanced_launch_views(1, 128) == 1
+def test_launch_views_planning():
+    """Views per extractor launch.  Round 3: 769 views at the cap of 128 -> 7 equal launches of 110 (109).  Round 4: the
+    split is tile-round aware -- 605 M panels (110 views) give the N = 768 GEMMs 7.09 -> 8 rounds of 256 tiles, 682 panels
+    (124 views) 7.99 -- and chosen by a small dynamic program; the reference's --extract_bsz does not enter."""
+    from dvt_amd.vit import balanced_launch_views, plan_launches
+    assert balanced_launch_views(769, 128) == 110 and balanced_launch_views(769, 32) == 31 and balanced_launch_views(1, 128) == 1
+    plan = plan_launches(769, 128)
+    assert sum(plan) == 769 and max(plan) <= 128 and plan == sorted(plan, reverse=True)
+    assert plan[0] == 124, plan   # 682 M panels: 23.98 / 31.97 / 7.99 / 7.99 rounds for qkv / fc1 / proj / fc2
+
+    def rounds(v, nt):
+        return -(-(-(-v * 1408 // 256)) * nt // 256)
+    for nt in (9, 12, 3):  # never more tile rounds than the equal split
+        assert sum(rounds(v, nt) for v in plan) <= 6 * rounds(110, nt) + rounds(109, nt), (nt, plan)
+    assert plan_launches(17, 128) == [17] and plan_launches(1, 128) == [1]
+    assert sum(plan_launches(769, 32)) == 769 and max(plan_launches(769, 32)) <= 32
+    os.environ["DVT_VIT_BALANCE"] = "1"
+    try:
+        assert plan_launches(769, 128) == [110] * 6 + [109]
+    finally:
+        del os.environ["DVT_VIT_BALANCE"]
 
 
 def test_stage1_rejects_unknown_fp32_matmul_before_allocating():
