@@ -307,6 +307,20 @@ __global__ __launch_bounds__(256) void adam_dense_lazy_kernel(AdamKArgs a, AdamP
   const int b = (int)blockIdx.x;
   adam_lazy_body<false, EXACT>(z, b % lazy_bx, b / lazy_bx, blockIdx.y, tab_ns, tab_ib);
 }
+// ... and with the dense blocks gathering the gradient of G from the row lists (the fp32-operand step of round 4: no fused
+// weight-gradient launch writes dG there)
+template <bool EXACT>
+__global__ __launch_bounds__(256) void adam_dense_lazy_gather_kernel(AdamKArgs a, AdamPtrs q, LazyArgs z, int dense_blocks,
+                                                                     int lazy_bx, AdamGather gr) {
+  __shared__ float tab_ns[LAZY_TAB], tab_ib[LAZY_TAB];
+  const int lazy_blocks = (int)gridDim.x - dense_blocks;
+  if ((int)blockIdx.x >= lazy_blocks) {
+    adam_dense_body<true>(a, q, gr, (int)blockIdx.x - lazy_blocks, dense_blocks, blockIdx.y);
+    return;
+  }
+  const int b = (int)blockIdx.x;
+  adam_lazy_body<false, EXACT>(z, b % lazy_bx, b / lazy_bx, blockIdx.y, tab_ns, tab_ib);
+}
 template <bool EXACT>
 __global__ __launch_bounds__(256) void adam_dense_lazy_shadow_kernel(AdamKArgs a, AdamPtrs q, LazyArgs z, int dense_blocks,
                                                                      int lazy_bx, AdamShadow shw) {
@@ -406,7 +420,19 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
   if (blocks > 256 * 16) blocks = 256 * 16;
   {
     DvtProbeScope probe(DVT_PROBE_ADAM, stream, work * k);
-    if (lazy_next != nullptr && gr.q_end <= gr.q_begin) {  // + the catch-up of the next step's entries, same launch
+    if (lazy_next != nullptr && gr.q_end > gr.q_begin) {  // catch-up of the next step's entries + the G row gather
+      if (shadow_L != nullptr && shadow != nullptr) return DVT_E_BADARG;  // (the fused step never gathers)
+      LazyArgs z{};
+      const int rc = make_lazy_args(lazy_next, k, false, lazy_target, lazy_ukeys, lazy_ucount, &z);
+      if (rc) return rc;
+      const int lazy_bx = dvt_cdiv((long long)lazy_next->nt * 4, LAZY_BLOCK);
+      const unsigned total = (unsigned)blocks + (unsigned)(lazy_bx * (lazy_next->n_levels - lazy_next->l0));
+      const dim3 grid(total, k), blk(256);
+      if (lazy_next->exact)
+        hipLaunchKernelGGL((adam_dense_lazy_gather_kernel<true>), grid, blk, 0, stream, a, q, z, (int)blocks, lazy_bx, gr);
+      else
+        hipLaunchKernelGGL((adam_dense_lazy_gather_kernel<false>), grid, blk, 0, stream, a, q, z, (int)blocks, lazy_bx, gr);
+    } else if (lazy_next != nullptr) {  // + the catch-up of the next step's entries, same launch
       LazyArgs z{};
       const int rc = make_lazy_args(lazy_next, k, false, lazy_target, lazy_ukeys, lazy_ucount, &z);
       if (rc) return rc;

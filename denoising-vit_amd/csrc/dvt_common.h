@@ -69,7 +69,7 @@ int dvt_fit_prep_k(const DvtGridTable* tbl, int k, const float* const* xy, const
                    float* const* raw, int n, int c, hipStream_t stream);
 int dvt_grid_bwd_k(const DvtGridTable* tbl, int k, const float* const* xy, const int32_t* const* ridx,
                    const float* const* d_enc, float* const* d_params, uint32_t* const* touched, int n,
-                   hipStream_t stream);
+                   hipStream_t stream, uint32_t bitmap_end = 0u);
 int dvt_loss_launch_k(int k, const float* const* F, const float* const* G, const int32_t* const* g_idx,
                       int lattice, const float* const* Hres, const float* const* raw_rows,
                       float* const* d_pred, float* const* d_hres, float* const* d_G,

@@ -57,6 +57,12 @@ bool row_lists_ok(const DvtFitConfig* c) { return c->lattice <= 8192 && c->batch
 
 // Grid entries [e0, n_entries_total) are stepped lazily: everything from the first level with >= 64 k entries on
 // (a step touches <= 4 * batch = 8 k of them), e0 rounded up to a whole `touched` word / Adam chunk.
+// sorted lists / lazy Adam are available where their buffers were carved (dvt_fit_fused_shapes_ok), in both operand
+// precisions; dvt_tune_set(6, 0) (fused step off) leaves them to the bf16 layer-by-layer A/B as before
+bool g_fit_fused_enable_lists(const DvtFitConfig* c) {
+  return dvt_fit_fused_shapes_ok(c) && (!c->mlp_bf16 || dvt_fit_fused_ok(c));
+}
+
 bool lazy_range(const DvtFitConfig* c, uint32_t* e0, int* l0) {
   if (c->num_iters > 65535) return false;  // 16-bit step counters
   for (int l = 0; l < c->grid.n_levels; ++l)
@@ -372,7 +378,26 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
   {
     float* dgrid[KM];
     at(Gd, c->off_grid, dgrid);
-    DVT_TRY(dvt_grid_bwd_k(&c->grid, k, xy, ridx, denc, dgrid, touched, B, s));
+    bool lists = gs_local >= 0;
+    for (int f = 0; f < k; ++f) lists = lists && ws[f].gs_keys != nullptr;
+    if (lists) {
+      // this step's sorted (entry, sample, corner) lists exist (round 4: also with fp32 operands -- they depend on the
+      // coordinates and the index stream only): gather, deterministic sums, plain stores; entries from lazy_e0 on belong
+      // to the lazy Adam kernels and get no `touched` bit
+      const uint32_t* gk[KM];
+      const uint16_t* gp[KM];
+      const float* gw[KM];
+      const size_t gso = (size_t)gs_local * c->grid.n_levels * 4 * B;
+      for (int f = 0; f < k; ++f) {
+        gk[f] = ws[f].gs_keys + gso;
+        gp[f] = ws[f].gs_pay + gso;
+        gw[f] = ws[f].gs_w + gso;
+      }
+      DVT_TRY(dvt_grid_gather_k(&c->grid, k, gk, gp, gw, B, lazy_e0, denc, dgrid, touched, s));
+    } else {
+      DVT_TRY(dvt_grid_bwd_k(&c->grid, k, xy, ridx, denc, dgrid, touched, B, s,
+                             lazy_e0 != 0xffffffffu ? lazy_e0 : 0u));
+    }
   }
   if (use_res) {
     n_ops = 0;
@@ -490,8 +515,11 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
     rc = dvt_shadow_build_k(&L, k, pp, ss, 0, c->arena_floats, (hipStream_t)stream);
     if (rc) return rc;
   }
-  const bool sorted_lists = dvt_fit_fused_ok(c) && w[0].shadow != nullptr && w[0].g_offs != nullptr &&
-                            w[0].gs_keys != nullptr && g_fit_sorted_grid;
+  // Sorted grid lists and the lazy Adam depend on the coordinates and the index stream only, not on the operand
+  // precision of the MLP: since round 4 the fp32-operand step (the reference's default --dtype float32) uses them too --
+  // gather instead of atomics for the grid gradient, and the IEEE replay (bit-identical to the dense sweep) for the
+  // fine grid levels instead of streaming 515 MB per step.
+  const bool sorted_lists = g_fit_fused_enable_lists(c) && w[0].g_offs != nullptr && w[0].gs_keys != nullptr && g_fit_sorted_grid;
   uint32_t lazy_e0 = 0xffffffffu;
   int lazy_l0 = 0;
   DvtAdamLazy lz{};
@@ -512,7 +540,7 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
     lz.neg_step = w[0].lazy_ns;
     lz.inv_bc2s = w[0].lazy_ib;
     lz.bc2s = w[0].lazy_bc;
-    lz.exact = g_fit_lazy_exact;
+    lz.exact = g_fit_lazy_exact || !c->mlp_bf16;  // fp32 operands: the reference's arithmetic, to the bit
     int rc = dvt_adam_lazy_tables(bufs[0]->h_lr, step_begin, step_end, c->beta1, c->beta2, w[0].lazy_ns, w[0].lazy_ib,
                                   w[0].lazy_bc, (hipStream_t)stream);
     if (rc) return rc;

@@ -280,6 +280,44 @@ int dvt_grid_sort_k(const DvtGridTable* T, int k, const float* const* xy, const 
   return 0;
 }
 
+namespace {
+struct GridGatherArgs {
+  DvtGridTable T;
+  GridSortedPtrs gs;
+  const float* d_enc[DVT_FIT_BATCH_MAX];
+  float* d_params[DVT_FIT_BATCH_MAX];
+  uint32_t* touched[DVT_FIT_BATCH_MAX];
+};
+__global__ __launch_bounds__(1024) void grid_gather_kernel(GridGatherArgs a) {
+  const int parts = a.gs.nt >> 10, bx = blockIdx.x, fy = blockIdx.y;
+  grid_gather_body(a.T, a.gs, fy, bx / parts, bx % parts, a.d_enc[fy], a.d_params[fy], a.touched[fy]);
+}
+}  // namespace
+
+int dvt_grid_gather_k(const DvtGridTable* T, int k, const uint32_t* const* keys, const uint16_t* const* pay,
+                      const float* const* w, int n, uint32_t bitmap_end, const float* const* d_enc, float* const* d_params,
+                      uint32_t* const* touched, hipStream_t s) {
+  if (!dvt_grid_sorted_ok(T, n) || k < 1 || k > DVT_FIT_BATCH_MAX) return DVT_E_BADARG;
+  GridGatherArgs a{};
+  a.T = *T;
+  a.gs.nt = 4 * n;
+  a.gs.bitmap_end = bitmap_end;
+  for (int f = 0; f < k; ++f) {
+    if (!keys[f] || !pay[f] || !w[f] || !d_enc[f] || !d_params[f]) return DVT_E_BADARG;
+    a.gs.keys[f] = keys[f];
+    a.gs.pay[f] = pay[f];
+    a.gs.w[f] = w[f];
+    a.d_enc[f] = d_enc[f];
+    a.d_params[f] = d_params[f];
+    a.touched[f] = touched ? touched[f] : nullptr;
+  }
+  // algorithmic bytes: the lists (10 B per pair) + 32 B of d_enc per pair + one 32-B store per distinct entry (<= pairs)
+  DvtProbeScope probe(DVT_PROBE_GRID, s, (double)k * T->n_levels * a.gs.nt * (10 + 32 + 32));
+  hipLaunchKernelGGL(grid_gather_kernel, dim3(T->n_levels * (a.gs.nt >> 10), k), dim3(1024), 0, s, a);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
 void dvt_grid_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan) {
   plan->n_lds_blocks = 0;
   int l = 0;
@@ -353,9 +391,10 @@ int dvt_grid_bwd_idx(const DvtGridTable* tbl, const float* xy, const int32_t* ri
 
 int dvt_grid_bwd_k(const DvtGridTable* tbl, int k, const float* const* xy, const int32_t* const* ridx,
                    const float* const* d_enc, float* const* d_params, uint32_t* const* touched, int n,
-                   hipStream_t stream) {
+                   hipStream_t stream, uint32_t bitmap_end) {
   if (!tbl || k < 1 || k > DVT_FIT_BATCH_MAX || n < 0 || tbl->n_features != 8) return DVT_E_BADARG;
   GridBwdPtrs q{};
+  q.bitmap_end = bitmap_end;
   for (int f = 0; f < k; ++f) {
     if (!xy[f] || !d_enc[f] || !d_params[f]) return DVT_E_BADARG;
     q.xy[f] = (const float2*)xy[f];

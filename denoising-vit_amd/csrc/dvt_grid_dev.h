@@ -43,6 +43,7 @@ struct GridBwdPtrs {  // per fit of a batched launch
   const float* d_enc[DVT_FIT_BATCH_MAX];
   float* d_params[DVT_FIT_BATCH_MAX];
   uint32_t* touched[DVT_FIT_BATCH_MAX];
+  uint32_t bitmap_end;  // entries >= this get no `touched` bit (the lazy Adam kernels own them); 0 = no limit
 };
 
 // Body of the grid backward for workgroup `bx` of fit `fy` (1024 threads); `acc` / `flags` are the caller's
@@ -143,7 +144,7 @@ __device__ __forceinline__ void grid_bwd_body(const DvtGridTable& T, const GridB
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     atomic_add_f32(d_params + (size_t)idx[c] * 8 + f, w[c] * g);
-    if (touched != nullptr && f == 0) {
+    if (touched != nullptr && f == 0 && (q.bitmap_end == 0u || idx[c] < q.bitmap_end)) {
       const uint32_t bit = 1u << (idx[c] & 31u);
       uint32_t* wp = touched + (idx[c] >> 5);
       if ((__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0u)
@@ -220,6 +221,11 @@ bool dvt_grid_sorted_ok(const DvtGridTable* T, int n);
 int dvt_grid_sort_k(const DvtGridTable* T, int k, const float* const* xy, const int32_t* const* ridx, int n, int steps,
                     uint32_t* const* keys, uint16_t* const* pay, float* const* w, hipStream_t s,
                     uint32_t* const* ukeys = nullptr, int32_t* const* ucount = nullptr);
+// the gather-style grid backward as its own launch (the fp32-operand fit step; the fused step runs the same body inside
+// fit_backward_kernel): d_params[entry] = sum over this step's sorted (sample, corner) pairs; keys / pay / w = this step's lists
+int dvt_grid_gather_k(const DvtGridTable* T, int k, const uint32_t* const* keys, const uint16_t* const* pay,
+                      const float* const* w, int n, uint32_t bitmap_end, const float* const* d_enc, float* const* d_params,
+                      uint32_t* const* touched, hipStream_t s);
 
 void dvt_grid_bwd_plan(const DvtGridTable& T, int n, GridBwdPlan* plan);
 extern int g_grid_lds_chunk;
