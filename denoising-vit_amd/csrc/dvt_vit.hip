@@ -91,9 +91,6 @@ struct GemmBArgs {
   int n_prefix, pos_has_cls;  // EPI_EMBED: prefix rows; pos_embed row 0 belongs to cls (else patches only)
   int group;          // N tiles per L2-resident group (set by launch_gemm)
   int mblock;         // M panels per block of the tile order (1: n fastest)
-  int tpw;            // 8q kernel: consecutive tiles of the order per workgroup
-  int stagger;        // 8q kernel: first-round workgroups start (bid / 8 % 8) * stagger half-microseconds late
-  unsigned long long* dbg;  // 8q timing build (ABL = 64): [tiles][8 waves][4] cycles: k-loop, epilogue issue, store drain, start stamp
   int nt_store;       // bf16 outputs with the non-temporal hint
   // LayerNorm folded into the GEMMs (see ln_fold): consumer side (EPI_QKV / EPI_GELU) ...
   const float2* ln_stats;  // [M] (mean, rstd) of the fp32 residual rows; A is then bf16(x), W is bf16(gamma (.) W)
@@ -1092,319 +1089,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
 }
 
-// ---- 256x256x64, 8-phase ring, "8q": register epilogue + several tiles per workgroup ---------
-// Round 3.  Two measured costs of the 8p kernel sit outside its k-loop: at K = 768 a tile takes 25.9 us
-// of which 6.9 us are FIXED (prologue latency, drain, LDS round trip of the epilogue), and
-// the epilogue's parameter loads are serialised behind `s_waitcnt vmcnt(0)` one after the other.
-//   (1) Swapped MFMA operands.  acc = mfma(W fragment, A fragment) leaves C^T in the accumulators: a lane
-//       holds ONE output row (token lc of the 16-row block) and 4 consecutive columns per 16-column block.
-//       The W rows of a wave's 32-row half-tile block are permuted at the DMA SOURCE (LDS row 16 jj + lc
-//       holds W row 8 (lc >> 2) + 4 jj + (lc & 3)), so the two 16-column blocks of a half give each lane 8
-//       CONSECUTIVE columns: 16-B bf16 stores / 2 x float4 fp32 accesses straight from registers, no LDS
-//       round trip (64 ds_write_b32 + 32 ds_read_b128 per wave and tile in 8p), no barrier before it.
-//       V tiles of the qkv GEMM keep the un-swapped order (their store is token-contiguous, vt[b][h][d][s]).
-//   (2) Tile loop with the ring running THROUGH the tile boundary.  The LDS ring is free again as soon as
-//       the last phase has read it (the epilogue does not need LDS any more), so the last two k-tiles of
-//       tile i issue the first six half-tiles of tile i+1 in exactly the steady-state order; the next tile
-//       starts in steady state.  Operand staging goes through buffer descriptors (`buffer_load ... lds`):
-//       the per-lane part of a source address is 4 VGPRs for the whole kernel and a tile switch is SGPR-only.
-//       vmcnt is in issue order over loads AND stores on gfx9, so the first k-tile after an epilogue waits
-//       with `vmcnt(8 + S)`, S = a LOWER bound of the store instructions the epilogue issued after the DMAs.
-//   Workgroups keep living ~2-3 tiles (K = 768), not the whole launch: the fit's kernels on the other stream
-//   start only where a GEMM workgroup exits.
-template <int EPI>
-struct P8QStores {  // lower bound of VMEM store instructions per wave in the epilogue
-  static constexpr int n = (EPI == EPI_RESID) ? 24 : 16;
-};
-
-template <int N>
-__device__ __forceinline__ void wait_vm_q() {
-  static_assert(N <= 63, "vmcnt has 6 bits");
-  if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
+// (Round 3's "8q" kernel -- the 8p ring with a register epilogue and a tile loop -- lived here; it never beat 8p
+// (profiles/r03/r03a..g_gemm8q_*, profiles/LOG.md 5 finding 3) and round 4's 4-wave kernel below is the persistent variant
+// that is kept: same idea, deferred epilogue, same speed.  Removed in round 4.)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-struct QSrc {  // one tile's operands: descriptors based at its first A / W row
-  __amdgpu_buffer_rsrc_t a, b;
-};
-
-// one k-tile = 4 phases.  STG: 0 steady (this tile's k-tiles t+1, t+2); 1 / 2 the last two k-tiles of the
-// workgroup's LAST tile (nothing left to stage); 3 / 4 the last two k-tiles when another tile follows (stage the
-// next tile's k-tiles 0 and 1 where the steady state would stage t+1 / t+2).
-template <bool SWAP, int STG, int W1, int W2, int W4, int ABL = 0>
-__device__ __forceinline__ void q_ktile(f32x4 (&acc)[8][4], char* smem, char* ldsw, const QSrc& cur, const QSrc& nxt,
-                                        int t, int nk, const int (&voA)[2], const int (&voB)[2], int hA, int hB,
-                                        int oa0, int oa1, int ob0, int ob1) {
-  constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
-  const int bo_ = (t & 1) * BUF, bn_ = bo_ ^ BUF;
-  const char* base_ = smem + bo_;
-  // k-tile index (inside its tile) staged by P1/P2 and by P3/P4
-  const int k1 = (STG == 4) ? 0 : t + 1;
-  const int k2 = (STG == 3) ? 0 : (STG == 4) ? 1 : t + 2;
-  const QSrc& s1 = (STG == 4) ? nxt : cur;
-  const QSrc& s2 = (STG >= 3) ? nxt : cur;
-  constexpr bool ST12 = (STG == 0 || STG == 1 || STG == 3 || STG == 4);
-  constexpr bool ST34 = (STG == 0 || STG == 3 || STG == 4);
-  bf16x8 a[4][2], b0[2][2], b1[2][2];
-#define Q_RD(p_, off) ((ABL & 2) ? (bf16x8){(short)ob0, (short)oa0, (short)ob1, (short)oa1, 1, 2, 3, 4} : *reinterpret_cast<const bf16x8*>((p_) + (off)))
-#define Q_STAGE(RS, VO, soff, off)                                                                               \
-  do {                                                                                                           \
-    if constexpr (!(ABL & 4)) {                                                                                  \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, VO[0], soff, 0, 0);              \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, VO[1], soff, 0, 0);       \
-    }                                                                                                            \
-  } while (0)
-#define Q_BAR2() do { if constexpr (!(ABL & 16)) P8_BAR(); } while (0)
-#define Q_BAR1() do { if constexpr (!(ABL & 32)) P8_BAR(); } while (0)
-#define Q_MFMA(IB, JB, AF, BF)                                                                       \
-  do {                                                                                               \
-    if constexpr (ABL & 1) {                                                                         \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(AF[i][ks]));            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(BF[j][ks]));            \
-      }                                                                                              \
-      break;                                                                                         \
-    }                                                                                                \
-    __builtin_amdgcn_s_setprio(1);                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
-        acc[IB + i][JB + j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], AF[i][ks],   \
-                                                                             acc[IB + i][JB + j], 0, 0, 0) \
-                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][ks], BF[j][ks],   \
-                                                                             acc[IB + i][JB + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                   \
-  } while (0)
-  /* P1 */
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    b0[j][0] = Q_RD(base_ + OFF_B0 + j * 2048, ob0);
-    b0[j][1] = Q_RD(base_ + OFF_B0 + j * 2048, ob1);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a[i][0] = Q_RD(base_ + OFF_A0 + i * 2048, oa0);
-    a[i][1] = Q_RD(base_ + OFF_A0 + i * 2048, oa1);
-  }
-  if constexpr (ST12) Q_STAGE(s1.b, voB, hB + k1 * 128, bn_ + OFF_B1);
-  wait_vm_q<W1>();
-  Q_BAR1();
-  P8_LGKM0();
-  Q_MFMA(0, 0, a, b0);
-  Q_BAR2();
-  /* P2 */
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    b1[j][0] = Q_RD(base_ + OFF_B1 + j * 2048, ob0);
-    b1[j][1] = Q_RD(base_ + OFF_B1 + j * 2048, ob1);
-  }
-  if constexpr (ST12) Q_STAGE(s1.a, voA, hA + k1 * 128, bn_ + OFF_A1);
-  wait_vm_q<W2>();
-  Q_BAR1();
-  P8_LGKM0();
-  Q_MFMA(0, 2, a, b1);
-  Q_BAR2();
-  /* P3 */
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a[i][0] = Q_RD(base_ + OFF_A1 + i * 2048, oa0);
-    a[i][1] = Q_RD(base_ + OFF_A1 + i * 2048, oa1);
-  }
-  if constexpr (ST34) Q_STAGE(s2.a, voA, k2 * 128, bo_ + OFF_A0);
-  Q_BAR1();
-  P8_LGKM0();
-  Q_MFMA(4, 2, a, b1);
-  Q_BAR2();
-  /* P4 */
-  if constexpr (ST34) Q_STAGE(s2.b, voB, k2 * 128, bo_ + OFF_B0);
-  wait_vm_q<W4>();
-  Q_BAR1();
-  Q_MFMA(4, 0, a, b0);
-  Q_BAR2();
-#undef Q_RD
-#undef Q_STAGE
-#undef Q_MFMA
-#undef Q_BAR1
-#undef Q_BAR2
-}
-
-// What an epilogue needs of the launch arguments.  Read from the kernarg segment (scalar loads) per tile, behind an
-// opaque copy of the segment pointer, instead of living in ~40 SGPRs across the k-loop (the 8q kernel sat at the
-// 102-SGPR limit and spilled scalars into VGPR lanes inside the loop).
-struct EpiArgs {
-  const float* bias;
-  bf16_t* out;
-  bf16_t* vt;
-  float* x;
-  const float* gamma;
-  const float2* ln_stats;
-  const float* ln_cs;
-  bf16_t* xb;
-  float2* st_part;
-  int M, N, dim, heads, s_pad, nt_store;
-};
 typedef const __attribute__((address_space(4))) GemmBArgs* kernarg_ptr_t;
-__device__ __forceinline__ EpiArgs load_epi_args(kernarg_ptr_t k) {
-  EpiArgs e;
-  e.bias = k->bias; e.out = k->out; e.vt = k->vt; e.x = k->x; e.gamma = k->gamma;
-  e.ln_stats = k->ln_stats; e.ln_cs = k->ln_cs; e.xb = k->xb; e.st_part = k->st_part;
-  e.M = k->M; e.N = k->N; e.dim = k->dim; e.heads = k->heads; e.s_pad = k->s_pad; e.nt_store = k->nt_store;
-  return e;
-}
 
-// columns of a lane inside its wave's 64-column block under the W-row permutation:
-//   swapped:    acc[i][j][r] = C[16 i + lc][32 (j >> 1) + 8 g + 4 (j & 1) + r]
-//   un-swapped: acc[i][j][r] = C[16 i + 4 g + r][32 (j >> 1) + 8 (lc >> 2) + 4 (j & 1) + (lc & 3)]
-template <int EPI>
-__device__ __forceinline__ void q_epilogue_swapped(const EpiArgs& p, f32x4 (&acc)[8][4], int mb, int nb, int lane) {
-  const int g = lane >> 4, lc = lane & 15;
-  if constexpr (EPI == EPI_RESID) {
-    // x[m, n] += gamma[n] * (acc + bias[n]); fp32 read-modify-write, 32 B per lane and row.  Buffer addressing as in
-    // gemm_epilogue_resid_sq (one descriptor at the block, 32-bit lane offset); the row offset of a STORE goes into
-    // the VGPR offset (see RS_ST there: an SGPR soffset on a 128-bit buffer store lost a hazard wait state on gfx950).
-    const __amdgpu_buffer_rsrc_t xr =
-        __builtin_amdgcn_make_buffer_rsrc(p.x + (size_t)mb * p.N + nb, 0, 0x7fffffff, 0x00020000);
-    typedef int i32x4_t __attribute__((ext_vector_type(4)));
-    const int loff = (lc * p.N + 8 * g) * 4;
-    const int rstep = p.N * 64;  // bytes per 16 rows
-    float s1[8], s2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      __builtin_amdgcn_sched_barrier(0);  // keep the second round's 16 loads behind the first round's stores
-      float4 xl[8], xh[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        xl[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, loff + jp * 128, i * rstep, 0));
-        xh[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, loff + jp * 128 + 16, i * rstep, 0));
-      }
-      const int c = nb + 32 * jp + 8 * g;
-      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c), g1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
-      float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-      if (p.bias != nullptr) {
-        q0 = *reinterpret_cast<const float4*>(p.bias + c);
-        q1 = *reinterpret_cast<const float4*>(p.bias + c + 4);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 u = acc[i][2 * jp], v = acc[i][2 * jp + 1];
-        float4 o0 = xl[i], o1 = xh[i];
-        o0.x += g0.x * (u[0] + q0.x); o0.y += g0.y * (u[1] + q0.y); o0.z += g0.z * (u[2] + q0.z); o0.w += g0.w * (u[3] + q0.w);
-        o1.x += g1.x * (v[0] + q1.x); o1.y += g1.y * (v[1] + q1.y); o1.z += g1.z * (v[2] + q1.z); o1.w += g1.w * (v[3] + q1.w);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o0), xr, loff + jp * 128 + i * rstep, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o1), xr, loff + jp * 128 + 16 + i * rstep, 0, 0);
-        if (p.xb != nullptr) {  // LayerNorm producer side (ln_fold): bf16(x) and the row's partial (sum, sum of squares)
-          typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-          const u32x4_t pk = {pack2(o0.x, o0.y), pack2(o0.z, o0.w), pack2(o1.x, o1.y), pack2(o1.z, o1.w)};
-          *reinterpret_cast<u32x4_t*>(p.xb + (size_t)(mb + i * 16 + lc) * p.N + c) = pk;
-          s1[i] += ((o0.x + o0.y) + (o0.z + o0.w)) + ((o1.x + o1.y) + (o1.z + o1.w));
-          s2[i] += ((o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w)) +
-                   ((o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
-        }
-      }
-    }
-    if (p.xb != nullptr) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {  // the 4 lanes lc + 16 g hold the row's 64 columns
-        float a = s1[i], b = s2[i];
-        a += __shfl_xor(a, 16, 64);
-        b += __shfl_xor(b, 16, 64);
-        a += __shfl_xor(a, 32, 64);
-        b += __shfl_xor(b, 32, 64);
-        if (g == 0) p.st_part[(size_t)(nb >> 6) * p.M + mb + i * 16 + lc] = make_float2(a, b);
-      }
-    }
-  } else {
-    const bool ln = (IS_QKV(EPI) || IS_GELU(EPI)) && p.ln_stats != nullptr;
-    float2 st[8];
-    if (ln) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) st[i] = p.ln_stats[mb + i * 16 + lc];
-    }
-    const int ldo = (IS_QKV(EPI)) ? 2 * p.dim : p.N;
-    bf16_t* orow = p.out + (size_t)(mb + lc) * ldo + nb + 8 * g;
-    float4 cs[2][2], bs[2][2];
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      const int c = nb + 32 * jp + 8 * g;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        cs[jp][hh] = bs[jp][hh] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ln) cs[jp][hh] = *reinterpret_cast<const float4*>(p.ln_cs + c + 4 * hh);
-        if (p.bias != nullptr) bs[jp][hh] = *reinterpret_cast<const float4*>(p.bias + c + 4 * hh);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[i][2 * jp][r];
-          v[4 + r] = acc[i][2 * jp + 1][r];
-        }
-        const float cv[8] = {cs[jp][0].x, cs[jp][0].y, cs[jp][0].z, cs[jp][0].w, cs[jp][1].x, cs[jp][1].y, cs[jp][1].z, cs[jp][1].w};
-        const float bv[8] = {bs[jp][0].x, bs[jp][0].y, bs[jp][0].z, bs[jp][0].w, bs[jp][1].x, bs[jp][1].y, bs[jp][1].z, bs[jp][1].w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (ln) v[e] = fmaf(st[i].y, v[e] - st[i].x * cv[e], bv[e]);  // rstd * (acc - mean * cs) + b'
-          else v[e] += bv[e];
-          if (IS_GELU(EPI)) v[e] = gelu_erf(v[e]);
-        }
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        const u32x4_t pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-        u32x4_t* dst = reinterpret_cast<u32x4_t*>(orow + (size_t)i * 16 * ldo + 32 * jp);
-        if (p.nt_store) __builtin_nontemporal_store(pk, dst);
-        else *dst = pk;
-      }
-    }
-  }
-}
-
-// V tiles of the qkv GEMM (un-swapped operands): vt[b][h][d][s], the lane's 4 rows are 4 consecutive tokens
-__device__ __forceinline__ void q_epilogue_v(const EpiArgs& p, f32x4 (&acc)[8][4], int mb, int nb, int lane) {
-  const int g = lane >> 4, lc = lane & 15;
-  const bool ln = p.ln_stats != nullptr;
-  const int b = mb / p.s_pad, s0 = mb - b * p.s_pad;  // a 128-row block never straddles two images
-  float cs[4], bs[4];
-  int col[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    col[j] = nb + 32 * (j >> 1) + 8 * (lc >> 2) + 4 * (j & 1) + (lc & 3);
-    cs[j] = ln ? p.ln_cs[col[j]] : 0.f;
-    bs[j] = p.bias != nullptr ? p.bias[col[j]] : 0.f;
-  }
-  float4 sa[8], sb[8];  // (mean, rstd) of rows 16 i + 4 g + {0, 1} and {2, 3}
-#pragma unroll
-  for (int i = 0; i < 8; ++i) sa[i] = sb[i] = make_float4(0.f, 1.f, 0.f, 1.f);
-  if (ln) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4* sp = reinterpret_cast<const float4*>(p.ln_stats + mb + i * 16 + 4 * g);
-      sa[i] = sp[0];
-      sb[i] = sp[1];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float mu[4] = {sa[i].x, sa[i].z, sb[i].x, sb[i].z}, rs[4] = {sa[i].y, sa[i].w, sb[i].y, sb[i].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = ln ? fmaf(rs[r], acc[i][j][r] - mu[r] * cs[j], bs[j]) : acc[i][j][r] + bs[j];
-      const int f = col[j] - 2 * p.dim, h = f >> 6, d = f & 63;
-      uint2 pk;
-      pk.x = pack2(v[0], v[1]);
-      pk.y = pack2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(p.vt + ((size_t)(b * p.heads + h) * 64 + d) * p.s_pad + s0 + i * 16 + 4 * g) = pk;
-    }
-  }
-}
-
+// tile of position `id` in the L2-aware order of map_tile (see there)
 __device__ __forceinline__ TileMap map_tile_id(int id, int mt, int nt, int group, int mblock) {
   const int per_group = group * mt;
   int g = id / per_group;
@@ -1429,154 +1120,6 @@ __device__ __forceinline__ TileMap map_tile_id(int id, int mt, int nt, int group
   return t;
 }
 
-// the k-loop + epilogue of one tile; FIRST: the workgroup's first tile (its prologue was issued by the caller)
-template <int EPI, bool SWAP, int ABL = 0>
-__device__ __forceinline__ void q_tile(kernarg_ptr_t kp, f32x4 (&acc)[8][4], char* smem, char* ldsw, const QSrc& cur,
-                                       const QSrc& nxt, bool first, int nk, const int (&voA)[2],
-                                       const int (&voB)[2], int hA, int hB, int oa0, int oa1, int ob0, int ob1, int mb,
-                                       int nb, int lane, int tile_id) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int S = P8QStores<EPI>::n;
-#define Q_ARGS acc, smem, ldsw, cur, nxt
-#define Q_TAIL nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1
-  long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
-  if constexpr (ABL & 64) tm0 = __builtin_readcyclecounter();
-  int t = 0;
-  if (!first) {  // the previous tile's epilogue stores sit between this tile's first DMAs and the ones issued now
-    q_ktile<SWAP, 0, 8 + S, 8 + S, 8 + S, ABL>(Q_ARGS, 0, Q_TAIL);
-    t = 1;
-  }
-  for (; t < nk - 2; ++t) q_ktile<SWAP, 0, 8, 8, 8, ABL>(Q_ARGS, t, Q_TAIL);
-  // The last two k-tiles ALWAYS continue the ring into `nxt` -- when no tile follows, `nxt` is a zero-length
-  // descriptor (out-of-range buffer loads: no memory traffic) and the DMAs are drained before the workgroup exits.
-  // A second code path for "no next tile" would merge with 128 live accumulators behind it: hipcc's register
-  // allocator then spills ~280 VGPRs (measured on the .s), the straight-line body needs 206 and none.
-  q_ktile<SWAP, 3, 8, 8, 8, ABL>(Q_ARGS, nk - 2, Q_TAIL);
-  q_ktile<SWAP, 4, 8, 8, 8, ABL>(Q_ARGS, nk - 1, Q_TAIL);
-#undef Q_ARGS
-#undef Q_TAIL
-  asm volatile("" : "+s"(kp));  // opaque: the loads below are not hoisted above the k-loop
-  const EpiArgs e = load_epi_args(kp);
-  if constexpr (ABL & 8) {  // ablation: no epilogue (accumulators kept alive)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-  } else if constexpr (ABL & 64) {  // timing build: where does a tile's time go (wave-level cycle stamps)
-    tm1 = __builtin_readcyclecounter();
-    q_epilogue_swapped<EPI>(e, acc, mb, nb, lane);
-    tm2 = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also drains the next tile's DMAs: this build measures, it is not fast)
-    tm3 = __builtin_readcyclecounter();
-    if (lane == 0 && kp->dbg != nullptr) {  // one slot per (tile, wave): plain stores
-      unsigned long long* d = kp->dbg + ((size_t)tile_id * 8 + (threadIdx.x >> 6)) * 4;
-      d[0] = (unsigned long long)(tm1 - tm0);
-      d[1] = (unsigned long long)(tm2 - tm1);
-      d[2] = (unsigned long long)(tm3 - tm2);
-      d[3] = (unsigned long long)tm0;
-    }
-  } else if constexpr (SWAP) q_epilogue_swapped<EPI>(e, acc, mb, nb, lane);
-  else q_epilogue_v(e, acc, mb, nb, lane);
-}
-
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8q(GemmBArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * 16384];  // the ring only: 8 half-tile slots
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int mt = p.M / 256, nt = p.N / 256, ntiles = mt * nt;
-  // workgroup -> run of `tpw` consecutive tiles of the order; XCD x owns a contiguous range of runs
-  int wid;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int first_tile = wid * p.tpw;
-  const int count = min(p.tpw, ntiles - first_tile);
-  // De-synchronise the CUs.  Every workgroup of a launch starts at the same instant and every tile takes the same
-  // time, so all 256 CUs reach their epilogues together: 256 x 128 KB = the whole 32-MB L2 written within a
-  // microsecond, once per tile period, and the store issue stalls on the HBM write-back (measured: the epilogue costs
-  // 5.6 us of a 26-us tile, and "barriers + epilogue only" runs at 3.3-4.2 TB/s of writes).  The first workgroup
-  // of every CU therefore starts up to 7/8 of a tile period late, in 8 phase groups; later workgroups inherit the
-  // phase of the one they replace.
-  if (p.stagger > 0 && blockIdx.x < 256) {
-    const int slot = (blockIdx.x >> 3) & 7;
-    for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles ~ 0.5 us
-  }
-  const int nk = p.K / GBK;
-
-  // per-lane parts of the DMA source addresses (bytes); the half (h) and the k-tile go into the scalar offset
-  int voA[2], voB[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int s_ = it * 512 + tid, r = s_ >> 3, c = (s_ & 7) ^ (r & 7);
-    voA[it] = (((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2;
-    const int rho = r & 31, jj = rho >> 4, l16 = rho & 15;
-    voB[it] = (((r >> 5) * 64 + 8 * (l16 >> 2) + 4 * jj + (l16 & 3)) * p.ldw + c * 8) * 2;
-  }
-  const int hA = 64 * p.lda * 2, hB = 32 * p.ldw * 2;  // second half-tile: +64 A rows / +32 W rows
-  char* const ldsw = smem + wave * 1024;
-  const int cg = lane >> 4;
-  const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
-  const int oa0 = ra * 128 + (((0 + cg) ^ (ra & 7)) << 4), oa1 = ra * 128 + (((4 + cg) ^ (ra & 7)) << 4);
-  const int ob0 = rb * 128 + (((0 + cg) ^ (rb & 7)) << 4), ob1 = rb * 128 + (((4 + cg) ^ (rb & 7)) << 4);
-
-  auto src_of = [&](int id, bool valid, int& m0, int& n0) {
-    const TileMap tm = map_tile_id(valid ? id : first_tile, mt, nt, p.group, p.mblock);
-    m0 = tm.m * 256;
-    n0 = tm.n * 256;
-    const int len = valid ? 0x7fffffff : 0;  // no tile: every access is out of range
-    QSrc s;
-    s.a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, len, 0x00020000);
-    s.b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, len, 0x00020000);
-    return s;
-  };
-  int m0, n0;
-  QSrc cur = src_of(first_tile, true, m0, n0);
-  {  // prologue: A0 B0 B1 A1 of k-tile 0, A0 B0 of k-tile 1 -- the order the steady state continues
-    constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
-#define Q_STAGE0(RS, VO, soff, off)                                                                              \
-  do {                                                                                                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, VO[0], soff, 0, 0);              \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, VO[1], soff, 0, 0);       \
-  } while (0)
-    Q_STAGE0(cur.a, voA, 0, OFF_A0);
-    Q_STAGE0(cur.b, voB, 0, OFF_B0);
-    Q_STAGE0(cur.b, voB, hB, OFF_B1);
-    Q_STAGE0(cur.a, voA, hA, OFF_A1);
-    Q_STAGE0(cur.a, voA, 128, BUF + OFF_A0);
-    Q_STAGE0(cur.b, voB, 128, BUF + OFF_B0);
-#undef Q_STAGE0
-  }
-  wait_vm<8>();
-  P8_BAR();
-  if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on (through every tile of the run)
-
-  f32x4 acc[8][4];
-  kernarg_ptr_t kp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-  for (int ti = 0; ti < count; ++ti) {
-    int m1, n1;
-    const QSrc nxt = src_of(first_tile + ti + 1, ti + 1 < count, m1, n1);
-    const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-#define Q_CALL(SW) q_tile<EPI, SW, ABL>(kp, acc, smem, ldsw, cur, nxt, ti == 0, nk, voA, voB, hA, hB, oa0, oa1, ob0, ob1, mb, nb, lane, first_tile + ti)
-    if constexpr (IS_QKV(EPI)) {
-      if (n0 >= 2 * p.dim) Q_CALL(false);
-      else Q_CALL(true);
-    } else {
-      Q_CALL(true);
-    }
-#undef Q_CALL
-    cur = nxt;
-    m0 = m1;
-    n0 = n1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (empty) DMAs of the non-existent next tile
-  if (wm == 0) P8_BAR();  // balance group 1's extra barrier
-}
 
 #include "dvt_vit_gemm4w.inc"
 
@@ -1593,15 +1136,13 @@ int g_vit_mblock = 0;
 int g_vit_nt_store = 0;
 // LayerNorm folded into the qkv / fc1 GEMMs and the proj / fc2 residual epilogues (ln_fold)
 int g_vit_fuse_ln = 1;
-// 8q kernel: tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
+// 4w kernel: target tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
 int g_vit_tpw = 0;
 // dvt_tune_set(1, -510 - mask): schedule mask of attention_kernel_v2 (see its header).  15 = k-step-major S, accumulator-major
 // P.V, no per-tile max tree, loop unrolled by two: 874-893 us against 908-928 us for mask 0 at 110 views (profiles/r03/r03i)
 int g_vit_attn_mask = 15;
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = software-pipelined S + deferred max, 1 = the round-2 kernel
-int g_vit_stagger = 0;  // dvt_tune_set(1, -400 - n): n half-microseconds per phase slot (0 off); -399: auto
-unsigned long long* g_vit_dbg = nullptr;  // dvt_vit_debug_buffer(): device buffer of the 8q timing build
-int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 8q kernel (EPI_BIAS only)
+int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 4w kernel (EPI_BIAS, timing only)
 int g_vit_w4_grid = 0;  // dvt_tune_set(1, -600 - n): workgroups of the 4w kernel (0 = auto: a whole number per CU)
 
 template <int EPI>
@@ -1659,25 +1200,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
         return 0;
       }
     }
-    if (g_vit_gemm_variant == 5 && EPI != EPI_EMBED && EPI != EPI_F32 && !IS_X3(EPI) && nk >= 4 && nk % 2 == 0) {
-      // tiles per workgroup: a workgroup should not live much longer than ~50 us (the fit's kernels on the other
-      // stream start where a GEMM workgroup exits): 3 tiles at K = 768 (19 us each), 1 at K = 3072
-      int tpw = g_vit_tpw > 0 ? g_vit_tpw : (nk <= 16 ? 3 : 1);
-      const int tiles = (a.M / 256) * nt;
-      tpw = tpw > tiles ? tiles : tpw;
-      a.tpw = tpw;
-      a.dbg = g_vit_dbg;
-      // per-slot delay in half-microseconds: tile period (~2.1 us per k-tile + 2 us) / 8 slots; -400 - n overrides (0 = off)
-      a.stagger = g_vit_stagger >= 0 ? g_vit_stagger : (int)((nk * 2.1 + 2.0) / 8.0 * 2.0 + 0.5);
-      const dim3 grid((tiles + tpw - 1) / tpw);
-      bool done = false;
-      if constexpr (EPI == EPI_BIAS) {  // developer ablations of the 8q structure (timing only, results are wrong)
-#define Q_ABL(n) if (g_vit_abl == n) { hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI, n>), grid, dim3(512), 0, s, a); done = true; }
-        Q_ABL(1) Q_ABL(2) Q_ABL(4) Q_ABL(8) Q_ABL(16) Q_ABL(3) Q_ABL(6) Q_ABL(7) Q_ABL(14) Q_ABL(15) Q_ABL(48) Q_ABL(24) Q_ABL(64)
-#undef Q_ABL
-      }
-      if (!done) hipLaunchKernelGGL((gemm_bf16_kernel_8q<EPI>), grid, dim3(512), 0, s, a);
-    } else if (g_vit_gemm_variant >= 4)
+    if (g_vit_gemm_variant >= 4)
       hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     else
       hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
@@ -2509,15 +2032,12 @@ int dvt_vit_tune(int v) {
     g_vit_attn_variant = -500 - v;
     return 0;
   }
-  if (v <= -399) {
-    g_vit_stagger = v == -399 ? -1 : -400 - v;
-    return 0;
-  }
+  if (v <= -399) return 0;  // (-399 .. -499: the removed 8q kernel's staggered start; accepted, no effect)
   if (v <= -300) {
     g_vit_abl = -300 - v;
     return 0;
   }
-  if (v <= -200) {  // -200 - n: tiles per workgroup of the 8q kernel, 0 = auto
+  if (v <= -200) {  // -200 - n: target tiles per workgroup of the 4w kernel, 0 = auto
     g_vit_tpw = -200 - v > 16 ? 16 : -200 - v;
     return 0;
   }
@@ -2529,15 +2049,14 @@ int dvt_vit_tune(int v) {
     g_vit_group_bytes = v * 1024;
     return 0;
   }
-  if (v < 0 || v > 9) return DVT_E_BADARG;
+  if (v < 0 || v > 9 || v == 5) return DVT_E_BADARG;  // (5 was the 8q kernel, removed in round 4)
   g_vit_gemm_variant = v;
   return 0;
 }
 
-// developer instrumentation: device buffer (tiles x 8 waves x 4 u64) the 8q timing build (dvt_tune_set(1, -364)) writes its
-// per-tile, per-wave cycle counts to; nullptr switches the reporting off
+// (was: the cycle-stamp buffer of the removed 8q timing build; the symbol stays in the ABI and does nothing)
 extern "C" int dvt_vit_debug_buffer(void* dev_u64x4) {
-  g_vit_dbg = (unsigned long long*)dev_u64x4;
+  (void)dev_u64x4;
   return 0;
 }
 

@@ -262,17 +262,21 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * re-entrant on distinct streams).
  * key 0 = fp32 GEMM tile configuration override
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
- * key 1 = ViT bf16 GEMM schedule (4: 256x256 8-phase ring; 5: the same ring with a register epilogue and
- *         several tiles per workgroup [-200 - n: n tiles, 0 = auto]; 0: 256x256 two-stage; 1: always
- *         128x128 two-stage; 2: 256x128 lock-step three-stage; 3: 256x128 ping-pong;
+ * key 1 = ViT bf16 GEMM schedule (4 [default]: 256x256 8-phase ring, 8 waves; 6 / 7: the 4-wave persistent kernel
+ *         of csrc/dvt_vit_gemm4w.inc for the bias / GELU (+ folded LayerNorm) epilogues where K >= 640 -- every tile
+ *         flushed at its end / DEFERRED epilogue under the next tile's k-loop [-200 - n: target tiles per workgroup,
+ *         -600 - n: force n workgroups, 0 = auto]; 8 / 9: the same two with the cheaper GELU of that file (2.7e-4 max
+ *         abs deviation from erf-GELU before the bf16 rounding -- the ONE schedule value that changes results beyond
+ *         rounding order, opt-in); 0: 256x256 two-stage; 1: always 128x128 two-stage; 2: 256x128 lock-step
+ *         three-stage; 3: 256x128 ping-pong; (5 was round 3's "8q" kernel, removed);
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation;
  *         -100 - b: b M panels per block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output
  *         stores off / on; -501 / -502: attention kernel of the bf16 extractor, round-2 loop / software-pipelined loop
  *         with deferred running max [default]; -510 - mask: schedule mask of that kernel (default 15; csrc/dvt_vit.hip,
  *         attention_kernel_v2: every mask computes the same function); -520 / -521 and -522 / -523: inside
  *         dvt_vit_forward_f32x3, exact-fp32 attention on / off [off] and split kernels instead of split epilogues
- *         on / off [off]; developer instrumentation of schedule 5: -300 - mask ablations [timing
- *         only, EPI_BIAS entry point, results wrong by construction], -400 - n staggered workgroup start).  No other
+ *         on / off [off]; developer instrumentation of schedules 6 / 7: -300 - mask ablations [timing
+ *         only, EPI_BIAS entry point, results wrong by construction]).  No other
  *         value changes the result beyond the summation order of the folded-LayerNorm row statistics (fp32, ~1e-7
  *         relative) and, between the two attention kernels, the bf16 rounding of P (different running max);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
@@ -281,8 +285,10 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
  *         2 / 3 = LDS stages of the stage-2 GEMMs (2, default: two workgroups per CU);
  * key 6 = bf16-mode fit step: 1 (default) the fused row kernel (dvt_fit_fused.hip), 0 = one launch per layer;
- * key 7 = fused step: 1 (default) hash-grid gradient gathered from per-step sorted corner lists, 0 = scattered with atomics;
- * key 9 = fused step: 1 (default) lazy Adam over the fine hash-grid levels, 0 = dense Adam over the whole arena,
+ * key 7 = fit step (both operand precisions since round 4): 1 (default) hash-grid gradient gathered from per-step sorted
+ *         corner lists, 0 = scattered with atomics;
+ * key 9 = fit step (both precisions): 1 (default) lazy Adam over the fine hash-grid levels -- with fp32 operands always the
+ *         IEEE replay of key 10 = 1, bit-identical to the dense sweep --, 0 = dense Adam over the whole arena,
  *         n >= 2 = lazy with a full refresh every n steps (default 32);
  * key 12 = the merged Adam launch also stores the bf16 weight shadow (1, default) or shadow_build_kernel runs (0);
  * key 11 = the lazy catch-up of the next step shares the Adam launch (1, default) or is its own launch (0);

@@ -66,7 +66,7 @@ def test_gemm_bias_vs_torch(L, m, n, k):
     assert rel(y.float(), want) < 6e-3, (m, n, k)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 3, 4])
 @pytest.mark.parametrize("m,n,k", [(512, 256, 128), (2816, 768, 768), (1408, 768, 3072), (256, 384, 192), (1792, 768, 768)])
 def test_gemm_residual_vs_torch(L, m, n, k, variant):
     """x += gamma * (a @ w^T + b) (LayerScale + residual epilogue) on every GEMM schedule: 0 = 256x256
@@ -88,7 +88,7 @@ def test_gemm_residual_vs_torch(L, m, n, k, variant):
     assert float(err.max()) < 2e-3 * float(want.abs().max()), (variant, (m, n, k), float(err.max()))
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [3, 4, 6, 7])
 def test_gemm_bias_variants(L, variant):
     """the non-default GEMM schedules against torch on the four ViT-B shapes (one M panel pair each); 6 / 7: the 4-wave
     persistent kernel (csrc/dvt_vit_gemm4w.inc; flush per tile / deferred epilogue) where K >= 640, else 8p"""
