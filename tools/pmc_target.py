@@ -1,4 +1,4 @@
-"""Small workload for PMC collection: one ViT forward of 110 views (the bench's extractor launch: 769 views = 7 x 110) + 60
+"""Small workload for PMC collection: one ViT forward of NV views in ONE launch (bench: 769 views = 398 + 371; default 110) + 60
 fit steps.  argv[1] overrides the view count."""
 import os
 import sys
@@ -19,7 +19,7 @@ with warnings.catch_warnings():
 NV = int(sys.argv[1]) if len(sys.argv) > 1 else 110
 x = torch.randn(NV, 3, 518, 518, device=dev)
 out = torch.empty(NV, 37, 37, 768, device=dev)
-vit.features_nhwc(x, out=out)
+vit.features_nhwc(x, out=out, max_batch=400)  # ONE launch of NV views (the driver's cap; the library default is 128)
 torch.cuda.synchronize()
 n_rows = NV * 1369
 eng = FitEngine(FitSettings(num_iters=60, warmup_iters=6, mlp_dtype="bfloat16"), n_rows, dev)
