@@ -67,8 +67,8 @@ IMAGE_CEILINGS = {"vit_base_patch14_dinov2.lvd142m": (6.2, 10.7)}
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=6, help="images timed per rank")
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20, help="images timed per rank (default = the flags the round-end driver passes)")
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--model", default="vit_base_patch14_dinov2.lvd142m")
     p.add_argument("--num-iters", type=int, default=1000)
     p.add_argument("--warmup-iters", type=int, default=100)
