@@ -31,11 +31,14 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int g_fit_rows32 = 1;  // dvt_tune_set(13, v), see launch_rows
+int g_fit_small_wg = 0;  // dvt_tune_set(14, v): 1 = 4-wave fit_rows + 8-wave fit_backward workgroups (same arithmetic, same results)
 
 namespace {
 
 constexpr int FR0 = 16;  // rows per workgroup of the round-2 kernel = M of the MFMA; the kernel template takes FR = 16 or 32
-constexpr int FW = 8;    // waves per workgroup
+constexpr int FW8 = 8;   // waves per workgroup (template parameter FW of the kernels below: 8, or 4 = the small-footprint
+                         // shape of dvt_tune_set(14, 1): one wave per SIMD, so that a workgroup fits where ONE attention
+                         // workgroup of the extractor has left -- see profiles/r04/r04p_pipeline_timeline.txt)
 constexpr int FE = 128;  // encoding width: 16 levels x 8 features
 
 // LDS row pitch of a [16][K] bf16 activation image: +16 B so that the 16 rows of an A-fragment read
@@ -57,7 +60,7 @@ __device__ __forceinline__ uint16_t bf16_of(float v) { return (uint16_t)(dvt_pac
 // One [16][NC] bf16 LDS image (pitch apitch(NC)) -> its slice of the transposed, fragment-major operand copy
 // dstT = [NC][B]: for every column the 16 batch rows of this workgroup are two 16-byte pieces (8 rows each)
 // of the 1-KB fragment block (tile col / 16, k-step b0 / 32).  Adjacent threads take adjacent columns.
-template <int NC, int FR>
+template <int NC, int FR, int FW>
 __device__ __forceinline__ void store_T(const char* img, uint16_t* __restrict__ dstT, int B, int b0, int tid) {
   // FR / 8 groups of 8 batch rows per column; group `grp` = batch rows b0 + 8 grp .. + 7 = lane group g of k-step
   for (int item = tid; item < NC * (FR / 8); item += 64 * FW) {
@@ -82,7 +85,7 @@ __device__ __forceinline__ void store_T(const char* img, uint16_t* __restrict__ 
 //   act_out LDS bf16 image [16][N] for the next layer (may alias `mask`: every element is read, then
 //           written, by the one lane that owns it), or nullptr
 //   gout    global fp32 [16][N] (this workgroup's rows), or nullptr
-template <int K, int N, bool RELU, bool MASK, int RB>
+template <int K, int N, bool RELU, bool MASK, int RB, int FW>
 __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __restrict__ W,
                                           const float* __restrict__ bias, char* act_out,
                                           float* __restrict__ gout, const char* mask, int wave, int lane) {
@@ -91,7 +94,9 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
   // k-steps of weights in flight per wave: ~24 x 1 KB.  The weights are L2 hits at best and memory-side
   // cache hits on first touch (every kernel starts with a cold L2), i.e. 0.3-2 us of latency: with 6 loads
   // in flight per wave the first version of this kernel streamed its 1.3 MB at 24 GB/s per CU (54 us).
-  constexpr int PD0 = 24 / NT > 16 ? 16 : 24 / NT;
+  constexpr int INFL = FW == 8 ? 24 : 16;  // (4-wave shape: 16, which keeps the phase-2 kernel at C = 768 under the 272 VGPRs one
+                                           // attention workgroup leaves per SIMD; a CU's L2 fill rate saturates far below either)
+  constexpr int PD0 = INFL / NT > 16 ? 16 : (INFL / NT < 1 ? 1 : INFL / NT);
   constexpr int PD = PD0 < S ? PD0 : S;
   static_assert(K % 32 == 0 && N % 16 == 0, "layer shape");
   const int lc = lane & 15, g = lane >> 4;
@@ -166,11 +171,12 @@ struct FusedLds {
   static constexpr int TOTAL = PH2 ? O_R2 + FR * apitch(R) : O_RAW;
 };
 
-template <int C, bool PH2, int FR>
+template <int C, bool PH2, int FR, int FW>
 __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   using L = FusedLds<C, PH2, FR>;
   constexpr int RB = FR / 16;
   static_assert(FR == 16 || FR == 32, "rows per workgroup");
+  static_assert(FW == 8 || (FW == 4 && FR == 16), "waves per workgroup");
   static_assert(L::TOTAL <= 160 * 1024, "LDS images of the row kernel");
   constexpr int H = C / 2, R = C / 4, E = FE, cq = C / 4;
   __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
     const long long l0 = slot * per, l1 = l0 + per < lines ? l0 + per : lines;
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(sh);
 #pragma unroll
-    for (int j = 0; j < 4 * RB; ++j) {
+    for (int j = 0; j < 4 * RB * (8 / FW); ++j) {
       const long long li = l0 + tid + (long long)j * 64 * FW;
       if (li < l1) warm[j & 3] ^= w32[li * 32];
     }
@@ -255,26 +261,26 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   // ---- forward: field MLP (neural_feature_field.py:40-44, :49), residual predictor (offline_denoiser.py:107)
   const int B = a.n;
   uint16_t* __restrict__ T = f.T;
-  mlp_layer<E, H, true, false, RB>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1, nullptr,
+  mlp_layer<E, H, true, false, RB, FW>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1, nullptr,
                                nullptr, wave, lane);
   if (PH2)
-    mlp_layer<C, R, true, false, RB>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1, nullptr,
+    mlp_layer<C, R, true, false, RB, FW>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1, nullptr,
                                  nullptr, wave, lane);
   __syncthreads();
-  mlp_layer<H, C, false, false, RB>(smem + L::O_H1, sh + a.S.direct[1], P + a.off_b2, nullptr,
+  mlp_layer<H, C, false, false, RB, FW>(smem + L::O_H1, sh + a.S.direct[1], P + a.off_b2, nullptr,
                                 f.F + (size_t)row0 * C, nullptr, wave, lane);
   // operands of the weight gradients leave as transposed bf16 copies while their LDS images are stable
-  store_T<H, FR>(smem + L::O_H1, T + a.TL.off[DVT_T_H1], B, row0, tid);
-  store_T<E, FR>(smem + L::O_ENC, T + a.TL.off[DVT_T_ENC], B, row0, tid);
+  store_T<H, FR, FW>(smem + L::O_H1, T + a.TL.off[DVT_T_H1], B, row0, tid);
+  store_T<E, FR, FW>(smem + L::O_ENC, T + a.TL.off[DVT_T_ENC], B, row0, tid);
   if (PH2) {
-    mlp_layer<R, R, true, false, RB>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2, nullptr,
+    mlp_layer<R, R, true, false, RB, FW>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2, nullptr,
                                  nullptr, wave, lane);
-    store_T<C, FR>(smem + L::O_RAW, T + a.TL.off[DVT_T_RAW], B, row0, tid);
-    store_T<R, FR>(smem + L::O_R1, T + a.TL.off[DVT_T_R1], B, row0, tid);
+    store_T<C, FR, FW>(smem + L::O_RAW, T + a.TL.off[DVT_T_RAW], B, row0, tid);
+    store_T<R, FR, FW>(smem + L::O_R1, T + a.TL.off[DVT_T_R1], B, row0, tid);
     __syncthreads();
-    mlp_layer<R, C, false, false, RB>(smem + L::O_R2, sh + a.S.direct[4], P + a.off_bh3, nullptr,
+    mlp_layer<R, C, false, false, RB, FW>(smem + L::O_R2, sh + a.S.direct[4], P + a.off_bh3, nullptr,
                                   f.Hres + (size_t)row0 * C, nullptr, wave, lane);
-    store_T<R, FR>(smem + L::O_R2, T + a.TL.off[DVT_T_R2], B, row0, tid);
+    store_T<R, FR, FW>(smem + L::O_R2, T + a.TL.off[DVT_T_R2], B, row0, tid);
   }
   __syncthreads();  // F (and Hres) rows of this workgroup are visible to all of its waves
 
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   static_assert(C <= 1024, "row warm-up above assumes <= 32 lines per row");
   {
     constexpr int NR = FR / FW;
-    constexpr int NB = (C <= 768) ? 2 : 1;  // rows whose loads are in flight together (register budget)
+    constexpr int NB = (C <= 768 && !(FW == 4 && PH2)) ? 2 : 1;  // rows whose loads are in flight together (register budget)
     DvtLossRowRegs<PH2> lr[NB];
 #pragma unroll
     for (int r0 = 0; r0 < NR; r0 += NB) {
@@ -311,24 +317,24 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
 
   // ---- data gradients: dh1 = (dF . W2) * (h1 > 0), denc = dh1 . W1; dr2 = (dH . Wh3) * (r2 > 0),
   //      dr1 = (dr2 . Wh2) * (r1 > 0)  (the [K][N] shadow copies make these k-contiguous as well)
-  mlp_layer<C, H, false, true, RB>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1, nullptr,
+  mlp_layer<C, H, false, true, RB, FW>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1, nullptr,
                                smem + L::O_H1, wave, lane);
-  store_T<C, FR>(smem + L::O_DF, T + a.TL.off[DVT_T_DF], B, row0, tid);
+  store_T<C, FR, FW>(smem + L::O_DF, T + a.TL.off[DVT_T_DF], B, row0, tid);
   if (PH2) {
-    mlp_layer<C, R, false, true, RB>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2, nullptr,
+    mlp_layer<C, R, false, true, RB, FW>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2, nullptr,
                                  smem + L::O_R2, wave, lane);
-    store_T<C, FR>(smem + L::O_RAW, T + a.TL.off[DVT_T_DH], B, row0, tid);
+    store_T<C, FR, FW>(smem + L::O_RAW, T + a.TL.off[DVT_T_DH], B, row0, tid);
   }
   __syncthreads();
-  mlp_layer<H, E, false, false, RB>(smem + L::O_H1, sh + a.S.transp[0], nullptr, nullptr,
+  mlp_layer<H, E, false, false, RB, FW>(smem + L::O_H1, sh + a.S.transp[0], nullptr, nullptr,
                                 f.denc + (size_t)row0 * E, nullptr, wave, lane);
-  store_T<H, FR>(smem + L::O_H1, T + a.TL.off[DVT_T_DH1], B, row0, tid);
+  store_T<H, FR, FW>(smem + L::O_H1, T + a.TL.off[DVT_T_DH1], B, row0, tid);
   if (PH2) {
-    mlp_layer<R, R, false, true, RB>(smem + L::O_R2, sh + a.S.transp[3], nullptr, smem + L::O_R1, nullptr,
+    mlp_layer<R, R, false, true, RB, FW>(smem + L::O_R2, sh + a.S.transp[3], nullptr, smem + L::O_R1, nullptr,
                                  smem + L::O_R1, wave, lane);
-    store_T<R, FR>(smem + L::O_R2, T + a.TL.off[DVT_T_DR2], B, row0, tid);
+    store_T<R, FR, FW>(smem + L::O_R2, T + a.TL.off[DVT_T_DR2], B, row0, tid);
     __syncthreads();
-    store_T<R, FR>(smem + L::O_R1, T + a.TL.off[DVT_T_DR1], B, row0, tid);
+    store_T<R, FR, FW>(smem + L::O_R1, T + a.TL.off[DVT_T_DR1], B, row0, tid);
   }
   // keeps the warm-up loads alive (a.n is never negative)
   if (a.n < 0) f.rows[tid] = __uint_as_float(warm[0] ^ warm[1] ^ warm[2] ^ warm[3] ^ warm[4]);
@@ -386,10 +392,11 @@ struct WgradArgs {
 // element, this half and the grid backward were both bound by the L2 atomic rate: side by side in one launch
 // they took exactly the sum of their stand-alone times.)
 constexpr int WG_PART_FLOATS = 32 * 32 + 32;  // a wave's partial block + its bias partials
+template <int SLOTS>  // units per workgroup: 4 (16 waves) or 2 (8 waves, dvt_tune_set(14, 1))
 __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int blk, int wave, int lane, float* red) {
   constexpr int PD = 4;
   const int slot = wave >> 2, ks = wave & 3;
-  const int unit = blk * 4 + slot;
+  const int unit = blk * SLOTS + slot;
   float* mine = red + (slot * 4 + ks) * WG_PART_FLOATS;
   const bool is_w = unit < a.units_total;
   const int gu = unit - a.units_total;  // gradient-of-G rows ride in the surplus units (4 rows per unit)
@@ -531,23 +538,25 @@ struct BackwardArgs {
   int n, grid_blocks_per_fit, k, wg_blocks;
   WgradArgs w;
 };
-__global__ __launch_bounds__(1024) void fit_backward_kernel(BackwardArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[16 * WG_PART_FLOATS];  // 66 KB: grid half uses the first 8.2 KB
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fit_backward_kernel(BackwardArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[WAVES * WG_PART_FLOATS];  // 66 KB at 16 waves: grid half uses the first 8.2 KB
   // weight-gradient blocks FIRST: the grid half alone is more blocks than the chip holds at once, behind
   // it the other half would only start when it drains (measured: the sum of the two, not the maximum)
   if ((int)blockIdx.x >= a.wg_blocks) {
     const int b = (int)blockIdx.x - a.wg_blocks;
     const int fy = b / a.grid_blocks_per_fit, bx = b - fy * a.grid_blocks_per_fit;
     if (a.gs.nt > 0) {
-      const int parts = a.gs.nt >> 10;
-      grid_gather_body(a.T, a.gs, fy, bx / parts, bx % parts, a.gp.d_enc[fy], a.gp.d_params[fy], a.gp.touched[fy]);
+      const int parts = a.gs.nt / (64 * WAVES);
+      grid_gather_body(a.T, a.gs, fy, bx / parts, bx % parts, a.gp.d_enc[fy], a.gp.d_params[fy], a.gp.touched[fy], 64 * WAVES);
       return;
     }
-    grid_bwd_body<256>(a.T, a.plan, a.gp, a.n, bx, fy, smem, reinterpret_cast<uint32_t*>(smem + 256 * 8));
+    if constexpr (WAVES == 16)  // (the scatter path is written for 1024 threads; the host only picks 8 waves with sorted lists)
+      grid_bwd_body<256>(a.T, a.plan, a.gp, a.n, bx, fy, smem, reinterpret_cast<uint32_t*>(smem + 256 * 8));
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  wgrad_block(a.w, (int)blockIdx.x, wave, threadIdx.x & 63, smem);
+  wgrad_block<WAVES / 4>(a.w, (int)blockIdx.x, wave, threadIdx.x & 63, smem);
 }
 
 // FR = 32 rows per workgroup halves the weight stream per row (every fragment feeds two MFMAs) and the number of
@@ -560,17 +569,21 @@ template <int C>
 int launch_rows(const FusedArgs& a, int k, bool phase2, hipStream_t s) {
   const bool fits32 = phase2 ? (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) : (FusedLds<C, false, 32>::TOTAL <= 160 * 1024);
   const bool r32 = fits32 && a.n % 32 == 0 && (g_fit_rows32 == 2 || (g_fit_rows32 == 1 && k >= 4));
-  dim3 grid(a.n / (r32 ? 32 : 16), k), block(64 * FW);
+  const bool small = g_fit_small_wg && !r32;
+  dim3 grid(a.n / (r32 ? 32 : 16), k), block(64 * (small ? 4 : FW8));
   if (r32) {
     if (phase2) {
-      if constexpr (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, true, 32>), grid, block, 0, s, a);
+      if constexpr (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, true, 32, FW8>), grid, block, 0, s, a);
     } else {
-      if constexpr (FusedLds<C, false, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, false, 32>), grid, block, 0, s, a);
+      if constexpr (FusedLds<C, false, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, false, 32, FW8>), grid, block, 0, s, a);
     }
+  } else if (small) {
+    if (phase2) hipLaunchKernelGGL((fit_rows_kernel<C, true, 16, 4>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((fit_rows_kernel<C, false, 16, 4>), grid, block, 0, s, a);
   } else if (phase2) {
-    hipLaunchKernelGGL((fit_rows_kernel<C, true, 16>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((fit_rows_kernel<C, true, 16, FW8>), grid, block, 0, s, a);
   } else {
-    hipLaunchKernelGGL((fit_rows_kernel<C, false, 16>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((fit_rows_kernel<C, false, 16, FW8>), grid, block, 0, s, a);
   }
   DVT_CHECK_LAUNCH();
   return 0;
@@ -741,10 +754,11 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
   ba.grid_blocks_per_fit = ba.plan.n_lds_blocks + dvt_cdiv(direct_threads, 1024);
   bool sorted = g_fit_sorted_grid && dvt_grid_sorted_ok(&c->grid, c->batch);
   for (int f = 0; f < k; ++f) sorted = sorted && fits[f].gs_keys && fits[f].gs_pay && fits[f].gs_w;
+  const bool small = g_fit_small_wg && sorted;  // 8-wave workgroups, 2 units each
   if (sorted) {
     ba.gs.nt = 4 * c->batch;
     ba.gs.bitmap_end = fits[0].gs_bitmap_end;
-    ba.grid_blocks_per_fit = c->grid.n_levels * (ba.gs.nt / 1024);
+    ba.grid_blocks_per_fit = c->grid.n_levels * (ba.gs.nt / (small ? 512 : 1024));
     for (int f = 0; f < k; ++f) {
       ba.gs.keys[f] = fits[f].gs_keys;
       ba.gs.pay[f] = fits[f].gs_pay;
@@ -758,10 +772,13 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
     ba.gp.d_params[f] = fits[f].grads + c->off_grid;
     ba.gp.touched[f] = fits[f].touched;
   }
-  const int wg_blocks = dvt_cdiv((long long)units + dvt_cdiv((long long)a.n_gather * a.lattice, 4), 4);
+  const int wg_blocks = dvt_cdiv((long long)units + dvt_cdiv((long long)a.n_gather * a.lattice, 4), small ? 2 : 4);
   ba.wg_blocks = wg_blocks;
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, flops);
-  hipLaunchKernelGGL(fit_backward_kernel, dim3(ba.grid_blocks_per_fit * k + wg_blocks), dim3(1024), 0, s, ba);
+  if (small)
+    hipLaunchKernelGGL(fit_backward_kernel<8>, dim3(ba.grid_blocks_per_fit * k + wg_blocks), dim3(512), 0, s, ba);
+  else
+    hipLaunchKernelGGL(fit_backward_kernel<16>, dim3(ba.grid_blocks_per_fit * k + wg_blocks), dim3(1024), 0, s, ba);
   DVT_CHECK_LAUNCH();
   return 0;
 }

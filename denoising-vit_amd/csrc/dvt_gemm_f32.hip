@@ -740,6 +740,7 @@ extern int g_fit_lazy_merge;
 extern int g_fit_shadow_in_adam;
 extern int g_adam_pingpong;
 extern int g_fit_rows32;
+extern int g_fit_small_wg;
 
 extern "C" int dvt_tune_set(int key, int value) {
   if (key == 0) {
@@ -785,6 +786,10 @@ extern "C" int dvt_tune_set(int key, int value) {
   if (key == 13) {
     if (value < 0 || value > 2) return DVT_E_BADARG;
     g_fit_rows32 = value;
+    return 0;
+  }
+  if (key == 14) {
+    g_fit_small_wg = value != 0;
     return 0;
   }
   if (key == 9) {

@@ -171,12 +171,13 @@ struct GridSortedPtrs {
   uint32_t bitmap_end;                      // entries >= this are stepped lazily (dvt_adam.hip): no `touched` bit
 };
 
-// One 1024-thread block = 1024 consecutive sorted pairs of level `l` of fit `fy` (part `part` of nt / 1024).
+// One block of `bs` threads (1024; 512 in the small-footprint backward) = `bs` consecutive sorted pairs of level `l` of fit
+// `fy` (part `part` of nt / bs).  Waves are independent of each other.
 __device__ __forceinline__ void grid_gather_body(const DvtGridTable& T, const GridSortedPtrs& q, int fy, int l, int part,
                                                  const float* __restrict__ d_enc, float* __restrict__ d_params,
-                                                 uint32_t* __restrict__ touched) {
+                                                 uint32_t* __restrict__ touched, int bs = 1024) {
   const int lane = threadIdx.x & 63;
-  const int u = part * 1024 + threadIdx.x;
+  const int u = part * bs + threadIdx.x;
   const size_t base = (size_t)l * q.nt;
   const uint32_t* __restrict__ keys = q.keys[fy] + base;
   const uint32_t key = keys[u];

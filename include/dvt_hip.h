@@ -300,6 +300,8 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         to the dense sweep; +18 us per step = -5.4 % bench `value` in a same-box A/B (profiles/r03);
  * key 13 = fused row kernel: rows per workgroup -- 1 (default) 32 when k >= 4 fits share the launch and the LDS images fit
  *         (C <= 768; C = 1024 in phase 1), else 16; 0 = always 16; 2 = 32 whenever the images fit.  Same arithmetic per row;
+ * key 14 = fit step, bf16 operands: workgroup shape of fit_rows / fit_backward -- 0 (default) 8 / 16 waves, 1 = 4 / 8 waves (one /
+ *          two waves per SIMD, the footprint one attention workgroup of the extractor leaves; same arithmetic, same results);
  * key 8 = Adam sweeps the arena in alternating directions on consecutive steps (1, default) or always forward (0);
  * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
 int dvt_tune_set(int key, int value);

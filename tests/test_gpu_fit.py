@@ -243,6 +243,47 @@ def test_bf16_operand_fit_vs_oracles(built_lib):
         assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (step, a, b)
 
 
+@pytest.mark.parametrize("C,V", [(768, 6), (1024, 4), (384, 6)])
+def test_small_footprint_workgroups_equal_default(built_lib, C, V):
+    """dvt_tune_set(14, 1): 4-wave fit_rows / 8-wave fit_backward workgroups (the shape that fits beside ONE attention
+    workgroup of the extractor).  Same MFMAs over the same k order, same partial-sum order in the weight gradients, same
+    wave-local segmented sums in the grid gather: the only freedom is the order of the few fp32 atomics that join list
+    segments across waves, which the default shape has as well -- so per-step losses agree to 1e-5 and parameters like two
+    launches of the same path (test above: 1e-5 in 59 of 60 cases, one sign flip of a near-zero gradient = ~2 lr)."""
+    from dvt_amd.fit import FitEngine, FitSettings
+    H = W = 37
+    feats, xy = synthetic_image(V, H, W, C, seed=C + 1)
+    n_rows = V * H * W
+    T = 16
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=2, mlp_dtype="bfloat16")
+    idx = np.random.RandomState(C + 1).randint(0, n_rows, (T, s.pixel_bsz)).astype(np.int32)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    res = {}
+    try:
+        assert built_lib.dvt_tune_set(13, 0) == 0
+        for small in (0, 1):
+            assert built_lib.dvt_tune_set(14, small) == 0
+            eng = FitEngine(s, n_rows, DEV)
+            eng.reset(torch.Generator(device=DEV).manual_seed(1))
+            eng.fit(f, c, idx, log_every=1)
+            torch.cuda.synchronize()
+            res[small] = (eng.params.clone(), eng.loss_log(), eng.infer(xy[-1].to(DEV)).cpu())
+            assert float(eng.grads.abs().max()) == 0.0 and int(eng.touched.abs().max()) == 0
+            del eng
+    finally:
+        built_lib.dvt_tune_set(14, 0)
+        built_lib.dvt_tune_set(13, 1)
+    (p1, l1, o1), (p0, l0, o0) = res[1], res[0]
+    for step in range(T):
+        for k, v in l0[step].items():
+            assert abs(l1[step][k] - v) <= 1e-5 * max(1.0, abs(v)), (step, k, l1[step][k], v)
+    d = (p1 - p0).abs()
+    print(f"small vs default workgroups (C={C}): params max |diff| {float(d.max()):.3e}, mean {float(d.mean()):.3e}, "
+          f"identical: {bool(torch.equal(p1, p0))}")
+    assert float(d.mean()) < 1e-6 and float(d.max()) < 0.05
+    assert per_patch_cos(o1, o0).min() > 0.99999
+
+
 @pytest.mark.parametrize("rows32", [0, 2])
 @pytest.mark.parametrize("C,V", [(768, 6), (1024, 4), (384, 6)])
 def test_fused_row_kernel_equals_layer_by_layer(built_lib, C, V, rows32):
