@@ -1,0 +1,247 @@
+// Developer probe: what ONE workgroup per CU (the GEMM's occupancy: 8 waves, >80 KB of LDS) can pull from L2 and push to
+// memory, by access pattern.  Answers two questions of profiles/r04: is the ~48 GB/s per CU that the GEMM's LDS-DMA stream,
+// fit_rows and fit_backward all land on a property of the pattern (128-B row pieces at a 1.5-6 KB pitch) or of the CU; and
+// would a tile-major (contiguous) layout of the intermediates make the epilogue's stores faster than 512-B row pieces at a
+// 4.6-KB pitch.
+//   build: hipcc --offload-arch=gfx950 -O3 cu_pipe.hip -o cu_pipe        run: ./cu_pipe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                    \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) {                                                      \
+      printf("%s failed: %s\n", #x, hipGetErrorString(e_));                      \
+      exit(1);                                                                   \
+    }                                                                            \
+  } while (0)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int LDS_BYTES = 96 * 1024;  // one workgroup per CU
+
+// ---- loads.  Every iteration a workgroup fetches PIECES x 8 KB: 512 threads x 16 B per piece.
+//   ROWB   bytes of one contiguous row piece (128 = a GEMM operand row of one k-tile; 8192 = fully contiguous)
+//   pitch  distance between consecutive row pieces
+//   The region a workgroup walks is `span` bytes starting at (blockIdx % nreg) * span: with nreg * span <= a few MB every
+//   fetch is an L2 hit after the first pass and never an L1 hit (32 KB L1, 8 KB per piece, span >> 32 KB).
+template <bool DMA, int ROWB>
+__global__ __launch_bounds__(512) void load_kernel(const char* __restrict__ src, size_t pitch, size_t span, int nreg,
+                                                   int iters, unsigned* sink) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int t = threadIdx.x;
+  constexpr int TPR = ROWB / 16;  // threads per row piece
+  const size_t lane_off = (size_t)(t / TPR) * pitch + (size_t)(t % TPR) * 16;
+  const size_t piece = (size_t)(512 / TPR) * pitch;  // bytes of address space one 8-KB piece covers
+  const char* base = src + (size_t)(blockIdx.x % nreg) * span;
+  size_t pos = ((size_t)blockIdx.x * 7919u * piece) % span;  // de-phase the workgroups that share a region
+  if (pos + piece > span) pos = 0;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const char* g = base + pos + lane_off;
+      if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (lds_ptr_t)(smem + ((it * 8 + p) % 8) * 8192 + (t >> 6) * 1024), 16, 0, 0);
+      } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(g);
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+      }
+      pos += piece;
+      if (pos + piece > span) pos = 0;
+    }
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    acc.x = *reinterpret_cast<unsigned*>(smem + t * 16);
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
+
+// ---- stores.  A workgroup writes `tiles` output tiles of 256 rows x 512 B (a 256 x 256 bf16 GEMM tile), 16 B per lane.
+//   BLOCKED = false: row-major [M][N]: row pieces of 512 B at pitch n_bytes (qkv: 4608, fc1: 6144)
+//   BLOCKED = true:  the tile is one contiguous 128-KB burst
+template <bool BLOCKED>
+__global__ __launch_bounds__(512) void store_kernel(char* __restrict__ dst, size_t n_bytes, int n_tiles_n, int tiles_total) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int t = threadIdx.x;
+  smem[t] = (char)t;
+  __syncthreads();
+  const uint4 v = make_uint4(t, smem[(t * 7) & 511], blockIdx.x, 42);
+  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+    const int tm = tile / n_tiles_n, tn = tile % n_tiles_n;
+    char* base = BLOCKED ? dst + (size_t)tile * 131072 : dst + (size_t)tm * 256 * n_bytes + (size_t)tn * 512;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      char* p = BLOCKED ? base + it * 8192 + t * 16 : base + (size_t)(it * 16 + (t >> 5)) * n_bytes + (t & 31) * 16;
+      *reinterpret_cast<uint4*>(p) = v;
+    }
+  }
+}
+
+// ---- the GEMM's operand stream, alone.  One workgroup = one 256 x 256 tile of y = x W^T (x [M][K], W [N][K] bf16, row-major):
+// per k-tile (64 k) eight 8-KB pieces -- 4 of A (64 rows x 128 B at pitch 2K), 4 of W -- by LDS-DMA, D pieces in flight, nothing
+// else (no MFMA, no LDS reads, no stores).  Tile order = dvt_vit.hip's map_tile (every XCD a contiguous run of the order
+// (n group, block of `mblock` M panels, n, m in block)).  Knobs:
+//   rot      0: every tile walks k = 0 .. nk-1 (the kernel today: the tiles that share an A panel / W slice ask for the same
+//               lines at the same time); 1: tile (m, n) starts at k-tile ((n * mblock + m % mblock) * nk) / (group * mblock)
+//               and wraps; 2: start = (n * nk) / group (only the sharers of an A panel are spread)
+//   a_panels > 0: A is read from panels (m % a_panels) only (an L2-resident A: the upper bound with no first-touch misses)
+struct TileMap { int m, n; };
+__device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, int group, int mblock) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int per_group = group * mt;
+  int g = id / per_group;
+  const int full = nt / group;
+  int width = group;
+  if (g >= full) { g = full; width = nt - full * group; }
+  const int rem = id - g * per_group;
+  TileMap t;
+  if (mblock <= 1) { t.m = rem / width; t.n = g * group + rem % width; }
+  else {
+    const int per_block = mblock * width;
+    const int mb = rem / per_block, r2 = rem - mb * per_block;
+    const int left = mt - mb * mblock, hb = left < mblock ? left : mblock;
+    t.n = g * group + r2 / hb;
+    t.m = mb * mblock + r2 % hb;
+  }
+  return t;
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void gemm_stream_kernel(const char* __restrict__ A, const char* __restrict__ W, int mt, int nt,
+                                                          int K, int group, int mblock, int rot, int a_panels) {
+  __shared__ __attribute__((aligned(16))) char smem[(D + 1) * 8192 > LDS_BYTES ? (D + 1) * 8192 : LDS_BYTES];
+  const int t = threadIdx.x;
+  const TileMap tm = map_tile(blockIdx.x, gridDim.x, mt, nt, group, mblock);
+  const int nk = K / 64;
+  const size_t pitch = (size_t)K * 2;
+  const int am = a_panels > 0 ? tm.m % a_panels : tm.m;
+  const char* a0 = A + (size_t)am * 256 * pitch + (size_t)(t >> 3) * pitch + (t & 7) * 16;
+  const char* w0 = W + (size_t)tm.n * 256 * pitch + (size_t)(t >> 3) * pitch + (t & 7) * 16;
+  int kt = 0;
+  if (rot == 1) kt = ((tm.n % group) * mblock + tm.m % mblock) * nk / (group * mblock);
+  if (rot == 2) kt = (tm.n % group) * nk / group;
+  int slot = 0;
+  for (int s = 0; s < nk; ++s) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const char* g = ((p & 2) ? w0 : a0) + (size_t)((p >> 2) * 2 + (p & 1)) * 64 * pitch + (size_t)kt * 128;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (lds_ptr_t)(smem + slot * 8192 + (t >> 6) * 1024), 16, 0, 0);
+      slot = slot == D ? 0 : slot + 1;
+      if constexpr (D == 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else if constexpr (D == 16) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    }
+    kt = kt + 1 == nk ? 0 : kt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename F>
+static float time_ms(F&& launch, int reps) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  launch();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) launch();
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("%s, %d CUs; one 512-thread workgroup per CU (96 KB LDS each)\n", prop.name, cus);
+  const size_t big = (size_t)2 << 30;
+  char* buf;
+  unsigned* sink;
+  CK(hipMalloc(&buf, big));
+  CK(hipMalloc(&sink, 64));
+  CK(hipMemset(buf, 1, big));
+  const int iters = 400;  // x 8 pieces x 8 KB = 25.6 MB per workgroup
+  const double bytes = (double)cus * iters * 8 * 8192;
+  struct Case { const char* name; size_t pitch; size_t span; int nreg; int rowb; };
+  const Case cases[] = {
+      {"128-B rows, pitch 1536 (K = 768), 2 MB shared per 8 regions [L2 hits]", 1536, (size_t)2 << 20, 8, 128},
+      {"128-B rows, pitch 6144 (K = 3072), 2 MB shared per 8 regions [L2 hits]", 6144, (size_t)2 << 20, 8, 128},
+      {"contiguous 8 KB pieces, 2 MB shared per 8 regions [L2 hits]", 128, (size_t)2 << 20, 8, 8192},
+      {"128-B rows, pitch 1536, 6 MB private per workgroup [HBM / MALL]", 1536, (size_t)6 << 20, 256, 128},
+      {"contiguous 8 KB pieces, 6 MB private per workgroup [HBM / MALL]", 128, (size_t)6 << 20, 256, 8192},
+      {"64-B rows, pitch 1536, 2 MB shared per 8 regions [L2 hits]", 1536, (size_t)2 << 20, 8, 64},
+  };
+  for (const Case& c : cases) {
+    for (int dma = 0; dma < 2; ++dma) {
+      auto launch = [&]() {
+        if (c.rowb == 128) {
+          if (dma) hipLaunchKernelGGL((load_kernel<true, 128>), dim3(cus), dim3(512), 0, 0, buf, c.pitch, c.span, c.nreg, iters, sink);
+          else hipLaunchKernelGGL((load_kernel<false, 128>), dim3(cus), dim3(512), 0, 0, buf, c.pitch, c.span, c.nreg, iters, sink);
+        } else if (c.rowb == 64) {
+          if (dma) hipLaunchKernelGGL((load_kernel<true, 64>), dim3(cus), dim3(512), 0, 0, buf, c.pitch, c.span, c.nreg, iters, sink);
+          else hipLaunchKernelGGL((load_kernel<false, 64>), dim3(cus), dim3(512), 0, 0, buf, c.pitch, c.span, c.nreg, iters, sink);
+        } else {
+          if (dma) hipLaunchKernelGGL((load_kernel<true, 8192>), dim3(cus), dim3(512), 0, 0, buf, (size_t)8192, c.span, c.nreg, iters, sink);
+          else hipLaunchKernelGGL((load_kernel<false, 8192>), dim3(cus), dim3(512), 0, 0, buf, (size_t)8192, c.span, c.nreg, iters, sink);
+        }
+      };
+      const float ms = time_ms(launch, 5);
+      printf("load  %-8s %-78s %7.1f GB/s per CU  %6.2f TB/s\n", dma ? "lds-dma" : "to-vgpr", c.name, bytes / cus / (ms * 1e6),
+             bytes / (ms * 1e9));
+    }
+  }
+  // the GEMM's operand stream alone: qkv (N = 2304, K = 768), fc1 (3072, 768), fc2 (768, 3072), proj (768, 768) at 110 views
+  {
+    const int mt = 605;
+    struct G { const char* name; int nt, K, group, mblock; };
+    const G gs[] = {{"qkv  N=2304 K=768 ", 9, 768, 9, 4}, {"fc1  N=3072 K=768 ", 12, 768, 12, 4}, {"proj N=768  K=768 ", 3, 768, 3, 1},
+                    {"fc2  N=768  K=3072", 3, 3072, 3, 1}};
+    char* Wb = buf + ((size_t)1 << 30);  // A at buf (605 * 256 * K * 2 <= 952 MB), W behind it
+    for (const G& g : gs) {
+      const int tiles = mt * g.nt, nk = g.K / 64;
+      const double rounds = (double)tiles / cus;
+      struct V { const char* name; int D, rot, a_panels; };
+      const V vs[] = {{"as the kernel walks it (8 pieces in flight)", 8, 0, 0}, {"16 pieces in flight", 16, 0, 0}, {"4 pieces in flight", 4, 0, 0},
+                      {"A L2-resident (8 panels only)", 8, 0, 8}, {"k start rotated per (n, m in block)", 8, 1, 0},
+                      {"k start rotated per n", 8, 2, 0}, {"rotated per (n, m), 16 in flight", 16, 1, 0}};
+      for (const V& v : vs) {
+        auto launch = [&]() {
+          if (v.D == 8) hipLaunchKernelGGL((gemm_stream_kernel<8>), dim3(tiles), dim3(512), 0, 0, buf, Wb, mt, g.nt, g.K, g.group, g.mblock, v.rot, v.a_panels);
+          else if (v.D == 16) hipLaunchKernelGGL((gemm_stream_kernel<16>), dim3(tiles), dim3(512), 0, 0, buf, Wb, mt, g.nt, g.K, g.group, g.mblock, v.rot, v.a_panels);
+          else hipLaunchKernelGGL((gemm_stream_kernel<4>), dim3(tiles), dim3(512), 0, 0, buf, Wb, mt, g.nt, g.K, g.group, g.mblock, v.rot, v.a_panels);
+        };
+        const float ms = time_ms(launch, 3);
+        printf("gemm-stream %s %-46s %7.1f us per launch  %5.2f us per k-tile and CU  %6.1f GB/s per CU\n", g.name, v.name, ms * 1e3,
+               ms * 1e3 / (rounds * nk), 65536.0 / (ms * 1e3 / (rounds * nk)) / 1e3);
+      }
+    }
+  }
+  // stores: the qkv output of a 110-view launch (154880 x 2304 bf16 = 605 x 9 tiles) and the fc1 output (x 3072 = 12 tiles)
+  for (int nt : {9, 12}) {
+    const int tiles = 605 * nt;
+    const size_t n_bytes = (size_t)nt * 512;
+    const double sb = (double)tiles * 131072;
+    for (int blocked = 0; blocked < 2; ++blocked) {
+      auto launch = [&]() {
+        if (blocked) hipLaunchKernelGGL((store_kernel<true>), dim3(cus), dim3(512), 0, 0, buf, n_bytes, nt, tiles);
+        else hipLaunchKernelGGL((store_kernel<false>), dim3(cus), dim3(512), 0, 0, buf, n_bytes, nt, tiles);
+      };
+      const float ms = time_ms(launch, 5);
+      printf("store %-8s 605 x %2d tiles of 256 x 512 B (%s)%*s %7.1f GB/s per CU  %6.2f TB/s  (%.0f us)\n",
+             blocked ? "blocked" : "rowmajor", nt, blocked ? "one 128-KB burst per tile" : "512-B pieces at the row pitch",
+             blocked ? 9 : 5, "", sb / cus / (ms * 1e6), sb / (ms * 1e9), ms * 1e3);
+    }
+  }
+  return 0;
+}
