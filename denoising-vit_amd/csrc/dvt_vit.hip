@@ -101,6 +101,7 @@ struct GemmBArgs {
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
   double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
+  unsigned* dbg;      // timing build of the 8p kernel (dvt_tune_set(1, 5) + (1, -303)): 16 cycle stamps per wave group and workgroup
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -930,15 +931,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //        (both groups) have retired at the second barrier of phase p.
 //   RAW  a half-tile is read one phase after the phase whose L segment waited for it: the waits
 //        of both groups precede the second barrier of that phase.
-template <int MODE>  // 0 steady state, 1 tile nk-2 (no issue in P3/P4), 2 tile nk-1 (no issue)
+template <int MODE, int SM>  // 0 steady state, 1 tile nk-2 (no issue in P3/P4), 2 tile nk-1 (no issue)
 struct P8Wait;
-template <> struct P8Wait<0> { static constexpr int w1 = 8, w2 = 8, w4 = 8; };
-template <> struct P8Wait<1> { static constexpr int w1 = 8, w2 = 8, w4 = 4; };
-template <> struct P8Wait<2> { static constexpr int w1 = 2, w2 = 0, w4 = -1; };
+template <> struct P8Wait<0, 0> { static constexpr int w1 = 8, w2 = 8, w4 = 8; };
+template <> struct P8Wait<1, 0> { static constexpr int w1 = 8, w2 = 8, w4 = 4; };
+template <> struct P8Wait<2, 0> { static constexpr int w1 = 2, w2 = 0, w4 = -1; };
+// SM = 1 ("8m", dvt_tune_set(1, 5)): the half-tile of a phase is staged in the MIDDLE OF ITS MFMA SEGMENT instead of in the load
+// segment, i.e. AFTER the phase's counted wait instead of before it -- the same issue order, every wait one stage (2
+// instructions) tighter.  Why: the load segment of one wave group (fragment reads + 2 DMA issues at 100-185 cycles + the wait)
+// outlasts the 256-cycle MFMA segment of the other group (426 cycles per half-phase measured, profiles/r04/r04u_*); among bare
+// MFMAs a DMA issue costs ~60.  WAR: the slot is re-staged even later than before.  RAW: unchanged (the waits still precede the
+// second barrier of the phase before the one that reads).
+template <> struct P8Wait<0, 1> { static constexpr int w1 = 6, w2 = 6, w4 = 6; };
+template <> struct P8Wait<1, 1> { static constexpr int w1 = 6, w2 = 6, w4 = 4; };
+template <> struct P8Wait<2, 1> { static constexpr int w1 = 2, w2 = 0, w4 = -1; };
+template <> struct P8Wait<0, 3> : P8Wait<0, 0> {};
+template <> struct P8Wait<1, 3> : P8Wait<1, 0> {};
+template <> struct P8Wait<2, 3> : P8Wait<2, 0> {};
+
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -963,10 +978,28 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
 
+// the same 16 MFMAs with MID (a DMA stage, or nothing) between the two k-steps
+#define P8_MFMA2(IB, JB, AF, BF, MID)                                                             \
+  do {                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+        acc[IB + i][JB + j] =                                                                     \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][0], BF[j][0], acc[IB + i][JB + j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    MID;                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+        acc[IB + i][JB + j] =                                                                     \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][1], BF[j][1], acc[IB + i][JB + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                \
+  } while (0)
+
 // 226-232 VGPRs (hipcc 7.2, per epilogue), not the 256 that two waves per SIMD would allow: 2 x 232 leaves 48
 // registers per SIMD, room for one wave of the fit's leanest streaming kernels beside the two GEMM waves; at 254
 // nothing else fitted and the HBM-bound fit could only time-slice whole CUs with the MFMA-bound extractor.
-template <int EPI>
+template <int EPI, int SM = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1020,6 +1053,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on
 
   bf16x8 a[4][2], b0[2][2], b1[2][2];
+  // SM == 3, the timing build: s_memtime after each of the 8 barriers of k-tiles 4 and 5 (shader cycles; wave-uniform SGPRs)
+  unsigned st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = 0u;
+#define P8_STAMP(t, i)                                                              \
+  do {                                                                              \
+    if constexpr (SM == 3) {                                                        \
+      unsigned long long t64_;                                                      \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_)::"memory");   \
+      __builtin_amdgcn_sched_barrier(0);                                            \
+      const unsigned now_ = (unsigned)t64_;                                         \
+      st[i] = (t) == 4 ? now_ : st[i];                                              \
+      if ((i) == 0) st[13] = (t) == 5 ? now_ : st[13];                              \
+    }                                                                               \
+  } while (0)
 #define P8_TILE(MODE, t)                                                                          \
   do {                                                                                            \
     const int bo_ = ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                                             \
@@ -1033,39 +1081,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       a[i][0] = P8_RD(base_ + OFF_A0 + i * 2048, oa0);                                            \
       a[i][1] = P8_RD(base_ + OFF_A0 + i * 2048, oa1);                                            \
     }                                                                                             \
-    if (MODE <= 1) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                                      \
-    wait_vm<P8Wait<MODE>::w1>();                                                                  \
+    if (MODE == 0) P8_STAMP(t, 8);  /* (its lgkmcnt(0): the 12 fragment reads have COMPLETED) */   \
+    if (MODE <= 1 && SM != 1) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                               \
+    if (MODE == 0) P8_STAMP(t, 9);                                                                \
+    wait_vm<P8Wait<MODE, SM>::w1>();                                                                  \
+    if (MODE == 0) P8_STAMP(t, 10);                                                               \
     P8_BAR();                                                                                     \
+    if (MODE == 0) P8_STAMP(t, 0);                                                            \
     P8_LGKM0();                                                                                   \
-    P8_MFMA(0, 0, a, b0);                                                                         \
+    if constexpr (SM == 1 && MODE <= 1) P8_MFMA2(0, 0, a, b0, P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1)); \
+    else P8_MFMA(0, 0, a, b0);                                                                    \
+    if (MODE == 0) P8_STAMP(t, 11);  /* 16 MFMAs issued */                                         \
     P8_BAR();                                                                                     \
+    if (MODE == 0) P8_STAMP(t, 1);                                                            \
     /* P2 */                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
       b1[j][0] = P8_RD(base_ + OFF_B1 + j * 2048, ob0);                                           \
       b1[j][1] = P8_RD(base_ + OFF_B1 + j * 2048, ob1);                                           \
     }                                                                                             \
-    if (MODE <= 1) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                                      \
-    wait_vm<P8Wait<MODE>::w2>();                                                                  \
+    if (MODE <= 1 && SM != 1) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                               \
+    wait_vm<P8Wait<MODE, SM>::w2>();                                                                  \
     P8_BAR();                                                                                     \
+    if (MODE == 0) P8_STAMP(t, 2);                                                            \
     P8_LGKM0();                                                                                   \
-    P8_MFMA(0, 2, a, b1);                                                                         \
+    if constexpr (SM == 1 && MODE <= 1) P8_MFMA2(0, 2, a, b1, P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1)); \
+    else P8_MFMA(0, 2, a, b1);                                                                    \
     P8_BAR();                                                                                     \
+    if (MODE == 0) P8_STAMP(t, 3);                                                            \
     /* P3 */                                                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
       a[i][0] = P8_RD(base_ + OFF_A1 + i * 2048, oa0);                                            \
       a[i][1] = P8_RD(base_ + OFF_A1 + i * 2048, oa1);                                            \
     }                                                                                             \
-    if (MODE == 0) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                                      \
+    if (MODE == 0 && SM != 1) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                               \
     P8_BAR();                                                                                     \
+    if (MODE == 0) P8_STAMP(t, 4);                                                            \
     P8_LGKM0();                                                                                   \
-    P8_MFMA(4, 2, a, b1);                                                                         \
+    if constexpr (SM == 1 && MODE == 0) P8_MFMA2(4, 2, a, b1, P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0)); \
+    else P8_MFMA(4, 2, a, b1);                                                                    \
     P8_BAR();                                                                                     \
+    if (MODE == 0) P8_STAMP(t, 5);                                                            \
     /* P4 */                                                                                      \
-    if (MODE == 0) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                                      \
-    wait_vm<P8Wait<MODE>::w4>();                                                                  \
+    if (MODE == 0 && SM != 1) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                               \
+    wait_vm<P8Wait<MODE, SM>::w4>();                                                                  \
     P8_BAR();                                                                                     \
-    P8_MFMA(4, 0, a, b0);                                                                         \
+    if (MODE == 0) P8_STAMP(t, 6);                                                            \
+    if constexpr (SM == 1 && MODE == 0) P8_MFMA2(4, 0, a, b0, P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0)); \
+    else P8_MFMA(4, 0, a, b0);                                                                    \
     P8_BAR();                                                                                     \
+    if (MODE == 0) P8_STAMP(t, 7);                                                            \
   } while (0)
 
   int t = 0;
@@ -1076,6 +1140,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef P8_TILE
 #undef P8_STAGE
 #undef P8_RD
+#undef P8_STAMP
+  if constexpr (SM == 3) {
+    if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + i] = st[i];
+    }
+  }
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
   __syncthreads();        // operand buffers become epilogue space
   if constexpr (EPI == EPI_RESID) {
@@ -1143,6 +1214,7 @@ int g_vit_tpw = 0;
 int g_vit_attn_mask = 15;
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = software-pipelined S + deferred max, 1 = the round-2 kernel
 int g_vit_abl = 0;  // dvt_tune_set(1, -300 - mask): ablation mask of the 4w kernel (EPI_BIAS, timing only)
+unsigned* g_vit_dbg = nullptr;  // dvt_vit_debug_buffer
 int g_vit_w4_grid = 0;  // dvt_tune_set(1, -600 - n): workgroups of the 4w kernel (0 = auto: a whole number per CU)
 
 template <int EPI>
@@ -1200,8 +1272,19 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
         return 0;
       }
     }
-    if (g_vit_gemm_variant >= 4)
-      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+    bool stamped = false;
+    if constexpr (EPI == EPI_BIAS) {  // the timing build exists for the bias epilogue only (tools/lab_gemm8p_stamps.py)
+      if (g_vit_gemm_variant == 5 && g_vit_abl == 3) {
+        a.dbg = g_vit_dbg;
+        hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 3>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+        stamped = true;
+      }
+    }
+    if (stamped) {
+    } else if (g_vit_gemm_variant == 5)
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 1>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+    else if (g_vit_gemm_variant >= 4)
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 0>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     else
       hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     DVT_CHECK_LAUNCH();
@@ -2049,14 +2132,14 @@ int dvt_vit_tune(int v) {
     g_vit_group_bytes = v * 1024;
     return 0;
   }
-  if (v < 0 || v > 9 || v == 5) return DVT_E_BADARG;  // (5 was the 8q kernel, removed in round 4)
+  if (v < 0 || v > 9) return DVT_E_BADARG;  // (5: the 8p ring with the DMA issue inside the MFMA segments, "8m")
   g_vit_gemm_variant = v;
   return 0;
 }
 
-// (was: the cycle-stamp buffer of the removed 8q timing build; the symbol stays in the ABI and does nothing)
-extern "C" int dvt_vit_debug_buffer(void* dev_u64x4) {
-  (void)dev_u64x4;
+// device buffer of the 8p timing build (dvt_tune_set(1, 5) + dvt_tune_set(1, -303)): 2 x 16 u32 cycle stamps per workgroup
+extern "C" int dvt_vit_debug_buffer(void* dev_u32) {
+  g_vit_dbg = static_cast<unsigned*>(dev_u32);
   return 0;
 }
 
