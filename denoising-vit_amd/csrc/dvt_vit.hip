@@ -1048,7 +1048,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   P8_STAGE(srcA[1], 0, OFF_A1);
   P8_STAGE(srcA[0], 1, BUF + OFF_A0);
   P8_STAGE(srcB[0], 1, BUF + OFF_B0);
-  wait_vm<8>();
+  if constexpr (SM == 2) wait_vm<6>();  // (its first load segment reads B1 of tile 0 as well)
+  else wait_vm<8>();
   P8_BAR();
   if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on
 
@@ -1132,11 +1133,72 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (MODE == 0) P8_STAMP(t, 7);                                                            \
   } while (0)
 
+// SM == 2 ("8h", dvt_tune_set(1, 10)): the same ring and the same issue order on TWO phases per k-tile instead of
+// four -- X = {reads B0 B1 A0; stage B1(t+1) A1(t+1); wait [A1(t)]} 32 MFMAs (A0,B0) (A0,B1);  Y = {reads A1; stage A0(t+2)
+// B0(t+2); wait [B1(t+1) and older]} 32 MFMAs (A1,B1) (A1,B0) -- i.e. four barriers per k-tile and MFMA segments of 512 cycles.
+// Hazards as in the four-phase walk: a slot is re-staged a full phase (two barriers) or more after the load segments that read
+// it; a half-tile is read in the load segment after the one whose counted wait covered it.
+#define P8H_TILE(MODE, t)                                                                         \
+  do {                                                                                            \
+    const int bo_ = ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                                             \
+    const char* base_ = smem + bo_;                                                               \
+    /* X */                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+      b0[j][0] = P8_RD(base_ + OFF_B0 + j * 2048, ob0);                                           \
+      b0[j][1] = P8_RD(base_ + OFF_B0 + j * 2048, ob1);                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      a[i][0] = P8_RD(base_ + OFF_A0 + i * 2048, oa0);                                            \
+      a[i][1] = P8_RD(base_ + OFF_A0 + i * 2048, oa1);                                            \
+    }                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+      b1[j][0] = P8_RD(base_ + OFF_B1 + j * 2048, ob0);                                           \
+      b1[j][1] = P8_RD(base_ + OFF_B1 + j * 2048, ob1);                                           \
+    }                                                                                             \
+    if (MODE <= 1) {                                                                              \
+      P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                                                   \
+      P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                                                   \
+      wait_vm<8>();                                                                               \
+    } else {                                                                                      \
+      wait_vm<0>();                                                                               \
+    }                                                                                             \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(0, 0, a, b0);                                                                         \
+    P8_MFMA(0, 2, a, b1);                                                                         \
+    P8_BAR();                                                                                     \
+    /* Y */                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      a[i][0] = P8_RD(base_ + OFF_A1 + i * 2048, oa0);                                            \
+      a[i][1] = P8_RD(base_ + OFF_A1 + i * 2048, oa1);                                            \
+    }                                                                                             \
+    if (MODE == 0) {                                                                              \
+      P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                                                   \
+      P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                                                   \
+      wait_vm<6>();                                                                               \
+    } else if (MODE == 1) {                                                                       \
+      wait_vm<2>();                                                                               \
+    }                                                                                             \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(4, 2, a, b1);                                                                         \
+    P8_MFMA(4, 0, a, b0);                                                                         \
+    P8_BAR();                                                                                     \
+  } while (0)
+
   int t = 0;
-  for (; t < nk - 2; ++t) P8_TILE(0, t);
-  P8_TILE(1, t);
-  ++t;
-  P8_TILE(2, t);
+  if constexpr (SM == 2) {
+    for (; t < nk - 2; ++t) P8H_TILE(0, t);
+    P8H_TILE(1, t);
+    ++t;
+    P8H_TILE(2, t);
+  } else {
+    for (; t < nk - 2; ++t) P8_TILE(0, t);
+    P8_TILE(1, t);
+    ++t;
+    P8_TILE(2, t);
+  }
+#undef P8H_TILE
 #undef P8_TILE
 #undef P8_STAGE
 #undef P8_RD
@@ -1247,7 +1309,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.nt_store = g_vit_nt_store;
     const int nk = a.K / GBK;
     if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU) {
-      if (g_vit_gemm_variant >= 6 && a.K >= W4_MIN_K) {
+      if (g_vit_gemm_variant >= 6 && g_vit_gemm_variant <= 9 && a.K >= W4_MIN_K) {
         // 4w: persistent runs of ~`tpw` tiles; the grid is a whole number of workgroups per CU
         const int tiles = (a.M / 256) * nt;
         const int tpw = g_vit_tpw > 0 ? g_vit_tpw : (nk <= 16 ? 3 : 1);
@@ -1281,7 +1343,9 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       }
     }
     if (stamped) {
-    } else if (g_vit_gemm_variant == 5)
+    } else if (g_vit_gemm_variant == 10)
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 2>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+    else if (g_vit_gemm_variant == 5)
       hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 1>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
     else if (g_vit_gemm_variant >= 4)
       hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 0>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
@@ -2132,7 +2196,7 @@ int dvt_vit_tune(int v) {
     g_vit_group_bytes = v * 1024;
     return 0;
   }
-  if (v < 0 || v > 9) return DVT_E_BADARG;  // (5: the 8p ring with the DMA issue inside the MFMA segments, "8m")
+  if (v < 0 || v > 10) return DVT_E_BADARG;  // (5: the 8p ring with the DMA issue inside the MFMA segments, "8m"; 10: two phases per k-tile, "8h")
   g_vit_gemm_variant = v;
   return 0;
 }

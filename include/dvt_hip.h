@@ -268,7 +268,9 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         -600 - n: force n workgroups, 0 = auto]; 8 / 9: the same two with the cheaper GELU of that file (2.7e-4 max
  *         abs deviation from erf-GELU before the bf16 rounding -- the ONE schedule value that changes results beyond
  *         rounding order, opt-in); 0: 256x256 two-stage; 1: always 128x128 two-stage; 2: 256x128 lock-step
- *         three-stage; 3: 256x128 ping-pong; (5 was round 3's "8q" kernel, removed);
+ *         three-stage; 3: 256x128 ping-pong; 5: the 8-phase ring with every half-tile staged inside its phase's MFMA
+ *         segment; 10: the same ring walked in two phases of 32 MFMAs per k-tile (half the barriers) -- both bit-identical
+ *         to 4; 5 + (-303): the cycle-stamp timing build of 4 (tools/lab_gemm8p_stamps.py, dvt_vit_debug_buffer);
  *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation;
  *         -100 - b: b M panels per block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output
  *         stores off / on; -501 / -502: attention kernel of the bf16 extractor, round-2 loop / software-pipelined loop

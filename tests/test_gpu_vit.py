@@ -66,7 +66,7 @@ def test_gemm_bias_vs_torch(L, m, n, k):
     assert rel(y.float(), want) < 6e-3, (m, n, k)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 3, 4, 5, 10])
 @pytest.mark.parametrize("m,n,k", [(512, 256, 128), (2816, 768, 768), (1408, 768, 3072), (256, 384, 192), (1792, 768, 768)])
 def test_gemm_residual_vs_torch(L, m, n, k, variant):
     """x += gamma * (a @ w^T + b) (LayerScale + residual epilogue) on every GEMM schedule: 0 = 256x256
@@ -88,7 +88,7 @@ def test_gemm_residual_vs_torch(L, m, n, k, variant):
     assert float(err.max()) < 2e-3 * float(want.abs().max()), (variant, (m, n, k), float(err.max()))
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7, 10])
 def test_gemm_bias_variants(L, variant):
     """the non-default GEMM schedules against torch on the four ViT-B shapes (one M panel pair each); 6 / 7: the 4-wave
     persistent kernel (csrc/dvt_vit_gemm4w.inc; flush per tile / deferred epilogue) where K >= 640, else 8p"""
@@ -492,12 +492,14 @@ def test_vit_large_full_depth(L):
     assert err32 <= 1e-5 and cos32.min() > 0.999999
 
 
+@pytest.mark.parametrize("variant", [5, 10])
 @pytest.mark.parametrize("n,k,gelu", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 0)])
-def test_gemm_8m_bit_identical_to_8p(L, n, k, gelu):
-    """dvt_tune_set(1, 5): the 8p ring with every half-tile staged in the middle of its phase's MFMA segment (after the phase's
-    counted wait instead of before it; waits one stage tighter).  Same MFMAs in the same order on the same operands, so the
-    output must equal the 8p kernel's BIT FOR BIT -- at a size that keeps every CU busy for many rounds of tiles (a slot
-    re-staged too early or read too early shows up as a different bit somewhere), five launches in a row."""
+def test_gemm_8m_8h_bit_identical_to_8p(L, n, k, gelu, variant):
+    """Two re-schedules of the 8p ring: dvt_tune_set(1, 5) stages every half-tile in the middle of its phase's MFMA segment
+    (after the phase's counted wait instead of before it; waits one stage tighter); dvt_tune_set(1, 10) walks a k-tile in two
+    phases of 32 MFMAs instead of four of 16 (half the barriers, its own counted waits).  Same MFMAs in the same k order on
+    the same operands, so the output must equal the 8p kernel's BIT FOR BIT -- at a size that keeps every CU busy for many
+    rounds of tiles (a slot re-staged or read too early shows up as a different bit somewhere), five launches in a row."""
     m = 256 * 520
     g = torch.Generator(device=DEV).manual_seed(n + k)
     x = (torch.rand(m, k, device=DEV, generator=g) * 2 - 1).bfloat16()
@@ -505,22 +507,22 @@ def test_gemm_8m_bit_identical_to_8p(L, n, k, gelu):
     b = torch.randn(n, device=DEV, generator=g)
     outs = {}
     try:
-        for variant, reps in ((4, 1), (5, 5)):
-            assert L.dvt_tune_set(1, variant) == 0
+        for v, reps in ((4, 1), (variant, 5)):
+            assert L.dvt_tune_set(1, v) == 0
             for r in range(reps):
                 y = torch.full((m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
                 assert L.dvt_vit_gemm_lnfold(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k, None, None, gelu, _s()) == 0
                 torch.cuda.synchronize()
-                outs[(variant, r)] = y
+                outs[(v, r)] = y
     finally:
         L.dvt_tune_set(1, GEMM_DEFAULT)
     ref = outs[(4, 0)].view(torch.int16)
     assert bool(torch.isfinite(outs[(4, 0)].float()).all())
     for r in range(5):
-        assert torch.equal(outs[(5, r)].view(torch.int16), ref), (n, k, r)
+        assert torch.equal(outs[(variant, r)].view(torch.int16), ref), (variant, n, k, r)
 
 
-@pytest.mark.parametrize("variant,grid", [(4, 0), (5, 0), (6, 0), (7, 0), (7, 1), (7, 3), (7, 5), (9, 2)])
+@pytest.mark.parametrize("variant,grid", [(4, 0), (5, 0), (10, 0), (6, 0), (7, 0), (7, 1), (7, 3), (7, 5), (9, 2)])
 @pytest.mark.parametrize("m,n,k,gelu,fold", [(2048, 1024, 768, 1, 1), (1280, 3072, 768, 1, 1), (1536, 2304, 768, 0, 0),
                                              (1024, 512, 1024, 0, 0), (768, 768, 3072, 0, 0)])
 def test_gemm_4w_persistent_vs_fp64(L, m, n, k, gelu, fold, variant, grid):

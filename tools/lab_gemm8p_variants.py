@@ -1,5 +1,5 @@
 """Developer tool: A/B timing of the 8p GEMM and its experiment builds (dvt_tune_set(1, 5) + dvt_tune_set(1, -300 - abl)):
-abl 0 = "8m" (DMA issue inside the MFMA segments).  Round 4 also measured, and removed: accumulators in AGPRs, lgkmcnt(0) right after
+variant 5 = "8m" (DMA issue inside the MFMA segments), 10 = "8h" (two phases per k-tile).  Round 4 also measured, and removed: accumulators in AGPRs, lgkmcnt(0) right after
 the fragment reads / before the barrier (profiles/r04/r04w_*): all within 2 % of 8p.  Variants are interleaved; min and median."""
 import os
 import sys
@@ -14,7 +14,7 @@ from dvt_amd import _lib  # noqa: E402
 dev = torch.device("cuda:0")
 L = _lib.lib()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 110 * 1408
-cases = [(4, 0)] + [(5, int(a)) for a in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]
+cases = [(4, 0)] + [(int(v), 0) for v in (sys.argv[2] if len(sys.argv) > 2 else "5,10").split(",")]
 shapes = [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
 torch.manual_seed(0)
 for name, n, k in shapes:

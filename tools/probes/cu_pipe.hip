@@ -144,6 +144,75 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const char* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- does LDS / LDS-DMA traffic of ONE wave slow the MFMAs of the OTHER wave on the same SIMD?  (the 8p GEMM's premise is that
+// it does not: one wave group issues MFMAs while the other reads fragments and issues the DMA.)  512 threads: waves 0-3 (one per
+// SIMD) run a pure MFMA loop on register operands and time it with s_memtime; waves 4-7 (their SIMD partners) run `partner`:
+//   0 nothing, 1 ds_read_b128 stream (the GEMM's swizzled fragment pattern), 2 LDS-DMA stream from an L2-resident buffer,
+//   3 both interleaved (12 reads : 2 DMA, the mix of a GEMM load segment), 4 the same with the MFMA waves at s_setprio 1
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, int partner, int n_mfma_iters, int n_partner_iters,
+                                                  unsigned long long* out) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < LDS_BYTES / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(i, i * 3, i * 5, i * 7);
+  __syncthreads();
+  if (wave < 4) {
+    bf16x8 a[4], b[2];
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(smem + (lane + 64 * i) * 16);
+    for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const bf16x8*>(smem + (lane + 64 * (4 + i)) * 16);
+    f32x4 acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (partner == 4) __builtin_amdgcn_s_setprio(1);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < n_mfma_iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) sum += acc[i][j][0] + acc[i][j][3];
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) out[blockIdx.x * 4 + wave] = (t1 - t0) | (sum == 123.f ? 1ull << 63 : 0ull);
+  } else if (partner != 0) {
+    const int w = wave - 4;
+    const int row = w * 16 + (lane & 15), cg = lane >> 4;
+    const int o0 = row * 128 + (((0 + cg) ^ (row & 7)) << 4), o1 = row * 128 + (((4 + cg) ^ (row & 7)) << 4);
+    const char* g = src + (size_t)(blockIdx.x & 7) * (2 << 20) + (size_t)t * 16;
+    uint4 x = make_uint4(0, 0, 0, 0);
+    const unsigned long long p0 = __builtin_readcyclecounter();
+    for (int it = 0; it < n_partner_iters; ++it) {
+      asm volatile("" ::: "memory");  // the reads below are loop-invariant otherwise
+      if (partner == 1 || partner >= 3) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          uint4 v0, v1;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"((unsigned)(unsigned long)(lds_ptr_t)(smem + r * 8192 + o0)) : "memory");
+          asm volatile("ds_read_b128 %0, %1" : "=v"(v1) : "v"((unsigned)(unsigned long)(lds_ptr_t)(smem + r * 8192 + o1)) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          x.x ^= v0.x ^ v1.y; x.y ^= v0.z ^ v1.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if (partner >= 2) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)((it * 2 + r) & 127) * 8192),
+                                           (lds_ptr_t)(smem + 49152 + r * 8192 + w * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long p1 = __builtin_readcyclecounter();
+    if (lane == 0) out[(gridDim.x + blockIdx.x) * 4 + w] = p1 - p0;
+    if ((x.x ^ x.y) == 0x1234567u) out[0] = 1;
+  }
+}
+
 template <typename F>
 static float time_ms(F&& launch, int reps) {
   hipEvent_t a, b;
@@ -199,6 +268,30 @@ int main() {
       const float ms = time_ms(launch, 5);
       printf("load  %-8s %-78s %7.1f GB/s per CU  %6.2f TB/s\n", dma ? "lds-dma" : "to-vgpr", c.name, bytes / cus / (ms * 1e6),
              bytes / (ms * 1e9));
+    }
+  }
+  {  // MFMA waves vs LDS / DMA partner waves
+    unsigned long long* mo;
+    CK(hipMalloc(&mo, (size_t)cus * 8 * 8));
+    CK(hipMemset(mo, 0, (size_t)cus * 8 * 8));
+    std::vector<unsigned long long> h(cus * 8);
+    const int n_it = 4000;  // x 16 MFMAs
+    const char* names[] = {"alone", "partner: ds_read_b128 stream", "partner: LDS-DMA stream", "partner: 12 reads : 2 DMA",
+                           "partner: 12 reads : 2 DMA, MFMA waves at s_setprio 1"};
+    for (int partner = 0; partner < 5; ++partner) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(mix_kernel, dim3(cus), dim3(512), 0, 0, buf, partner, n_it, 1 << 20 >> (partner == 2 ? 2 : 4), mo);
+        CK(hipDeviceSynchronize());
+      }
+      CK(hipMemcpy(h.data(), mo, h.size() * 8, hipMemcpyDeviceToHost));
+      double sum = 0, psum = 0;
+      for (int i = 0; i < cus * 4; ++i) sum += (double)(h[i] & ~(1ull << 63));
+      for (int i = cus * 4; i < cus * 8; ++i) psum += (double)h[i];
+      const int pit = 1 << 20 >> (partner == 2 ? 2 : 4);
+      const double pbytes = (double)pit * ((partner == 1 || partner >= 3 ? 12 * 1024.0 : 0.0) + (partner >= 2 ? 2 * 1024.0 : 0.0));
+      printf("mfma-mix %-56s %6.2f cycles per v_mfma_f32_16x16x32_bf16 (16.0 = the pipe's rate); partner waves: %6.1f LDS bytes per cycle and CU over %.1fx the MFMA loop's duration\n",
+             names[partner], sum / (cus * 4) / (n_it * 16.0), partner ? 4.0 * pbytes / (psum / (cus * 4)) : 0.0,
+             partner ? (psum / (cus * 4)) / (sum / (cus * 4)) : 0.0);
     }
   }
   // the GEMM's operand stream alone: qkv (N = 2304, K = 768), fc1 (3072, 768), fc2 (768, 3072), proj (768, 768) at 110 views
