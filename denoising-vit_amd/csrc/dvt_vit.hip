@@ -948,6 +948,19 @@ template <> struct P8Wait<2, 1> { static constexpr int w1 = 2, w2 = 0, w4 = -1; 
 template <> struct P8Wait<0, 3> : P8Wait<0, 0> {};
 template <> struct P8Wait<1, 3> : P8Wait<1, 0> {};
 template <> struct P8Wait<2, 3> : P8Wait<2, 0> {};
+template <> struct P8Wait<0, 6> : P8Wait<0, 0> {};
+template <> struct P8Wait<1, 6> : P8Wait<1, 0> {};
+template <> struct P8Wait<2, 6> : P8Wait<2, 0> {};
+template <> struct P8Wait<0, 7> : P8Wait<0, 0> {};
+template <> struct P8Wait<1, 7> : P8Wait<1, 0> {};
+template <> struct P8Wait<2, 7> : P8Wait<2, 0> {};
+template <> struct P8Wait<0, 8> : P8Wait<0, 0> {};
+template <> struct P8Wait<1, 8> : P8Wait<1, 0> {};
+template <> struct P8Wait<2, 8> : P8Wait<2, 0> {};
+template <> struct P8Wait<0, 9> : P8Wait<0, 0> {};
+template <> struct P8Wait<1, 9> : P8Wait<1, 0> {};
+template <> struct P8Wait<2, 9> : P8Wait<2, 0> {};
+
 
 
 template <int N>
@@ -1001,6 +1014,8 @@ __device__ __forceinline__ void wait_vm() {
 // nothing else fitted and the HBM-bound fit could only time-slice whole CUs with the MFMA-bound extractor.
 template <int EPI, int SM = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
+  unsigned long long entry_t_ = 0;
+  if constexpr (SM >= 3) entry_t_ = __builtin_readcyclecounter();
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1054,6 +1069,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on
 
   bf16x8 a[4][2], b0[2][2], b1[2][2];
+  // SM >= 6: ablation builds for tools/lab_gemm8p_stamps.py (timing only, results wrong): 6 = no LDS-DMA inside the k-loop, 7 = 6 +
+  // the ring parity frozen (compile-time fragment-read addresses), 8 = the kernel as it is (k-loop cycles only), 9 = no fragment reads
+  constexpr bool NO_DMA = SM == 6 || SM == 7, NO_PARITY = SM == 7, NO_READS = SM == 9;
+  if constexpr (NO_READS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i][0] = a[i][1] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b0[j][0] = b0[j][1] = b1[j][0] = b1[j][1] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+  }
   // SM == 3, the timing build: s_memtime after each of the 8 barriers of k-tiles 4 and 5 (shader cycles; wave-uniform SGPRs)
   unsigned st[16];
 #pragma unroll
@@ -1071,21 +1095,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   } while (0)
 #define P8_TILE(MODE, t)                                                                          \
   do {                                                                                            \
-    const int bo_ = ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                                             \
+    const int bo_ = NO_PARITY ? 0 : ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                             \
     const char* base_ = smem + bo_;                                                               \
     /* P1 */                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+    if (!NO_READS) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
       b0[j][0] = P8_RD(base_ + OFF_B0 + j * 2048, ob0);                                           \
       b0[j][1] = P8_RD(base_ + OFF_B0 + j * 2048, ob1);                                           \
     }                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+    if (!NO_READS) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
       a[i][0] = P8_RD(base_ + OFF_A0 + i * 2048, oa0);                                            \
       a[i][1] = P8_RD(base_ + OFF_A0 + i * 2048, oa1);                                            \
     }                                                                                             \
     if (MODE == 0) P8_STAMP(t, 8);  /* (its lgkmcnt(0): the 12 fragment reads have COMPLETED) */   \
-    if (MODE <= 1 && SM != 1) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                               \
+    if (MODE <= 1 && SM != 1 && !NO_DMA) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                               \
     if (MODE == 0) P8_STAMP(t, 9);                                                                \
-    wait_vm<P8Wait<MODE, SM>::w1>();                                                                  \
+    if (!NO_DMA) wait_vm<P8Wait<MODE, SM>::w1>();                                                                  \
     if (MODE == 0) P8_STAMP(t, 10);                                                               \
     P8_BAR();                                                                                     \
     if (MODE == 0) P8_STAMP(t, 0);                                                            \
@@ -1096,12 +1120,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     P8_BAR();                                                                                     \
     if (MODE == 0) P8_STAMP(t, 1);                                                            \
     /* P2 */                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+    if (!NO_READS) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
       b1[j][0] = P8_RD(base_ + OFF_B1 + j * 2048, ob0);                                           \
       b1[j][1] = P8_RD(base_ + OFF_B1 + j * 2048, ob1);                                           \
     }                                                                                             \
-    if (MODE <= 1 && SM != 1) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                               \
-    wait_vm<P8Wait<MODE, SM>::w2>();                                                                  \
+    if (MODE <= 1 && SM != 1 && !NO_DMA) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                               \
+    if (!NO_DMA) wait_vm<P8Wait<MODE, SM>::w2>();                                                                  \
     P8_BAR();                                                                                     \
     if (MODE == 0) P8_STAMP(t, 2);                                                            \
     P8_LGKM0();                                                                                   \
@@ -1110,11 +1134,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     P8_BAR();                                                                                     \
     if (MODE == 0) P8_STAMP(t, 3);                                                            \
     /* P3 */                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+    if (!NO_READS) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
       a[i][0] = P8_RD(base_ + OFF_A1 + i * 2048, oa0);                                            \
       a[i][1] = P8_RD(base_ + OFF_A1 + i * 2048, oa1);                                            \
     }                                                                                             \
-    if (MODE == 0 && SM != 1) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                               \
+    if (MODE == 0 && SM != 1 && !NO_DMA) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                               \
     P8_BAR();                                                                                     \
     if (MODE == 0) P8_STAMP(t, 4);                                                            \
     P8_LGKM0();                                                                                   \
@@ -1123,8 +1147,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     P8_BAR();                                                                                     \
     if (MODE == 0) P8_STAMP(t, 5);                                                            \
     /* P4 */                                                                                      \
-    if (MODE == 0 && SM != 1) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                               \
-    wait_vm<P8Wait<MODE, SM>::w4>();                                                                  \
+    if (MODE == 0 && SM != 1 && !NO_DMA) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                               \
+    if (!NO_DMA) wait_vm<P8Wait<MODE, SM>::w4>();                                                                  \
     P8_BAR();                                                                                     \
     if (MODE == 0) P8_STAMP(t, 6);                                                            \
     if constexpr (SM == 1 && MODE == 0) P8_MFMA2(4, 0, a, b0, P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0)); \
@@ -1186,6 +1210,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     P8_BAR();                                                                                     \
   } while (0)
 
+  unsigned long long loop_t0_ = 0;
+  if constexpr (SM >= 3) loop_t0_ = __builtin_readcyclecounter();
   int t = 0;
   if constexpr (SM == 2) {
     for (; t < nk - 2; ++t) P8H_TILE(0, t);
@@ -1203,10 +1229,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef P8_STAGE
 #undef P8_RD
 #undef P8_STAMP
-  if constexpr (SM == 3) {
+  if constexpr (SM >= 3) {
+    const unsigned loop_cyc_ = (unsigned)(__builtin_readcyclecounter() - loop_t0_);
     if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + i] = st[i];
+      for (int i = 0; i < 13; ++i) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + i] = st[i];
+      p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 14] = loop_cyc_;  // the whole k-loop of this tile (nk k-tiles)
+      p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 15] = (unsigned)nk;
     }
   }
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
@@ -1220,6 +1249,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
+  if constexpr (SM >= 3) {  // ticks from kernel entry to the last store issued AND retired
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned total_ = (unsigned)(__builtin_readcyclecounter() - entry_t_);
+    if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 13] = total_;
+  }
 }
 
 // (Round 3's "8q" kernel -- the 8p ring with a register epilogue and a tile loop -- lived here; it never beat 8p
@@ -1336,9 +1370,16 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     }
     bool stamped = false;
     if constexpr (EPI == EPI_BIAS) {  // the timing build exists for the bias epilogue only (tools/lab_gemm8p_stamps.py)
-      if (g_vit_gemm_variant == 5 && g_vit_abl == 3) {
+      if (g_vit_gemm_variant == 5 && (g_vit_abl == 3 || (g_vit_abl >= 6 && g_vit_abl <= 9))) {
         a.dbg = g_vit_dbg;
-        hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 3>), dim3((a.M / 256) * nt), dim3(512), 0, s, a);
+        const dim3 grid_((a.M / 256) * nt);
+        switch (g_vit_abl) {
+          case 3: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 3>), grid_, dim3(512), 0, s, a); break;
+          case 6: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 6>), grid_, dim3(512), 0, s, a); break;
+          case 7: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 7>), grid_, dim3(512), 0, s, a); break;
+          case 8: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 8>), grid_, dim3(512), 0, s, a); break;
+          default: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 9>), grid_, dim3(512), 0, s, a); break;
+        }
         stamped = true;
       }
     }

@@ -1,4 +1,5 @@
-"""Developer tool: cycle anatomy of the 8p GEMM's k-loop from its timing build (dvt_tune_set(1, 5) + (1, -303)): s_memtime
+"""Developer tool (CAVEAT: the stamps perturb the loop -- 3300-3600 cycles per k-tile with them, 2360-2530 without, see
+tools/lab_gemm8p_ablate.py and profiles/r04/r04w_*; use the intervals as a picture of the instrumented build only): cycle anatomy of the 8p GEMM's k-loop from its timing build (dvt_tune_set(1, 5) + (1, -303)): s_memtime
 after each of the 8 barriers of k-tiles 4 and 5, for one wave of each wave group (wave 0 = group 0, wave 4 = group 1, which runs
 half a phase behind), every workgroup.  Prints the eight barrier-to-barrier intervals of a k-tile (shader cycles).
 
@@ -22,6 +23,8 @@ L.dvt_vit_debug_buffer.argtypes = [C.c_void_p]
 L.dvt_vit_debug_buffer.restype = C.c_int
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 110 * 1408
 shapes = [("qkv", 2304, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
+if len(sys.argv) > 2:  # "name:N:K,..." -- e.g. 2048 rows x "wide:8192:768,wide:8192:3072": 256 tiles whose operands stay on chip
+    shapes = [(a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[2].split(",")]
 torch.manual_seed(0)
 for name, n, k in shapes:
     x = torch.randn(M, k, device=dev).bfloat16()

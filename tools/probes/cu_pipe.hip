@@ -213,6 +213,128 @@ __global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, 
   }
 }
 
+// ---- the 8p k-loop in miniature: which ingredient stretches it from the pipe's 2048 cycles per k-tile to the kernel's ~3400?
+// 8 waves, two groups half a phase apart, four phases per k-tile {fragment reads; barrier; 16 MFMAs; barrier} with 8p's read
+// pattern (12 / 4 / 8 / 0 ds_read_b128 per wave) and 8p's fragment-register reuse (loads TIED to the registers the previous
+// segments read).  FLAGS: 1 = the fragments of consecutive k-tiles alternate between two full register sets instead;
+// 2 = 8p's LDS-DMA staging (2 x global_load_lds per phase and wave into the ring, counted vmcnt(8) in phases 1, 2, 4; L2-resident
+// source); 4 = 32 accumulators per wave in 8p's quadrant order (instead of 8 reused by every phase); 8 = s_setprio 1 around the
+// MFMA segments; 16 = the LDS image holds random bf16 values (instead of a counter pattern); 32 = the fragment-read addresses are
+// COMPUTED in each load segment (one VALU op per address register from a run-time buffer offset, as the kernel's k-loop does)
+// instead of being immediates.
+template <int FLAGS>
+__device__ __forceinline__ void kloop_body(const char* __restrict__ src, int n_tiles, unsigned long long* out) {
+  __shared__ __attribute__((aligned(16))) char smem[131072 + 8192];
+  constexpr bool DB = FLAGS & 1, DMA = FLAGS & 2, ACC32 = FLAGS & 4, PRIO = FLAGS & 8, RND = FLAGS & 16, VADDR = FLAGS & 32;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
+  for (int i = t; i < 131072 / 16; i += 512) {
+    unsigned h = i * 2654435761u + blockIdx.x * 40503u;
+    uint4 v = make_uint4(i, i * 3, i * 5, i * 7);
+    if (RND) {  // bf16 pairs in (-2, 2): exponent bits 0x3f80 / 0xbf80 + random mantissa
+      unsigned w[4];
+      for (int q = 0; q < 4; ++q) { h = h * 1664525u + 1013904223u; w[q] = (h & 0x807f807fu) | 0x3f803f80u; }
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    reinterpret_cast<uint4*>(smem)[i] = v;
+  }
+  __syncthreads();
+  const int cg = lane >> 4;
+  const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
+  const int oa0_ = ra * 128 + (((0 + cg) ^ (ra & 7)) << 4), oa1_ = ra * 128 + (((4 + cg) ^ (ra & 7)) << 4);
+  const int ob0_ = rb * 128 + (((0 + cg) ^ (rb & 7)) << 4), ob1_ = rb * 128 + (((4 + cg) ^ (rb & 7)) << 4);
+  const int rt_par = n_tiles < 0 ? 16 : 0;
+  constexpr int NS = DB ? 2 : 1;
+  bf16x8 a0[NS][4][2], a1[NS][4][2], b0[NS][2][2], b1[NS][2][2];
+  for (int n = 0; n < NS; ++n)
+    for (int k = 0; k < 2; ++k) {
+      for (int i = 0; i < 4; ++i) a0[n][i][k] = a1[n][i][k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      for (int j = 0; j < 2; ++j) b0[n][j][k] = b1[n][j][k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  constexpr int NA = ACC32 ? 8 : 4, NB = ACC32 ? 4 : 2;
+  f32x4 acc[NA][NB];
+  for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // DMA sources: as in 8p, two passes of 512 threads x 16 B per half-tile; a 2-MB region per XCD keeps them L2 hits
+  const char* g0 = src + (size_t)(blockIdx.x & 7) * (2 << 20) + (size_t)((blockIdx.x >> 3) & 15) * 65536 + (size_t)t * 16;
+  char* const ldsw = smem + wave * 1024;
+// the destination is TIED to the variable's current register ("+v"): the new fragment lands where the old one lived
+#define KL_LD(dst, off) asm volatile("ds_read_b128 %0, %1" : "+v"(dst) : "v"((unsigned)(unsigned long)(lds_ptr_t)(smem + (off))) : "memory")
+#define KL_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KL_STAGE(slot_off, kofs)                                                                              \
+  do {                                                                                                        \
+    if constexpr (DMA) {                                                                                      \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (kofs)), (lds_ptr_t)(ldsw + (slot_off)), 16, 0, 0);        \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (kofs) + 8192), (lds_ptr_t)(ldsw + (slot_off) + 8192), 16, 0, 0); \
+    }                                                                                                         \
+  } while (0)
+#define KL_WAIT() do { if constexpr (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
+#define KL_MFMA(IB, JB, AF, BF)                                                                               \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+        acc[(ACC32 ? IB : 0) + i][(ACC32 ? JB : 0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
+            AF[i][ks], BF[j][ks], acc[(ACC32 ? IB : 0) + i][(ACC32 ? JB : 0) + j], 0, 0, 0);                  \
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);                                                        \
+  } while (0)
+  // ring: parity buffers of 64 KB: A0 +0, A1 +16384, B0 +32768, B1 +49152
+#define KL_TILE(S)                                                                                            \
+  do {                                                                                                        \
+    constexpr int bo_ = (S) * 65536, bn_ = bo_ ^ 65536;                                                       \
+    int rt_ = 0;                                                                                              \
+    if constexpr (VADDR) { rt_ = rt_par; asm volatile("" : "+s"(rt_)); } /* opaque run-time 0: the adds below are real VALU ops */ \
+    const int oa0 = oa0_ + rt_, oa1 = oa1_ + rt_, ob0 = ob0_ + rt_, ob1 = ob1_ + rt_;                          \
+    auto& A0 = a0[DB ? (S) : 0];                                                                              \
+    auto& A1 = DB ? a1[(S)] : a0[0]; /* reuse: A1 lands in A0's registers, as in 8p */                        \
+    auto& B0 = b0[DB ? (S) : 0];                                                                              \
+    auto& B1 = b1[DB ? (S) : 0];                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) { KL_LD(B0[j][0], bo_ + 32768 + j * 2048 + ob0); KL_LD(B0[j][1], bo_ + 32768 + j * 2048 + ob1); } \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { KL_LD(A0[i][0], bo_ + i * 2048 + oa0); KL_LD(A0[i][1], bo_ + i * 2048 + oa1); }                 \
+    KL_STAGE(bn_ + 49152, kq * 16384); KL_WAIT();                                                             \
+    KL_BAR(); KL_MFMA(0, 0, A0, B0); KL_BAR();                                                                \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) { KL_LD(B1[j][0], bo_ + 49152 + j * 2048 + ob0); KL_LD(B1[j][1], bo_ + 49152 + j * 2048 + ob1); } \
+    KL_STAGE(bn_ + 16384, kq * 16384 + 16384 * 64); KL_WAIT();                                                \
+    KL_BAR(); KL_MFMA(0, 2, A0, B1); KL_BAR();                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { KL_LD(A1[i][0], bo_ + 16384 + i * 2048 + oa0); KL_LD(A1[i][1], bo_ + 16384 + i * 2048 + oa1); } \
+    KL_STAGE(bo_ + 0, kq * 16384 + 16384 * 128);                                                              \
+    KL_BAR(); KL_MFMA(4, 2, A1, B1); KL_BAR();                                                                \
+    KL_STAGE(bo_ + 32768, kq * 16384 + 16384 * 192); KL_WAIT();                                               \
+    KL_BAR(); KL_MFMA(4, 0, A1, B0); KL_BAR();                                                                \
+    kq = (kq + 1) & 3;                                                                                        \
+  } while (0)
+  int kq = 0;
+  if (wm == 1) KL_BAR();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < n_tiles; it += 2) {
+    KL_TILE(0);
+    KL_TILE(1);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wm == 0) KL_BAR();
+  float sum = 0.f;
+  for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) sum += acc[i][j][0] + acc[i][j][2];
+  if (lane == 0) out[blockIdx.x * 8 + wave] = (t1 - t0) | (sum == 123.f ? 1ull << 63 : 0ull);
+#undef KL_TILE
+#undef KL_MFMA
+#undef KL_WAIT
+#undef KL_STAGE
+#undef KL_BAR
+#undef KL_LD
+}
+template <int FLAGS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void kloop_kernel(const char* src, int n_tiles, unsigned long long* out) {
+  kloop_body<FLAGS>(src, n_tiles, out);
+}
+
+// ---- what does one s_memtime tick last?  (one wave spins until the counter has advanced by `ticks`)
+__global__ void tick_kernel(unsigned long long ticks, unsigned long long* out) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  unsigned long long t1 = t0;
+  while (t1 - t0 < ticks) t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) out[0] = t1 - t0;
+}
+
 template <typename F>
 static float time_ms(F&& launch, int reps) {
   hipEvent_t a, b;
@@ -269,6 +391,54 @@ int main() {
       printf("load  %-8s %-78s %7.1f GB/s per CU  %6.2f TB/s\n", dma ? "lds-dma" : "to-vgpr", c.name, bytes / cus / (ms * 1e6),
              bytes / (ms * 1e9));
     }
+  }
+  {  // s_memtime calibration
+    unsigned long long* to;
+    CK(hipMalloc(&to, 8));
+    const unsigned long long ticks = 200000000ull;
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, 0, 1000ull, to);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, 0, ticks, to);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("s_memtime: %llu ticks in %.3f ms = %.1f MHz (an idle chip: one wave spinning)\n", ticks, ms, ticks / (ms * 1e3));
+  }
+  {  // the 8p k-loop in miniature, ingredient by ingredient
+    unsigned long long* ko;
+    CK(hipMalloc(&ko, (size_t)cus * 8 * 8));
+    std::vector<unsigned long long> h(cus * 8);
+    const int n_tiles = 2000;
+    auto run = [&](int flags, const char* name) {
+      for (int rep = 0; rep < 2; ++rep) {
+        switch (flags) {
+#define KCASE(F) case F: hipLaunchKernelGGL(kloop_kernel<F>, dim3(cus), dim3(512), 0, 0, buf, n_tiles, ko); break;
+          KCASE(0) KCASE(1) KCASE(2) KCASE(4) KCASE(6) KCASE(14) KCASE(30) KCASE(16) KCASE(20) KCASE(32) KCASE(62)
+#undef KCASE
+        }
+        CK(hipDeviceSynchronize());
+      }
+      CK(hipMemcpy(h.data(), ko, h.size() * 8, hipMemcpyDeviceToHost));
+      double sum = 0;
+      for (auto v : h) sum += (double)(v & ~(1ull << 63));
+      printf("k-loop   %-78s %7.0f cycles per k-tile (2048 = the pipe's rate)\n", name, sum / h.size() / n_tiles);
+    };
+    run(0, "8p's phases, reads and register reuse; no DMA, 8 accumulators, pattern data");
+    run(1, "+ fresh fragment registers (two sets)");
+    run(16, "+ random bf16 data in LDS");
+    run(4, "+ 32 accumulators (8p's quadrants)");
+    run(20, "+ 32 accumulators + random data");
+    run(2, "+ LDS-DMA staging (2 per phase, vmcnt(8) in phases 1, 2, 4)");
+    run(6, "+ DMA + 32 accumulators");
+    run(14, "+ DMA + 32 accumulators + s_setprio");
+    run(30, "+ DMA + 32 accumulators + s_setprio + random data  (= 8p's k-loop)");
+    run(32, "first line + fragment-read addresses computed by VALU ops in every load segment");
+    run(62, "8p's k-loop + those VALU ops");
   }
   {  // MFMA waves vs LDS / DMA partner waves
     unsigned long long* mo;
