@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned loop_cyc_ = (unsigned)(__builtin_readcyclecounter() - loop_t0_);
     if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
 #pragma unroll
-      for (int i = 0; i < 13; ++i) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + i] = st[i];
+      for (int i = 0; i < 10; ++i) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + i] = st[i];
       p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 14] = loop_cyc_;  // the whole k-loop of this tile (nk k-tiles)
       p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 15] = (unsigned)nk;
     }
@@ -1252,7 +1252,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if constexpr (SM >= 3) {  // ticks from kernel entry to the last store issued AND retired
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned total_ = (unsigned)(__builtin_readcyclecounter() - entry_t_);
-    if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 13] = total_;
+    if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
+      unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 2 + wm) * 16;
+      d_[13] = total_;
+      d_[12] = (unsigned)entry_t_;                                    // absolute tick of the kernel entry (low 32 bits)
+      d_[11] = __builtin_amdgcn_s_getreg((31 << 11) | 4);             // HW_REG_HW_ID: wave / simd / cu / sh / se
+      d_[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);            // HW_REG_XCC_ID
+    }
   }
 }
 

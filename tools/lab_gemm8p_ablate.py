@@ -46,7 +46,23 @@ for name, M, n, k in shapes:
         st = dbg.cpu().numpy().astype(np.uint32).reshape(tiles, 2, 16)
         cyc = st[:, :, 14].astype(np.float64) / np.maximum(st[:, :, 15], 1)
         tot = st[:, 0, 13].astype(np.float64)  # ticks from kernel entry to the last store retired, per workgroup
-        # the launch keeps 256 CUs busy with one workgroup each: wall ~ sum of per-workgroup ticks / (256 x tick rate)
+        if build == 8:  # per CU: how much of the launch's span (in ticks) is spent INSIDE workgroups, and what clock does the span imply
+            ent = st[:, 0, 12].astype(np.int64)
+            cu = (st[:, 0, 10].astype(np.int64) & 0xF) << 16 | (st[:, 0, 11].astype(np.int64) & 0xFF00)  # xcc | se / sh / cu bits
+            tt = st[:, 0, 13].astype(np.int64)
+            util, spans = [], []
+            for c in np.unique(cu):  # s_memtime is not synchronised between XCDs: spans per CU
+                sel = cu == c
+                e = ent[sel]
+                rel = ((e - e[0] + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)
+                rel = rel - rel.min()
+                sp = float((rel + tt[sel]).max())
+                spans.append(sp)
+                util.append(tt[sel].sum() / sp)
+            util, spans = np.array(util), np.array(spans)
+            print(f"    {len(util)} CUs; per CU: first entry -> last exit = {np.median(spans):.0f} ticks (median) = {np.median(spans) / wall_us:.0f} MHz "
+                  f"against the launch's wall time; inside workgroups {np.median(util) * 100:.1f} % of that span (min {util.min() * 100:.1f} %, max "
+                  f"{util.max() * 100:.1f} %), {sel.sum()} workgroups on the last CU", flush=True)
         mhz = tot.sum() / 256.0 / wall_us
         print(f"{name:14s} M={M:6d} N={n:5d} K={k:5d}  build {build}: k-loop {np.median(cyc):7.0f} cycles per k-tile (p10 "
               f"{np.percentile(cyc, 10):.0f}, p90 {np.percentile(cyc, 90):.0f}); whole workgroup {np.median(tot):8.0f} ticks; launch "
