@@ -101,7 +101,7 @@ struct GemmBArgs {
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
   double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
-  unsigned* dbg;      // timing build of the 8p kernel (dvt_tune_set(1, 5) + (1, -303)): 16 cycle stamps per wave group and workgroup
+  unsigned* dbg;      // timing builds of the 8p kernel (dvt_vit_debug_buffer): 24 u32 per wave group and workgroup
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -1233,9 +1233,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned loop_cyc_ = (unsigned)(__builtin_readcyclecounter() - loop_t0_);
     if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
 #pragma unroll
-      for (int i = 0; i < 10; ++i) p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + i] = st[i];
-      p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 14] = loop_cyc_;  // the whole k-loop of this tile (nk k-tiles)
-      p.dbg[((size_t)blockIdx.x * 2 + wm) * 16 + 15] = (unsigned)nk;
+      unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 2 + wm) * 24;  // 24 u32 per (workgroup, wave group): 0..13 stamps, 16..21 below
+      for (int i = 0; i < 14; ++i) d_[i] = st[i];
+      d_[20] = loop_cyc_;  // the whole k-loop of this tile (nk k-tiles)
+      d_[21] = (unsigned)nk;
     }
   }
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
@@ -1253,11 +1254,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned total_ = (unsigned)(__builtin_readcyclecounter() - entry_t_);
     if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
-      unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 2 + wm) * 16;
-      d_[13] = total_;
-      d_[12] = (unsigned)entry_t_;                                    // absolute tick of the kernel entry (low 32 bits)
-      d_[11] = __builtin_amdgcn_s_getreg((31 << 11) | 4);             // HW_REG_HW_ID: wave / simd / cu / sh / se
-      d_[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20);            // HW_REG_XCC_ID
+      unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 2 + wm) * 24;
+      d_[19] = total_;
+      d_[18] = (unsigned)entry_t_;                                    // absolute tick of the kernel entry (low 32 bits)
+      d_[17] = __builtin_amdgcn_s_getreg((31 << 11) | 4);             // HW_REG_HW_ID: wave / simd / cu / sh / se
+      d_[16] = __builtin_amdgcn_s_getreg((31 << 11) | 20);            // HW_REG_XCC_ID
     }
   }
 }
@@ -2248,7 +2249,7 @@ int dvt_vit_tune(int v) {
   return 0;
 }
 
-// device buffer of the 8p timing build (dvt_tune_set(1, 5) + dvt_tune_set(1, -303)): 2 x 16 u32 cycle stamps per workgroup
+// device buffer of the 8p timing builds (dvt_tune_set(1, 5) + dvt_tune_set(1, -300 - build), build 3, 6..9): 2 x 24 u32 per workgroup
 extern "C" int dvt_vit_debug_buffer(void* dev_u32) {
   g_vit_dbg = static_cast<unsigned*>(dev_u32);
   return 0;

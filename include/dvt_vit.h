@@ -157,10 +157,12 @@ int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, i
 int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
                       int n_valid, void* stream);
 
-/* Developer instrumentation (no reference counterpart): device buffer of (M/256)*(N/256) tiles x 8 waves x 4 uint64 that the
- * timing build of GEMM schedule 5 (dvt_tune_set(1, -364), EPI_BIAS entry point only) fills with cycle counts per tile and wave:
- * [0] k-loop, [1] epilogue issue, [2] store drain, [3] start stamp.  NULL switches it off. */
-int dvt_vit_debug_buffer(void* dev_u64x4);
+/* Developer instrumentation (no reference counterpart): device buffer of (M/256)*(N/256) tiles x 2 wave groups x 24 uint32 that
+ * the timing builds of the 8p GEMM schedule (dvt_tune_set(1, 5) + dvt_tune_set(1, -300 - build), build 3 or 6..9; EPI_BIAS entry
+ * point only; builds 6, 7, 9 are ablations whose results are wrong by construction) fill per workgroup: [0..13] s_memtime stamps
+ * of build 3, [16] XCC_ID, [17] HW_ID, [18] entry tick, [19] ticks entry -> last store retired, [20] k-loop ticks, [21] k-tiles.
+ * tools/lab_gemm8p_ablate.py, tools/lab_gemm8p_stamps.py.  NULL switches it off. */
+int dvt_vit_debug_buffer(void* dev_u32);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ for name, M, n, k in shapes:
     b = torch.randn(n, device=dev)
     y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
     tiles = (M // 256) * (n // 256)
-    dbg = torch.zeros(tiles * 2 * 16, device=dev, dtype=torch.int32)
+    dbg = torch.zeros(tiles * 2 * 24, device=dev, dtype=torch.int32)
     assert L.dvt_vit_debug_buffer(dbg.data_ptr()) == 0
     for build in builds:
         L.dvt_tune_set(1, 5)
@@ -43,13 +43,13 @@ for name, M, n, k in shapes:
         ev1.record()
         torch.cuda.synchronize()
         wall_us = ev0.elapsed_time(ev1) / 4 * 1e3
-        st = dbg.cpu().numpy().astype(np.uint32).reshape(tiles, 2, 16)
-        cyc = st[:, :, 14].astype(np.float64) / np.maximum(st[:, :, 15], 1)
-        tot = st[:, 0, 13].astype(np.float64)  # ticks from kernel entry to the last store retired, per workgroup
+        st = dbg.cpu().numpy().astype(np.uint32).reshape(tiles, 2, 24)
+        cyc = st[:, :, 20].astype(np.float64) / np.maximum(st[:, :, 21], 1)
+        tot = st[:, 0, 19].astype(np.float64)  # ticks from kernel entry to the last store retired, per workgroup
         if build == 8:  # per CU: how much of the launch's span (in ticks) is spent INSIDE workgroups, and what clock does the span imply
-            ent = st[:, 0, 12].astype(np.int64)
-            cu = (st[:, 0, 10].astype(np.int64) & 0xF) << 16 | (st[:, 0, 11].astype(np.int64) & 0xFF00)  # xcc | se / sh / cu bits
-            tt = st[:, 0, 13].astype(np.int64)
+            ent = st[:, 0, 18].astype(np.int64)
+            cu = (st[:, 0, 16].astype(np.int64) & 0xF) << 16 | (st[:, 0, 17].astype(np.int64) & 0xFF00)  # xcc | se / sh / cu bits
+            tt = st[:, 0, 19].astype(np.int64)
             util, spans = [], []
             for c in np.unique(cu):  # s_memtime is not synchronised between XCDs: spans per CU
                 sel = cu == c

@@ -32,7 +32,7 @@ for name, n, k in shapes:
     b = torch.randn(n, device=dev)
     y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
     tiles = (M // 256) * (n // 256)
-    dbg = torch.zeros(tiles * 2 * 16, device=dev, dtype=torch.int32)
+    dbg = torch.zeros(tiles * 2 * 24, device=dev, dtype=torch.int32)
     assert L.dvt_vit_debug_buffer(dbg.data_ptr()) == 0
     for variant, abl in ((4, 0), (5, 3)):
         L.dvt_tune_set(1, variant)
@@ -49,7 +49,7 @@ for name, n, k in shapes:
     L.dvt_tune_set(1, 4)
     L.dvt_tune_set(1, -300)
     L.dvt_vit_debug_buffer(None)
-    st = dbg.cpu().numpy().astype(np.uint32).reshape(tiles, 2, 16)
+    st = dbg.cpu().numpy().astype(np.uint32).reshape(tiles, 2, 24)
     for grp in (0, 1):
         s = st[:, grp, :].astype(np.int64)
         ok = (s[:, :12] != 0).all(axis=1) & (s[:, 13] != 0)
