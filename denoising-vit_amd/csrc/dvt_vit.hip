@@ -1232,8 +1232,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if constexpr (SM >= 3) {
     const unsigned loop_cyc_ = (unsigned)(__builtin_readcyclecounter() - loop_t0_);
     if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
-#pragma unroll
       unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 2 + wm) * 24;  // 24 u32 per (workgroup, wave group): 0..13 stamps, 16..21 below
+#pragma unroll
       for (int i = 0; i < 14; ++i) d_[i] = st[i];
       d_[20] = loop_cyc_;  // the whole k-loop of this tile (nk k-tiles)
       d_[21] = (unsigned)nk;
