@@ -161,3 +161,40 @@ def test_stage1_rejects_unknown_fp32_matmul_before_allocating():
     from dvt_amd import _lib, stage1
     with pytest.raises(_lib.DvtError, match="fp32_matmul"):
         stage1.Stage1(Namespace(fp32_matmul="medium"), "cpu")
+
+
+def test_pipe_timeline_tool_on_a_synthetic_trace(tmp_path, capsys):
+    """tools/pipe_timeline.py (the two-stream pipeline's timeline from a rocprofv3 kernel trace) on a hand-made `kernels`
+    table: two extractor launches per image, a fit that runs beside the second image, one idle gap."""
+    import importlib.util
+    import sqlite3
+    db = tmp_path / "t.db"
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, start integer, end integer, grid_x integer)")
+    rows, t = [], 1000
+    for img in range(3):
+        for launch in range(2):
+            rows.append(("im2col_kernel(float const*)", t, t + 100, 64)); t += 100
+            for blk in range(2):
+                rows.append(("void gemm_bf16_kernel_8p<1, 0>(GemmBArgs)", t, t + 2000, 512)); t += 2000
+                rows.append(("void attention_kernel_v2<15>(...)", t, t + 3000, 1024)); t += 3000
+        if img == 0:
+            t += 2000000  # the extractor waits once (2 ms)
+    f = 1000 + 10200 + 2000000
+    for step in range(40):
+        rows.append(("void fit_rows_kernel<768, false, 16, 8>(FusedArgs)", f, f + 60, 128)); f += 70
+        rows.append(("fit_backward_kernel<16>(BackwardArgs)", f, f + 40, 128)); f += 50
+        rows.append(("void adam_dense_lazy_shadow_kernel<false>(AdamKArgs)", f, f + 30, 256)); f += 40
+    c.executemany("insert into kernels values (?, ?, ?, ?)", rows)
+    c.commit()
+    c.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pipe_timeline", os.path.join(root, "tools", "pipe_timeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(str(db))
+    mod.interference(str(db))
+    out = capsys.readouterr().out
+    assert "6 extractor launches -> 3 images" in out
+    assert "idle before next image" in out and "between image 0 and 1" in out
+    assert "extractor launch duration vs fit steps completed inside it" in out
