@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of bench.py under developer knobs: bash tools/gpu_ab_bench.sh "<args A>" "<args B>" ... (each run: 8 images)
+# same-box A/B of bench.py under developer knobs: bash tools/r04/gpu_ab_bench.sh "<args A>" "<args B>" ... (each run: 8 images)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/${DVT_TAG:-ab}; mkdir -p $O
