@@ -335,6 +335,16 @@ __global__ void tick_kernel(unsigned long long ticks, unsigned long long* out) {
   if (threadIdx.x == 0) out[0] = t1 - t0;
 }
 
+// ---- does s_memtime keep counting while the only wave of a CU is stalled on memory?  (a dependent chain of HBM loads: the wave
+// spends its life in s_waitcnt.)  If ticks / wall time stays at the idle clock, tick counts under load measure the real clock.
+__global__ void chase_kernel(const unsigned* __restrict__ next, int hops, unsigned long long* out) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  unsigned i = threadIdx.x;
+  for (int h = 0; h < hops; ++h) i = next[i];
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = i; }
+}
+
 template <typename F>
 static float time_ms(F&& launch, int reps) {
   hipEvent_t a, b;
@@ -391,6 +401,33 @@ int main() {
       printf("load  %-8s %-78s %7.1f GB/s per CU  %6.2f TB/s\n", dma ? "lds-dma" : "to-vgpr", c.name, bytes / cus / (ms * 1e6),
              bytes / (ms * 1e9));
     }
+  }
+  {  // s_memtime while a lone wave is stalled on dependent HBM loads
+    const size_t n = (size_t)64 << 20;  // 256 MB of indices: every hop is a miss
+    unsigned* nx;
+    unsigned long long* co;
+    CK(hipMalloc(&nx, n * 4));
+    CK(hipMalloc(&co, 16));
+    std::vector<unsigned> hnx(n);
+    unsigned long long x = 88172645463325252ull;
+    for (size_t i = 0; i < n; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; hnx[i] = (unsigned)(x % n); }
+    CK(hipMemcpy(nx, hnx.data(), n * 4, hipMemcpyHostToDevice));
+    const int hops = 4000;
+    hipLaunchKernelGGL(chase_kernel, dim3(1), dim3(64), 0, 0, nx, 10, co);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(chase_kernel, dim3(1), dim3(64), 0, 0, nx, hops, co);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long hco[2];
+    CK(hipMemcpy(hco, co, 16, hipMemcpyDeviceToHost));
+    printf("s_memtime under stalls: %d dependent HBM loads, %llu ticks in %.3f ms = %.1f MHz (%.0f ns per hop): the counter %s while the wave waits\n",
+           hops, hco[0], ms, hco[0] / (ms * 1e3), ms * 1e6 / hops, hco[0] / (ms * 1e3) > 2000.0 ? "keeps running" : "SLOWS DOWN");
   }
   {  // s_memtime calibration
     unsigned long long* to;
