@@ -15,6 +15,7 @@ import torch
 
 CSRC = Path(__file__).resolve().parent.parent / "csrc"
 LIB_PATH = CSRC / "libdvt_hip.so"
+LAB_LIB_PATH = CSRC / "libdvt_hip_lab.so"  # developer build (-DDVT_LAB), see build(lab=True); never loaded by dvt_amd
 HIP_SOURCES = [
     "dvt_grid.hip",
     "dvt_gemm_f32.hip",
@@ -187,34 +188,46 @@ def register_signatures(extra: dict) -> None:
             fn.restype, fn.argtypes = res, args
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source for gfx950 into csrc/libdvt_hip.so (hipcc cross-compiles
-    without a GPU).  Rebuilds only when a source/header is newer than the library."""
+def build(force: bool = False, verbose: bool = False, lab: bool = False) -> Path:
+    """Compile every HIP source for gfx950 into csrc/libdvt_hip.so (hipcc cross-compiles without a GPU): one object per
+    source, compiled in parallel, then one link.  Rebuilds only when a source/header is newer than the library.
+    lab=True builds the DEVELOPER library csrc/libdvt_hip_lab.so with -DDVT_LAB (superseded schedules, experiments and
+    timing builds of csrc/lab/); nothing in dvt_amd loads it (tools/build_lab.py, tools/lab_*.py, tests/test_gpu_lab.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = LAB_LIB_PATH if lab else LIB_PATH
     srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
     deps = srcs + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list((CSRC.parent.parent / "include").glob("*.h"))
+    if lab:
+        deps += list((CSRC / "lab").glob("*.inc"))
     deps = [d for d in deps if d.exists()]
-    if (not force and LIB_PATH.exists()
-            and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps)):
-        return LIB_PATH
+    if (not force and out.exists()
+            and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps)):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           *[str(s) for s in srcs], "-o", str(LIB_PATH)]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DDVT_LAB"] if lab else [])
+    objdir = CSRC / "build" / ("lab" if lab else "product")
+    objdir.mkdir(parents=True, exist_ok=True)
+
+    def compile_one(src: Path) -> Path:
+        obj = objdir / (src.stem + ".o")
+        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=str(CSRC))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(o) for o in objs], "-o", str(out)]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=str(CSRC))
-    return LIB_PATH
+    return out
 
 
-def lib() -> C.CDLL:
-    """Load (once) and type the shared library; fail loudly when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
-        raise DvtError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
-            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    handle = C.CDLL(str(LIB_PATH))
+def open_library(path: Path) -> C.CDLL:
+    """dlopen + type one build of the library (every declared symbol must exist; struct mirrors are verified)."""
+    handle = C.CDLL(str(path))
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
@@ -225,7 +238,19 @@ def lib() -> C.CDLL:
             C.sizeof(FitBuffers)]
     if list(sizes) != mine:
         raise DvtError(f"struct layout mismatch between ctypes mirrors {mine} and C {list(sizes)}")
-    _lib = handle
+    return handle
+
+
+def lib() -> C.CDLL:
+    """Load (once) and type the PRODUCT shared library; fail loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise DvtError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _lib = open_library(LIB_PATH)
     return _lib
 
 

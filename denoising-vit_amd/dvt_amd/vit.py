@@ -53,6 +53,7 @@ _lib.register_signatures({
     "dvt_vit_forward_f32": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
     "dvt_vit_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dvt_vit_debug_buffer": (_I, [_P]),
+    "dvt_vit_is_lab_build": (_I, []),
     "dvt_vit_split3": (_I, [_P, _P, C.c_longlong, _I, _I, _I, _P]),
     "dvt_vit_linear_f32x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dvt_vit_gemm_f32out": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -262,25 +262,22 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * re-entrant on distinct streams).
  * key 0 = fp32 GEMM tile configuration override
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
- * key 1 = ViT bf16 GEMM schedule (4 [default]: 256x256 8-phase ring, 8 waves; 6 / 7: the 4-wave persistent kernel
- *         of csrc/dvt_vit_gemm4w.inc for the bias / GELU (+ folded LayerNorm) epilogues where K >= 640 -- every tile
- *         flushed at its end / DEFERRED epilogue under the next tile's k-loop [-200 - n: target tiles per workgroup,
- *         -600 - n: force n workgroups, 0 = auto]; 8 / 9: the same two with the cheaper GELU of that file (2.7e-4 max
- *         abs deviation from erf-GELU before the bf16 rounding -- the ONE schedule value that changes results beyond
- *         rounding order, opt-in); 0: 256x256 two-stage; 1: always 128x128 two-stage; 2: 256x128 lock-step
- *         three-stage; 3: 256x128 ping-pong; 5: the 8-phase ring with every half-tile staged inside its phase's MFMA
- *         segment; 10: the same ring walked in two phases of 32 MFMAs per k-tile (half the barriers) -- both bit-identical
- *         to 4; 5 + (-303): the cycle-stamp timing build of 4 (tools/lab_gemm8p_stamps.py, dvt_vit_debug_buffer);
- *         values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation;
- *         -100 - b: b M panels per block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output
- *         stores off / on; -501 / -502: attention kernel of the bf16 extractor, round-2 loop / software-pipelined loop
- *         with deferred running max [default]; -510 - mask: schedule mask of that kernel (default 15; csrc/dvt_vit.hip,
- *         attention_kernel_v2: every mask computes the same function); -520 / -521 and -522 / -523: inside
- *         dvt_vit_forward_f32x3, exact-fp32 attention on / off [off] and split kernels instead of split epilogues
- *         on / off [off]; developer instrumentation of schedules 6 / 7: -300 - mask ablations [timing
- *         only, EPI_BIAS entry point, results wrong by construction]).  No other
- *         value changes the result beyond the summation order of the folded-LayerNorm row statistics (fp32, ~1e-7
- *         relative) and, between the two attention kernels, the bf16 rounding of P (different running max);
+ * key 1 = bf16 ViT extractor.  The PRODUCT library accepts only values under which every entry point still computes its
+ *         documented result, and returns DVT_E_BADARG for anything else:
+ *           4 [default] / 3 / 1: GEMM schedule -- 256x256 8-phase ring (whole 256-tiles, else 3) / 256x128 ping-pong (M a
+ *             whole 256-tile, else 1) / 128x128 two-stage;
+ *           values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation; -100 - b: b M panels per
+ *             block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output stores off / on;
+ *           -60 / -61: LayerNorm as its own kernels / folded into the qkv and fc1 GEMMs [default];
+ *           -520 / -521 and -522 / -523: inside dvt_vit_forward_f32x3, exact-fp32 attention on / off [off] and split kernels
+ *             instead of split epilogues on / off [off];
+ *           -502 and -525 (= -510 - 15): the one attention kernel / schedule mask the product contains (accepted, no effect).
+ *         None of these changes a result beyond summation order (fp32 row statistics of the folded LayerNorm, ~1e-7 relative).
+ *         Developer builds (-DDVT_LAB, csrc/lab/, include/dvt_vit.h) add: schedules 0, 2 (superseded), 5, 10 (re-schedules of
+ *         4, bit-identical), 6..9 (4-wave persistent kernel; 8 / 9 with an approximate GELU), -200 - n / -600 - n (its tiles
+ *         per workgroup / grid), -300 - n (ablation mask of the selected 4-wave schedule, or timing build of schedule 5:
+ *         TIMING ONLY, results wrong by construction; reset by every change of schedule), -501 (round-2 attention loop),
+ *         -510 - mask (attention schedule masks);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);

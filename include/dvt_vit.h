@@ -157,11 +157,16 @@ int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, i
 int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
                       int n_valid, void* stream);
 
-/* Developer instrumentation (no reference counterpart): device buffer of (M/256)*(N/256) tiles x 2 wave groups x 24 uint32 that
- * the timing builds of the 8p GEMM schedule (dvt_tune_set(1, 5) + dvt_tune_set(1, -300 - build), build 3 or 6..9; EPI_BIAS entry
- * point only; builds 6, 7, 9 are ablations whose results are wrong by construction) fill per workgroup: [0..13] s_memtime stamps
- * of build 3, [16] XCC_ID, [17] HW_ID, [18] entry tick, [19] ticks entry -> last store retired, [20] k-loop ticks, [21] k-tiles.
- * tools/lab_gemm8p_ablate.py, tools/lab_gemm8p_stamps.py.  NULL switches it off. */
+/* Developer builds (no reference counterpart).  The product library libdvt_hip.so contains only the kernels the extractor
+ * launches; superseded schedules, experiments and timing builds live under csrc/lab/ and are compiled only with -DDVT_LAB
+ * (tools/build_lab.py -> csrc/libdvt_hip_lab.so, loaded by tools/lab_*.py and tests/test_gpu_lab.py, never by dvt_amd).
+ * dvt_vit_is_lab_build: 1 in such a build, 0 in the product library.
+ * dvt_vit_debug_buffer: lab builds only (product: DVT_E_BADARG) -- device buffer of (M/256)*(N/256) tiles x 2 wave groups x 24
+ * uint32 that the timing builds of the 8p GEMM schedule (dvt_tune_set(1, 5) then dvt_tune_set(1, -300 - build), build 3 or 6..9;
+ * EPI_BIAS entry point only; builds 6, 7, 9 are ablations whose results are wrong by construction) fill per workgroup: [0..13]
+ * s_memtime stamps of build 3, [16] XCC_ID, [17] HW_ID, [18] entry tick, [19] ticks entry -> last store retired, [20] k-loop
+ * ticks, [21] k-tiles.  tools/lab_gemm8p_ablate.py, tools/lab_gemm8p_stamps.py.  NULL switches it off. */
+int dvt_vit_is_lab_build(void);
 int dvt_vit_debug_buffer(void* dev_u32);
 
 #ifdef __cplusplus

@@ -9,6 +9,9 @@ ONCE in the build container at the schedule the headline metric is quoted on:
     C = 1024 (ViT-L/14, MLP 128 -> 512 -> 1024) -> tests/golden/fit1000_c1024.npz
 
     python tests/golden/make_fit1000_golden.py [768|1024]        (~6 min per configuration on 8 cores)
+    python tests/golden/make_fit1000_golden.py 768:769           -> tests/golden/fit1000_c768_v769.npz: the metric's LITERAL
+        configuration -- 768 views + the original = 1 052 761 rows, a 3.2-GB feature store, row indices beyond 2^20
+        (main_img_denoising.py:64-76); the oracle's cost is per step (dense Adam), not per view
 
 Inputs are the structured synthetic features of SURVEY.md 8d (tests/test_gpu_fit.synthetic_image: smooth
 field of the global coordinates + a lattice artefact shared by all views + noise), regenerated from seeds on
@@ -35,19 +38,19 @@ KEYS = ("loss", "patch_l2_loss", "cosine_similarity_loss", "residual_loss", "res
 DATA_SEED, INIT_SEED, IDX_SEED = 31, 0, 17
 
 
-def out_path(C):
-    return os.path.join(ROOT, "tests", "golden", f"fit1000_c{C}.npz")
+def out_path(C, views=V):
+    return os.path.join(ROOT, "tests", "golden", f"fit1000_c{C}.npz" if views == V else f"fit1000_c{C}_v{views}.npz")
 
 
 def checksum(tensors) -> float:
     return float(sum(float(t.detach().double().abs().sum()) for t in tensors))
 
 
-def inputs(C):
-    """(feats [V,H,H,C], xy [V,H,H,2], idx [T,B] int32) -- identical on the GPU box (seeded CPU generators)."""
+def inputs(C, views=V):
+    """(feats [views,H,H,C], xy [views,H,H,2], idx [T,B] int32) -- identical on the GPU box (seeded CPU generators)."""
     from tests.test_gpu_fit import synthetic_image
-    feats, xy = synthetic_image(V, H, H, C, seed=DATA_SEED + C)
-    idx = np.random.RandomState(IDX_SEED).randint(0, V * H * H, (T, B)).astype(np.int32)
+    feats, xy = synthetic_image(views, H, H, C, seed=DATA_SEED + C)
+    idx = np.random.RandomState(IDX_SEED).randint(0, views * H * H, (T, B)).astype(np.int32)
     return feats, xy, idx
 
 
@@ -59,9 +62,9 @@ def fresh_modules(C, seed=INIT_SEED):
     return d, f
 
 
-def run(C):
+def run(C, views=V):
     from oracle import fit as ofit
-    feats, xy, idx = inputs(C)
+    feats, xy, idx = inputs(C, views)
 
     def one(perturb):
         d, f = fresh_modules(C)
@@ -82,17 +85,18 @@ def run(C):
     _, tab_p, den_p = one(1e-6)
     cos = torch.nn.functional.cosine_similarity(den.reshape(-1, C).double(), den_p.reshape(-1, C).double(), dim=-1)
     np.savez_compressed(
-        out_path(C), losses=tab, denoised_f16=den.numpy().astype(np.float16), losses_perturbed=tab_p,
+        out_path(C, views), losses=tab, denoised_f16=den.numpy().astype(np.float16), losses_perturbed=tab_p,
         perturbed_cos=np.array([float(cos.mean()), float(cos.min())]),
         feats_checksum=np.float64(checksum([feats, xy])), init_checksum=np.float64(init),
-        meta=np.array([V, H, T, WARM, B, C, DATA_SEED + C, INIT_SEED, IDX_SEED], np.int64))
+        meta=np.array([views, H, T, WARM, B, C, DATA_SEED + C, INIT_SEED, IDX_SEED], np.int64))
     rel = np.abs(tab_p[:, 0] - tab[:, 0]) / np.abs(tab[:, 0])
-    print(f"wrote {out_path(C)} ({os.path.getsize(out_path(C)) / 1e6:.2f} MB); loss {tab[0, 0]:.4f} -> {tab[-1, 0]:.4f}; "
+    print(f"wrote {out_path(C, views)} ({os.path.getsize(out_path(C, views)) / 1e6:.2f} MB); loss {tab[0, 0]:.4f} -> {tab[-1, 0]:.4f}; "
           f"oracle vs itself (init perturbed 1e-6): loss rel diff max {rel.max():.2e} (last step {rel[-1]:.2e}), "
           f"saved tensor cos mean {cos.mean():.6f} min {cos.min():.6f}")
 
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 8)))
-    for C in ([int(a) for a in sys.argv[1:]] or [768, 1024]):
-        run(C)
+    for a in (sys.argv[1:] or ["768", "1024"]):  # "768" or "768:769" = C[:views]
+        c, _, v = a.partition(":")
+        run(int(c), int(v) if v else V)

@@ -38,10 +38,19 @@ def synthetic_image(V, H, W, C, seed=0):
     freq = torch.randn(C, 4, 2, generator=g) * 3
     phase = torch.rand(C, 4, generator=g) * 6.28
     amp = torch.randn(C, 4, generator=g)
-    arg = torch.einsum("vhwd,ckd->vhwck", xy, freq) + phase
-    smooth = (torch.sin(arg) * amp).sum(-1)
+    if V <= 128:
+        arg = torch.einsum("vhwd,ckd->vhwck", xy, freq) + phase
+        smooth = (torch.sin(arg) * amp).sum(-1)
+    else:  # the metric's own 769 views: the [V, H, W, C, 4] intermediates (13 GB each) are formed 32 views at a time
+        smooth = torch.empty(V, H, W, C)
+        for v0 in range(0, V, 32):
+            arg = torch.einsum("vhwd,ckd->vhwck", xy[v0:v0 + 32], freq) + phase
+            smooth[v0:v0 + 32] = (torch.sin(arg) * amp).sum(-1)
     artefact = torch.randn(1, H, W, C, generator=g) * 0.5
-    feats = smooth + artefact + torch.randn(V, H, W, C, generator=g) * 0.1
+    if V <= 128:
+        feats = smooth + artefact + torch.randn(V, H, W, C, generator=g) * 0.1
+    else:  # in place: one 3.2-GB tensor instead of four
+        feats = torch.randn(V, H, W, C, generator=g).mul_(0.1).add_(smooth).add_(artefact)
     return feats.contiguous(), xy.contiguous()
 
 

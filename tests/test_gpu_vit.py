@@ -15,15 +15,17 @@ from oracle import vit as ovit
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-ATTN_DEFAULT = 2   # dvt_tune_set(1, -500 - v): attention kernel of the bf16 extractor (1: round 2, 2: round 3)
+ATTN_DEFAULT = 2   # dvt_tune_set(1, -500 - v): attention kernel of the bf16 extractor (1: round 2 [lab builds], 2: round 3)
 ATTN_MASK_DEFAULT = 15  # dvt_tune_set(1, -510 - mask): schedule mask of the round-3 kernel (csrc/dvt_vit.hip, attention_kernel_v2)
-# (kernel, mask): round 2; round 3 as first measured; the shipped schedule; the two-barrier ping-pong experiment
-ATTN_CASES = [(1, 0), (2, 0), (2, 15), (2, 79)]
+# (kernel, mask).  The product library contains the shipped pair only; tests/test_gpu_lab.py runs the same checks on the
+# developer build's other kernels / masks (round 2; round 3 as first measured; the two-barrier ping-pong experiment)
+ATTN_CASES = [(2, 15)]
+LAB_ATTN_CASES = [(1, 0), (2, 0), (2, 79)]
 
 
 def set_attn(L, variant=ATTN_DEFAULT, mask=ATTN_MASK_DEFAULT):
     assert L.dvt_tune_set(1, -500 - variant) == 0 and L.dvt_tune_set(1, -510 - mask) == 0
-GEMM_DEFAULT = 4   # dvt_tune_set(1, v): ViT GEMM schedule
+GEMM_DEFAULT = 4   # dvt_tune_set(1, v): ViT GEMM schedule (product: 4 = 256x256 8-phase ring, 3 = 256x128 ping-pong, 1 = 128x128)
 
 
 def _s():
@@ -66,12 +68,19 @@ def test_gemm_bias_vs_torch(L, m, n, k):
     assert rel(y.float(), want) < 6e-3, (m, n, k)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 5, 10])
-@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (2816, 768, 768), (1408, 768, 3072), (256, 384, 192), (1792, 768, 768)])
+RESID_SHAPES = [(512, 256, 128), (2816, 768, 768), (1408, 768, 3072), (256, 384, 192), (1792, 768, 768)]
+
+
+@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("m,n,k", RESID_SHAPES)
 def test_gemm_residual_vs_torch(L, m, n, k, variant):
-    """x += gamma * (a @ w^T + b) (LayerScale + residual epilogue) on every GEMM schedule: 0 = 256x256
-    two-stage, 4 = 256x256 8-phase ring, 3 = 256x128 ping-pong.  Every element is checked: the
-    epilogue once lost single dwords of a 16-byte store to a VGPR-overwrite hazard."""
+    check_gemm_residual_vs_torch(L, m, n, k, variant)
+
+
+def check_gemm_residual_vs_torch(L, m, n, k, variant):
+    """x += gamma * (a @ w^T + b) (LayerScale + residual epilogue) on every GEMM schedule: 4 = 256x256 8-phase
+    ring, 3 = 256x128 ping-pong, 1 = 128x128 (lab builds: 0 = 256x256 two-stage, 5 / 10 = re-schedules of 4).
+    Every element is checked: the epilogue once lost single dwords of a 16-byte store to a VGPR-overwrite hazard."""
     torch.manual_seed(m + n + k)
     a = torch.randn(m, k).bfloat16()
     w = (torch.randn(n, k) / k ** 0.5).bfloat16()
@@ -88,10 +97,14 @@ def test_gemm_residual_vs_torch(L, m, n, k, variant):
     assert float(err.max()) < 2e-3 * float(want.abs().max()), (variant, (m, n, k), float(err.max()))
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7, 10])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 def test_gemm_bias_variants(L, variant):
-    """the non-default GEMM schedules against torch on the four ViT-B shapes (one M panel pair each); 6 / 7: the 4-wave
-    persistent kernel (csrc/dvt_vit_gemm4w.inc; flush per tile / deferred epilogue) where K >= 640, else 8p"""
+    check_gemm_bias_variants(L, variant)
+
+
+def check_gemm_bias_variants(L, variant):
+    """the GEMM schedules against torch on the four ViT-B shapes (one M panel pair each); lab builds: 6 / 7 = the 4-wave
+    persistent kernel (csrc/lab/dvt_vit_gemm4w.inc; flush per tile / deferred epilogue) where K >= 640, else 8p"""
     for n, k in [(2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 640)]:
         torch.manual_seed(n + k)
         m = 512
@@ -148,10 +161,16 @@ def test_layernorm_vs_torch(L, dim):
     assert rel(y.float(), F.layer_norm(x, (dim,), w, b, 1e-6)) < 5e-3
 
 
+ATTN_SHAPES = [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370), (1, 1, 128, 1), (1, 1, 256, 65)]
+
+
 @pytest.mark.parametrize("attn_variant", ATTN_CASES)
-@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370), (1, 1, 128, 1),
-                                                        (1, 1, 256, 65)])
+@pytest.mark.parametrize("batch,heads,s_pad,n_valid", ATTN_SHAPES)
 def test_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant):
+    check_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant)
+
+
+def check_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant):
     torch.manual_seed(s_pad + heads)
     dim = heads * 64
     q = torch.randn(batch, s_pad, heads, 64)
@@ -174,9 +193,16 @@ def test_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant):
     assert bool(torch.isfinite(got).all())
 
 
+SPIKES = [(1, 1.5), (5, 1.5), (20, 1.5), (21, 1.5), (7, 1.0), (13, 1.15)]
+
+
 @pytest.mark.parametrize("attn_variant", ATTN_CASES)
-@pytest.mark.parametrize("spike_tile,gain", [(1, 1.5), (5, 1.5), (20, 1.5), (21, 1.5), (7, 1.0), (13, 1.15)])
+@pytest.mark.parametrize("spike_tile,gain", SPIKES)
 def test_attention_late_max_growth(L, attn_variant, spike_tile, gain):
+    check_attention_late_max_growth(L, attn_variant, spike_tile, gain)
+
+
+def check_attention_late_max_growth(L, attn_variant, spike_tile, gain):
     """Online softmax with a running max that JUMPS late (programming guide 5.4 rule 26): one key row of tile
     `spike_tile` is aligned with a few queries so that its logit exceeds everything seen before by far more than the
     deferred-max threshold of the v2 kernel (8), forcing the rescale of o / l in the middle of the key loop -- a branch
@@ -492,76 +518,19 @@ def test_vit_large_full_depth(L):
     assert err32 <= 1e-5 and cos32.min() > 0.999999
 
 
-@pytest.mark.parametrize("variant", [5, 10])
-@pytest.mark.parametrize("n,k,gelu", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 0)])
-def test_gemm_8m_8h_bit_identical_to_8p(L, n, k, gelu, variant):
-    """Two re-schedules of the 8p ring: dvt_tune_set(1, 5) stages every half-tile in the middle of its phase's MFMA segment
-    (after the phase's counted wait instead of before it; waits one stage tighter); dvt_tune_set(1, 10) walks a k-tile in two
-    phases of 32 MFMAs instead of four of 16 (half the barriers, its own counted waits).  Same MFMAs in the same k order on
-    the same operands, so the output must equal the 8p kernel's BIT FOR BIT -- at a size that keeps every CU busy for many
-    rounds of tiles (a slot re-staged or read too early shows up as a different bit somewhere), five launches in a row."""
-    m = 256 * 520
-    g = torch.Generator(device=DEV).manual_seed(n + k)
-    x = (torch.rand(m, k, device=DEV, generator=g) * 2 - 1).bfloat16()
-    w = ((torch.rand(n, k, device=DEV, generator=g) * 2 - 1) / k ** 0.5 * 1.7).bfloat16()
-    b = torch.randn(n, device=DEV, generator=g)
-    outs = {}
-    try:
-        for v, reps in ((4, 1), (variant, 5)):
-            assert L.dvt_tune_set(1, v) == 0
-            for r in range(reps):
-                y = torch.full((m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
-                assert L.dvt_vit_gemm_lnfold(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k, None, None, gelu, _s()) == 0
-                torch.cuda.synchronize()
-                outs[(v, r)] = y
-    finally:
-        L.dvt_tune_set(1, GEMM_DEFAULT)
-    ref = outs[(4, 0)].view(torch.int16)
-    assert bool(torch.isfinite(outs[(4, 0)].float()).all())
-    for r in range(5):
-        assert torch.equal(outs[(variant, r)].view(torch.int16), ref), (variant, n, k, r)
-
-
-@pytest.mark.parametrize("variant,grid", [(4, 0), (5, 0), (10, 0), (6, 0), (7, 0), (7, 1), (7, 3), (7, 5), (9, 2)])
-@pytest.mark.parametrize("m,n,k,gelu,fold", [(2048, 1024, 768, 1, 1), (1280, 3072, 768, 1, 1), (1536, 2304, 768, 0, 0),
-                                             (1024, 512, 1024, 0, 0), (768, 768, 3072, 0, 0)])
-def test_gemm_4w_persistent_vs_fp64(L, m, n, k, gelu, fold, variant, grid):
-    """The 4-wave persistent GEMM with the deferred epilogue (dvt_tune_set(1, 6 .. 9), csrc/dvt_vit_gemm4w.inc) through the
-    fc1-type entry point dvt_vit_gemm_lnfold -- folded LayerNorm + GELU, or the bias epilogue -- against fp64, next to the
-    default 8p kernel (variant 4) on the same operands.  `grid` forces the number of workgroups (dvt_tune_set(1, -600 - n)),
-    so that a workgroup runs SEVERAL tiles: the parked tile drains under the next tile's k-loop, the ring runs through the
-    tile boundary, the last tile is flushed after the loop.  Every element is compared; a second launch must reproduce the
-    first bit for bit (the kernel has no atomics and no data-dependent order).  Variant 9 uses the opt-in cheaper GELU
-    (2.7e-4 max abs deviation from erf-GELU before the bf16 rounding): looser bound."""
-    g = torch.Generator(device=DEV).manual_seed(m + n + k)
-    x = (torch.rand(m, k, device=DEV, generator=g) * 2 - 1 +
-         torch.linspace(-1, 1, k, device=DEV)[None, :] * torch.linspace(0.5, 2, m, device=DEV)[:, None]).bfloat16()
-    w = ((torch.rand(n, k, device=DEV, generator=g) * 2 - 1) / k ** 0.5 * 1.7 +
-         torch.linspace(-0.02, 0.03, n, device=DEV)[:, None]).bfloat16()
-    b = torch.randn(n, device=DEV, generator=g)
-    stats = cs = None
-    acc = x.double() @ w.double().t()
-    if fold:
-        stats = torch.stack([torch.randn(m, device=DEV, generator=g) * 0.3, torch.rand(m, device=DEV, generator=g) + 0.5], 1).contiguous()
-        cs = w.float().sum(1).contiguous()
-        acc = stats[:, 1:2].double() * (acc - stats[:, 0:1].double() * cs.double()[None, :])
-    want = acc + b.double()
-    if gelu:
-        want = F.gelu(want.float().bfloat16().double())  # the reference's autocast semantics: GELU of the bf16 linear output
-    outs = []
-    try:
-        assert L.dvt_tune_set(1, variant) == 0 and L.dvt_tune_set(1, -600 - grid) == 0
-        for _ in range(2):
-            y = torch.full((m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
-            assert L.dvt_vit_gemm_lnfold(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k,
-                                         stats.data_ptr() if fold else None, cs.data_ptr() if fold else None, gelu, _s()) == 0
-            torch.cuda.synchronize()
-            outs.append(y)
-    finally:
-        L.dvt_tune_set(1, GEMM_DEFAULT)
-        L.dvt_tune_set(1, -600)
-    y = outs[0]
-    assert bool(torch.isfinite(y.float()).all())
-    err = float((y.double() - want).abs().max() / want.abs().max())
-    assert err < (8e-3 if variant >= 8 else 6e-3), (variant, grid, (m, n, k), err)
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+def test_product_library_rejects_lab_knobs(L):
+    """the product library carries no superseded / experimental / timing kernel, and dvt_tune_set refuses every
+    value that would have selected one (before: `dvt_tune_set(1, -301)` made a product entry point return wrong numbers with
+    rc 0).  What it accepts are the schedules the tests above hold against the references."""
+    BADARG = -1
+    assert L.dvt_vit_is_lab_build() == 0
+    for v in (0, 2, 5, 6, 7, 8, 9, 10, 11,           # superseded / experimental GEMM schedules
+              -200, -203, -300, -301, -303, -309,     # 4w tiles per workgroup, ablation masks / timing builds
+              -364, -399, -400, -410, -499,           # retired 8q values
+              -500, -501, -503, -510, -511, -589,     # round-2 attention loop, other schedule masks
+              -600, -616):                            # 4w grid
+        assert L.dvt_tune_set(1, v) == BADARG, v
+    assert L.dvt_vit_debug_buffer(None) == BADARG
+    for v in (4, 3, 1, -502, -525, -61, -60, -51, -50, -104, -100, 2400, 4800, -521, -523, GEMM_DEFAULT):
+        assert L.dvt_tune_set(1, v) == 0, v
+    assert L.dvt_tune_set(1, -61) == 0 and L.dvt_tune_set(1, 4800) == 0 and L.dvt_tune_set(1, GEMM_DEFAULT) == 0

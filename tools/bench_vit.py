@@ -17,7 +17,8 @@ with warnings.catch_warnings():
     vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14, allow_random_init=True)
 x = torch.randn(256, 3, 518, 518, device=dev)
 out = torch.empty(256, 37, 37, 768, device=dev)
-L = _lib.lib()
+from tools.labenv import use_lab_library  # noqa: E402
+L = use_lab_library()  # schedules / timing builds of csrc/lab/: the developer library, not the product one
 for kib in (0, 4, 0, 4):
     L.dvt_tune_set(1, kib)  # GEMM variant: 0 = 256x256 2-stage, 4 = 256x256 8-phase
     vit.features_nhwc(x, out=out)

@@ -9,7 +9,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "denoising-vit_amd")]
 from dvt_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
-L = _lib.lib()
+from tools.labenv import use_lab_library  # noqa: E402
+L = use_lab_library()  # schedules / timing builds of csrc/lab/: the developer library, not the product one
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,4").split(",")]
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 128 * 1408
 PAD = int(sys.argv[3]) if len(sys.argv) > 3 else 0

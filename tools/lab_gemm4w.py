@@ -1,4 +1,4 @@
-"""Lab for the 4-wave persistent GEMM (csrc/dvt_vit_gemm4w.inc; dvt_tune_set(1, 6..9)): correctness against fp64 on shapes
+"""Lab for the 4-wave persistent GEMM (csrc/lab/dvt_vit_gemm4w.inc; dvt_tune_set(1, 6..9)): correctness against fp64 on shapes
 that force multi-tile runs (deferred epilogue), a 20-launch race screen (bit-identical repeats), and same-process timing
 against the 8p kernel on the extractor's shapes at 110 views.
 
@@ -15,7 +15,8 @@ import torch  # noqa: E402
 from dvt_amd import _lib  # noqa: E402
 import dvt_amd.vit  # noqa: E402,F401  (registers the ViT entry points)
 
-L = _lib.lib()
+from tools.labenv import use_lab_library  # noqa: E402
+L = use_lab_library()  # schedules / timing builds of csrc/lab/: the developer library, not the product one
 DEV = "cuda"
 S = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
 

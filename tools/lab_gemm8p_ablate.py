@@ -15,7 +15,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "denoising-vit_amd")]
 from dvt_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
-L = _lib.lib()
+from tools.labenv import use_lab_library  # noqa: E402
+L = use_lab_library()  # schedules / timing builds of csrc/lab/: the developer library, not the product one
 L.dvt_vit_debug_buffer.argtypes = [C.c_void_p]
 L.dvt_vit_debug_buffer.restype = C.c_int
 shapes = [("qkv 110 views", 110 * 1408, 2304, 768), ("fc2 110 views", 110 * 1408, 768, 3072), ("on chip", 2048, 8192, 768),

@@ -12,7 +12,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "denoising-vit_amd")]
 from dvt_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
-L = _lib.lib()
+from tools.labenv import use_lab_library  # noqa: E402
+L = use_lab_library()  # schedules / timing builds of csrc/lab/: the developer library, not the product one
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 110 * 1408
 cases = [(4, 0)] + [(int(v), 0) for v in (sys.argv[2] if len(sys.argv) > 2 else "5,10").split(",")]
 shapes = [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]

@@ -20,7 +20,8 @@ with warnings.catch_warnings():
     vit = PretrainedViTWrapper("vit_base_patch14_dinov2.lvd142m", stride=14, allow_random_init=True)
 x = torch.randn(769, 3, 518, 518, device=dev)
 out = torch.empty(769, 37, 37, 768, device=dev)
-L = _lib.lib()
+from tools.labenv import use_lab_library  # noqa: E402
+L = use_lab_library()  # schedules / timing builds of csrc/lab/: the developer library, not the product one
 configs = [("equal launches (round 3)", "1", 128, 4), ("planned launches", "2", 128, 4), ("planned, cap 160", "2", 160, 4),
            ("planned, cap 192", "2", 192, 4), ("planned, cap 256", "2", 256, 4), ("planned, cap 400", "2", 400, 4),
            ("equal, cap 256", "1", 256, 4), ("equal, cap 192", "1", 192, 4)]

@@ -33,8 +33,4 @@ def loop(fn, secs, label):
 print("idle:", smi(), flush=True)
 loop(lambda: L.dvt_vit_gemm_bias(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, 2304, 768, S()), 4.0, "qkv gemm, random operands")
 loop(lambda: L.dvt_vit_gemm_bias(zx.data_ptr(), zw.data_ptr(), b.data_ptr(), y.data_ptr(), M, 2304, 768, S()), 4.0, "qkv gemm, ZERO operands")
-L.dvt_tune_set(1, -501)
-loop(lambda: L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), 110, 12, 1408, 1370, S()), 4.0, "attention v1")
-L.dvt_tune_set(1, -502)
 loop(lambda: L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), 110, 12, 1408, 1370, S()), 4.0, "attention v2")
-L.dvt_tune_set(1, -502)  # default
