@@ -203,18 +203,19 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
 
 // ---- profiling probes (dvt_prof.hip) ----
 extern unsigned g_dvt_prof_mask;
-long dvt_prof_begin(int probe, hipStream_t s);  // -> this scope's sample index (thread-safe, dvt_prof.hip)
-void dvt_prof_end(int probe, long idx, hipStream_t s, double work);
+long dvt_prof_begin(int probe, hipStream_t s, unsigned long long* gen);  // -> this scope's sample index + pool generation (thread-safe, dvt_prof.hip)
+void dvt_prof_end(int probe, long idx, unsigned long long gen, hipStream_t s, double work);
 struct DvtProbeScope {
   int probe;
   hipStream_t s;
   double work;
   long idx;
-  DvtProbeScope(int p, hipStream_t st, double w) : probe(p), s(st), work(w), idx(-1) {
-    if ((g_dvt_prof_mask >> p) & 1u) idx = dvt_prof_begin(probe, s);
+  unsigned long long gen;
+  DvtProbeScope(int p, hipStream_t st, double w) : probe(p), s(st), work(w), idx(-1), gen(0) {
+    if ((g_dvt_prof_mask >> p) & 1u) idx = dvt_prof_begin(probe, s, &gen);
   }
   ~DvtProbeScope() {
-    if (idx >= 0) dvt_prof_end(probe, idx, s, work);
+    if (idx >= 0) dvt_prof_end(probe, idx, gen, s, work);
   }
 };
 int dvt_vit_tune(int gemm_variant);

@@ -23,6 +23,27 @@ def env_ranks() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", 0)))
 
 
+def _first_env(names, default):
+    """Value of the first variable of `names` that is set to something int()-able (SLURM writes e.g. "8(x2)": leading digits)."""
+    for n in names:
+        v = os.environ.get(n, "")
+        n = 0
+        while n < len(v) and v[n].isdigit():
+            n += 1
+        if n:
+            return v[:n]
+    return default
+
+
+_warned: set = set()
+
+
+def _warn_once(msg: str) -> None:
+    if msg not in _warned:
+        _warned.add(msg)
+        print(msg, flush=True)
+
+
 _pin_info: dict | None = None        # what pin_host_threads did for this process (it acts once)
 _orig_affinity: list | None = None   # the CPU set the process started with
 
@@ -35,11 +56,22 @@ def pin_host_threads(local_rank: int | None = None, local_world: int | None = No
     (`sched_setaffinity`) and caps its torch / OpenMP pools to that slice (at most 8 threads).  A single-process run
     (local_world == 1) is left alone.  DVT_NO_AFFINITY=1 disables the pinning; returns what was done."""
     global _pin_info, _orig_affinity
-    local_rank = int(os.environ.get("LOCAL_RANK", 0)) if local_rank is None else local_rank
-    # the ranks of THIS host only: without LOCAL_WORLD_SIZE (a launcher that does not export it) nothing is pinned --
-    # WORLD_SIZE would under-use the host on a multi-node launch
+    if local_rank is None:
+        local_rank = int(_first_env(("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "MPI_LOCALRANKID"), 0))
+    # the ranks of THIS host only.  torch.distributed.run exports LOCAL_WORLD_SIZE; mpirun / srun / hand-rolled spawns
+    # export their own names (ADVICE r4: with only LOCAL_WORLD_SIZE read, such launches silently lost the pinning and
+    # eight ranks fought over the same cores again).  Last resort: WORLD_SIZE when it cannot span more than this host's GPUs.
     if local_world is None:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", 0))
+        local_world = int(_first_env(("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE",
+                                      "MPI_LOCALNRANKS"), 0))
+        if local_world <= 0:
+            world = int(os.environ.get("WORLD_SIZE", 1))
+            n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if 1 < world <= n_dev:
+                local_world = world
+            elif world > 1:
+                _warn_once(f"dvt_amd.dist: WORLD_SIZE={world} but no local world size in the environment (LOCAL_WORLD_SIZE / "
+                           "OMPI_COMM_WORLD_LOCAL_SIZE / SLURM_NTASKS_PER_NODE / MPI_LOCALNRANKS): host threads are NOT pinned")
     info = {"local_rank": local_rank, "local_world": local_world, "pinned": False}
     if local_world <= 1 or os.environ.get("DVT_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
         return info

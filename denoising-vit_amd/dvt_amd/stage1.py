@@ -33,6 +33,16 @@ from .models import MODEL_LIST, PretrainedViTWrapper
 from .utils import misc
 
 
+
+class _ExplicitInt(argparse.Action):
+    """int option that also records that it was GIVEN (namespace.<dest>_explicit): --extract_bsz keeps the reference's default
+    of 32 in the table, but only a value the user typed bounds the extractor's launches."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        setattr(namespace, self.dest, int(values))
+        setattr(namespace, self.dest + "_explicit", True)
+
+
 def get_args(argv=None):
     p = argparse.ArgumentParser(description="DVT Stage-1: Single Image Denoising (MI355X)")
     p.add_argument("--model", type=str, default="vit_base_patch14_dinov2.lvd142m", choices=MODEL_LIST)
@@ -61,11 +71,12 @@ def get_args(argv=None):
     p.add_argument("--lr", type=float, default=0.01)
     p.add_argument("--min_lr", type=float, default=0.001)
     p.add_argument("--weight_decay", type=float, default=1e-5)
-    p.add_argument("--extract_bsz", type=int, default=32,
-                   help="the reference's DataLoader batch for feature extraction (main_img_denoising.py:196).  Kept with "
-                        "its default for CLI compatibility; here the views are already on the device and results do not "
-                        "depend on the batching (tested), so the number of views per extractor LAUNCH is its own knob, "
-                        "--extract_launch_views")
+    p.add_argument("--extract_bsz", type=int, default=32, action=_ExplicitInt,
+                   help="the reference's DataLoader batch for feature extraction (main_img_denoising.py:196; its default 32). "
+                        "Here the views are already on the device and results do not depend on the batching (tested), so the "
+                        "number of views per extractor LAUNCH is its own knob, --extract_launch_views.  An EXPLICIT "
+                        "--extract_bsz still bounds the launches (and with them the extractor's workspace, ~26 MB per view "
+                        "for ViT-B/14) when --extract_launch_views is left at 0")
     p.add_argument("--pixel_bsz", type=int, default=2048)
     p.add_argument("--output_dir", type=str, default="./work_dirs/demo")
     p.add_argument("--num_vis_samples", type=int, default=5)
@@ -197,8 +208,12 @@ class Stage1:
                           else _cu_masked_stream(dev, fit_cus, 32 - fit_cus))
         else:
             self.s_vit = self.s_fit = torch.cuda.current_stream(dev)
-        # views per extractor launch (NOT the reference's --extract_bsz, which is a DataLoader batch and is only accepted)
-        self.extract_launch_views = max(1, int(getattr(args, "extract_launch_views", 0) or 400))
+        # views per extractor launch: --extract_launch_views, else an EXPLICIT --extract_bsz (the reference's DataLoader
+        # batch; a user who passes a small one to bound memory keeps that bound -- ADVICE r4), else 400
+        elv = int(getattr(args, "extract_launch_views", 0) or 0)
+        ebs = getattr(args, "extract_bsz", None) if getattr(args, "extract_bsz_explicit", False) else None
+        self.extract_launch_views = max(1, elv if elv > 0 else (min(400, int(ebs)) if ebs else 400))
+        self._plan_logged = False
         # `--dtype` is the reference's one precision switch (main_img_denoising.py:173, :257): float32 = fp32
         # extractor AND fp32-operand fit (autocast off, its default); bfloat16 = both under bf16 autocast
         self.extract_dtype = ("bfloat16" if str(getattr(args, "dtype", "float32")) in
@@ -220,8 +235,15 @@ class Stage1:
 
     # -- single-image pieces (each enqueues on the CURRENT stream) -------------------------
     def extract(self, slot: _Slot) -> None:
-        """Feature extraction of all views into the feature store (:315-339), NHWC, no
-        NCHW round trip; batches of 128 views keep every GEMM at M = 128*1408 rows."""
+        """Feature extraction of all views into the feature store (:315-339), NHWC, no NCHW round trip, in launches of at
+        most `extract_launch_views` views (default cap 400: 769 views -> 398 + 371, dvt_amd.vit.plan_launches)."""
+        if not self._plan_logged:  # once: what the launches and their workspace will be
+            self._plan_logged = True
+            eng = self.vit._engine(self.device, self.extract_dtype, self.extract_matmul)
+            plan = eng.launch_plan(slot.views.shape[0], self.extract_launch_views)
+            print(f"extractor: {slot.views.shape[0]} views per image in launches of {plan} views "
+                  f"(cap {self.extract_launch_views}), workspace {eng.workspace_bytes(max(plan)) / 2**30:.1f} GiB, {self.extract_dtype}",
+                  flush=True)
         with torch.no_grad():
             self.vit.features_nhwc(slot.views, self.layer_index, out=slot.features,
                                    max_batch=self.extract_launch_views, dtype=self.extract_dtype,

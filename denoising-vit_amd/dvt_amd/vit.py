@@ -179,8 +179,8 @@ def plan_launches(n_views: int, max_batch: int, s_pad: int = 1408, dim: int = 76
     fc2) 7.09 -> 8 rounds, 11 % of them idle, while 124 views (682 panels) give 23.98 / 31.97 / 7.99 / 7.99 rounds for qkv /
     fc1 / proj / fc2.  The split of `n_views` into launches of at most `max_batch` views is chosen by dynamic programming
     over a cost model in microseconds per tile round (k-loop 1.68 us per 64 k + the epilogue's 5.6 / 10.5 / 20 us: the
-    measured 8p figures) plus the per-view kernels (attention, im2col): 769 views at 128 -> 124 x 4 + 108 + 103 + 62,
-    modelled 4 % below 7 x 110.  Results do not depend on the split (tests).  DVT_VIT_BALANCE=1: equal launches (round 3),
+    measured 8p figures) plus the per-view kernels (attention, im2col): 769 views at a cap of 128 -> 124 x 5 + 103 + 46, at the
+    default cap of 400 -> 398 + 371, modelled 4 % below 7 x 110.  Results do not depend on the split (tests).  DVT_VIT_BALANCE=1: equal launches (round 3),
     0: plain chunks."""
     max_batch = max(1, int(max_batch))
     mode = os.environ.get("DVT_VIT_BALANCE", "2")
@@ -299,12 +299,16 @@ class HipViT:
         self._ws = None
         self._ws_batch = 0
 
+    def workspace_bytes(self, batch: int) -> int:
+        """Bytes of scratch one launch of `batch` views needs (the library's own arithmetic)."""
+        size_fn = (_lib.lib().dvt_vit_workspace_bytes_f32x3 if self.x3 else
+                   _lib.lib().dvt_vit_workspace_bytes_f32 if self.dtype == "float32"
+                   else _lib.lib().dvt_vit_workspace_bytes)
+        return int(size_fn(C.byref(self.cfg), batch))
+
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch < batch:
-            size_fn = (_lib.lib().dvt_vit_workspace_bytes_f32x3 if self.x3 else
-                       _lib.lib().dvt_vit_workspace_bytes_f32 if self.dtype == "float32"
-                       else _lib.lib().dvt_vit_workspace_bytes)
-            nbytes = int(size_fn(C.byref(self.cfg), batch))
+            nbytes = self.workspace_bytes(batch)
             self._ws = torch.zeros(nbytes, device=self.device, dtype=torch.uint8)
             self._ws_batch = batch
         return self._ws

@@ -287,7 +287,9 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * key 7 = fit step (both operand precisions since round 4): 1 (default) hash-grid gradient gathered from per-step sorted
  *         corner lists, 0 = scattered with atomics;
  * key 9 = fit step (both precisions): 1 (default) lazy Adam over the fine hash-grid levels -- with fp32 operands always the
- *         IEEE replay of key 10 = 1, bit-identical to the dense sweep --, 0 = dense Adam over the whole arena,
+ *         IEEE replay of key 10 = 1: the ADAM ARITHMETIC is bit-identical to the dense sweep (never-touched entries end
+ *         equal bit for bit, tests/test_gpu_fit.py::test_fp32_lazy_adam_vs_dense_sweep); touched entries carry the summation
+ *         order of the gathered grid gradient, run-to-run rounding noise in either mode --, 0 = dense Adam over the whole arena,
  *         n >= 2 = lazy with a full refresh every n steps (default 32);
  * key 12 = the merged Adam launch also stores the bf16 weight shadow (1, default) or shadow_build_kernel runs (0);
  * key 11 = the lazy catch-up of the next step shares the Adam launch (1, default) or is its own launch (0);

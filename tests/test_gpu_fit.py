@@ -381,10 +381,10 @@ def test_bf16_fit_any_batch_size(built_lib, B):
 LAZY_REPLAY_DEFAULT = 0  # dvt_tune_set(10, .): 0 = v_rcp / v_sqrt replay (default), 1 = IEEE replay
 
 
-def _bf16_run(built_lib, feats, xy, idx, T, knobs=(), splits=None, C=768, seed=1, warmup=None):
+def _bf16_run(built_lib, feats, xy, idx, T, knobs=(), splits=None, C=768, seed=1, warmup=None, mlp_dtype="bfloat16"):
     from dvt_amd.fit import FitEngine, FitSettings
     n_rows = feats.shape[0]
-    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=T // 10 if warmup is None else warmup, mlp_dtype="bfloat16")
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=T // 10 if warmup is None else warmup, mlp_dtype=mlp_dtype)
     try:
         for k, v in knobs:
             assert built_lib.dvt_tune_set(k, v) == 0
@@ -561,3 +561,31 @@ def test_long_run_many_list_chunks(built_lib):
         # reaches 0.9963 (the old 0.995 sat inside the run-to-run spread).
         assert abs(lo[T - 1]["loss"] - ld[T - 1]["loss"]) < 2e-2 * abs(ld[T - 1]["loss"])
         assert per_patch_cos(other.infer(xy[-1].to(DEV)).cpu(), ref).min() > 0.99
+
+
+def test_fp32_lazy_adam_vs_dense_sweep(built_lib):
+    """include/dvt_hip.h called the fp32-operand mode's lazy Adam "bit-identical to the dense sweep" with no test
+    saying so.  What IS bit-identical is the Adam arithmetic: a grid entry no sampled row ever touches sees only its own
+    (p, m, v) and the steps' scalars, so after 600 steps (4 list chunks, 18 refreshes) it must equal the dense sweep's entry
+    bit for bit in p, m and v.  Touched entries inherit the summation order of the gathered grid gradient (a few cross-wave
+    atomics per entry: run-to-run rounding noise in BOTH modes), so what is read -- losses, the saved tensor -- is held to the
+    same bounds as the bf16-mode test above."""
+    V, H, C, T = 4, 37, 768, 600
+    feats, xy = synthetic_image(V, H, H, C, seed=9)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    idx = np.random.RandomState(9).randint(0, f.shape[0], (T, 2048)).astype(np.int32)
+    dense = _bf16_run(built_lib, f, c, idx, T, knobs=[(9, 0)], mlp_dtype="float32")
+    lazy = _bf16_run(built_lib, f, c, idx, T, mlp_dtype="float32")  # the fp32 default: lazy, IEEE replay
+    mask = _never_touched_mask(built_lib, lazy, c, idx)
+    assert int(mask.sum()) > 1000
+    n8 = mask.numel() * 8
+    for name in ("params", "adam_m", "adam_v"):
+        x, y = getattr(lazy, name)[:n8].view(-1, 8)[mask], getattr(dense, name)[:n8].view(-1, 8)[mask]
+        assert torch.equal(x, y), f"fp32 lazy replay differs from the dense sweep in {name} of a never-touched entry"
+    ll, ld = lazy.loss_log(), dense.loss_log()
+    assert abs(ll[T - 1]["loss"] - ld[T - 1]["loss"]) < 2e-2 * abs(ld[T - 1]["loss"])
+    cos = per_patch_cos(lazy.infer(xy[-1].to(DEV)).cpu(), dense.infer(xy[-1].to(DEV)).cpu())
+    print(f"fp32 operands, {T} steps: lazy IEEE Adam bit-identical to the dense sweep on {int(mask.sum())} never-touched entries; "
+          f"final loss {ll[T - 1]['loss']:.5f} vs {ld[T - 1]['loss']:.5f}, saved-tensor cosine min {cos.min():.6f}")
+    assert cos.min() > 0.99
+    assert float(lazy.grads.abs().max()) == 0.0 and int(lazy.touched.abs().max()) == 0

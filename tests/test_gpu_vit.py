@@ -518,6 +518,33 @@ def test_vit_large_full_depth(L):
     assert err32 <= 1e-5 and cos32.min() > 0.999999
 
 
+def test_vit_large_launch_beyond_2p31_elements(L):
+    """the default launch cap (400 views) gives a ViT-L/14 launch of 395 views an fc1 output of 395 x 1408 x 4096 =
+    2.28e9 elements and a qkv output of 1.7e9 -- beyond 2^31, where every index must be 64-bit -- and no test ran there (the
+    full-depth test uses 2 views).  Two blocks of the ViT-L geometry on 395 views in ONE launch against the same views in
+    five launches of 79 (every intermediate below 2^31 elements): results must not depend on the batching.  The fold of the
+    LayerNorm statistics sums 64-column partials in a fixed order per row, so the two runs agree to the last bit."""
+    from dvt_amd.vit import HipViT, random_state_dict
+    sd = random_state_dict(1024, 2, 14, 1370, seed=7, well_conditioned=True)
+    n = 395
+    x = torch.randn(n, 3, 518, 518, device=DEV, generator=torch.Generator(device=DEV).manual_seed(11))
+    vit = HipViT(sd, 14, 14, (518, 518), DEV)
+    assert vit.launch_plan(n, 400) == [n] and n * vit.cfg.s_pad * vit.cfg.mlp_dim > 2 ** 31
+    big = vit.forward_features(x, max_batch=400)
+    torch.cuda.synchronize()
+    assert max(vit.launch_plan(n, 79)) <= 79
+    small = vit.forward_features(x, max_batch=79)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(big).all())
+    diff = float((big - small).abs().max())
+    print(f"ViT-L/14 geometry, 2 blocks: 1 launch of {n} views vs launches of <= 79: max |diff| {diff:.3e}")
+    assert diff == 0.0
+    # and the last view of the big launch against the oracle (the rows with the largest offsets)
+    want = ovit.forward_features(sd, x[-1:].cpu(), 14, 14)
+    cos = F.cosine_similarity(big[-1:].cpu().reshape(-1, 1024), want.reshape(-1, 1024), dim=-1)
+    assert cos.min() > 0.999, float(cos.min())
+
+
 def test_product_library_rejects_lab_knobs(L):
     """the product library carries no superseded / experimental / timing kernel, and dvt_tune_set refuses every
     value that would have selected one (before: `dvt_tune_set(1, -301)` made a product entry point return wrong numbers with

@@ -198,3 +198,22 @@ def test_pipe_timeline_tool_on_a_synthetic_trace(tmp_path, capsys):
     assert "6 extractor launches -> 3 images" in out
     assert "idle before next image" in out and "between image 0 and 1" in out
     assert "extractor launch duration vs fit steps completed inside it" in out
+
+
+def test_explicit_extract_bsz_bounds_the_launches():
+    """`--extract_bsz` keeps the reference's default (32) in the table and is otherwise ignored -- the views per
+    extractor launch are `--extract_launch_views` (default cap 400) -- but a value the user TYPED (to bound memory) bounds the
+    launches when `--extract_launch_views` is left at 0."""
+    from dvt_amd import stage1
+
+    def cap(argv):
+        a = stage1.get_args(argv)
+        elv = int(a.extract_launch_views or 0)
+        ebs = a.extract_bsz if getattr(a, "extract_bsz_explicit", False) else None
+        return a.extract_bsz, max(1, elv if elv > 0 else (min(400, int(ebs)) if ebs else 400))
+
+    assert cap([]) == (32, 400)
+    assert cap(["--extract_bsz", "32"]) == (32, 32)
+    assert cap(["--extract_bsz", "64"]) == (64, 64)
+    assert cap(["--extract_bsz", "1000"]) == (1000, 400)
+    assert cap(["--extract_bsz", "16", "--extract_launch_views", "128"]) == (16, 128)

@@ -109,9 +109,21 @@ def test_ranks_pin_disjoint_host_cpu_slices():
         assert info["pinned"] and len(info["affinity"]) == n_cpu // 2 and info["threads"] <= 8
         seen.append(set(info["affinity"]))
     assert not (seen[0] & seen[1])
-    # a launcher that does not export LOCAL_WORLD_SIZE: nothing is pinned (WORLD_SIZE may span several hosts)
+    # a launcher that exports NO local world size at all: nothing is pinned (WORLD_SIZE may span several hosts; on this
+    # CPU-only host it also exceeds the device count) -- and it says so once
     env = dict(os.environ, LOCAL_RANK="1", WORLD_SIZE="16")
-    env.pop("LOCAL_WORLD_SIZE", None)
+    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "MPI_LOCALNRANKS"):
+        env.pop(k, None)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
     info = json.loads(out.strip().splitlines()[-1])
     assert not info["pinned"] and len(info["affinity"]) == n_cpu
+    assert out.count("host threads are NOT pinned") == 1
+    # mpirun / srun: their own names for the ranks of this host are honoured
+    for extra in ({"OMPI_COMM_WORLD_LOCAL_SIZE": "2", "OMPI_COMM_WORLD_LOCAL_RANK": "1"},
+                  {"SLURM_NTASKS_PER_NODE": "2(x4)", "SLURM_LOCALID": "1"}):
+        env = dict(os.environ, WORLD_SIZE="8", **extra)
+        for k in ("LOCAL_WORLD_SIZE", "LOCAL_RANK", "DVT_NO_AFFINITY"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+        info = json.loads(out.strip().splitlines()[-1])
+        assert info["pinned"] and info["local_rank"] == 1 and set(info["affinity"]) == seen[1], (extra, info)
