@@ -568,6 +568,104 @@ __global__ __launch_bounds__(256) void gemm_f32_batched_small_k_kernel(GemmArgs 
   gemm_f32_body<A_KC, B_KC, 2, 2, 64>(q, blockIdx.x, blockIdx.y, 0, As, Bs);
 }
 
+// ---- 128 x 128 x 32 tile for LARGE-m forward layers (the fp32 extractor: m = views x 1408 tokens) ----------------------
+// Round 5 ("fp32 extractor GEMM 109 -> >= 125 TF/s").  The 64 x 64 tile above gives every wave ONE 32 x 32
+// accumulator: per MFMA (64 cycles) a wave reads two fragment values per lane from LDS and a workgroup moves (64 + 64) rows
+// through L2 -> LDS per 64 x 64 outputs.  Here a wave owns 64 x 64 outputs = 2 x 2 accumulators (64 VGPRs): every A / B
+// fragment value feeds TWO MFMAs, four independent 64-cycle accumulation chains keep the pipe issuing back to back, and the
+// workgroup's operand traffic per flop halves.  BK = 32 keeps the LDS rows at 128 B (whole lines per DMA row piece), the
+// stage at 32 KB and TWO stages at 64 KB, i.e. TWO workgroups per CU (one wave each per SIMD) that fill each other's
+// barrier / fragment-read gaps, as in the 64 x 64 kernel.  LDS image: lane-linear rows of 32 floats, 16-B chunk c of row r at
+// position c ^ ((r >> 1) & 7) (applied at the DMA source and at the b128 fragment reads: the 16 lanes of a read group cover
+// all 64 banks).  Both operands k-contiguous, M % 128 == N % 128 == K % 32 == 0 (the caller falls back otherwise).
+constexpr int GB_BK = 32;
+constexpr int GB_TILE_FLOATS = 128 * GB_BK;        // one operand tile: 16 KB
+constexpr int GB_STAGE_FLOATS = 2 * GB_TILE_FLOATS;  // A + B: 32 KB
+
+__device__ __forceinline__ void stage_big(const float* __restrict__ X, int ld, int r0, int k0, float* lds, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 256 + wave * 64 + lane;  // 16-B slot of the 16-KB tile: row s >> 3, position s & 7
+    const int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    glds16f(X + (size_t)(r0 + row) * ld + k0 + c * 4, lds + (it * 256 + wave * 64) * 4);
+  }
+}
+
+// 16-B piece q (k-values 4 q .. 4 q + 3 of k half `kh`) of row `row`: what one lane feeds into MFMA steps 4 q .. 4 q + 3
+__device__ __forceinline__ float4 frag4_big(const float* __restrict__ S, int row, int kh, int q) {
+  return *reinterpret_cast<const float4*>(S + row * GB_BK + (((kh * (GB_BK / 8) + q) ^ ((row >> 1) & 7)) << 2));
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * GB_STAGE_FLOATS];  // 64 KB, one LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+  const int nk = p.K / GB_BK;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#define GB_ISSUE(kt)                                                             \
+  do {                                                                           \
+    float* st_ = smem + ((kt) & 1) * GB_STAGE_FLOATS;                            \
+    stage_big(p.A, p.lda, m0, (kt) * GB_BK, st_, wave, lane);                    \
+    stage_big(p.B, p.ldb, n0, (kt) * GB_BK, st_ + GB_TILE_FLOATS, wave, lane);   \
+  } while (0)
+  GB_ISSUE(0);
+  const int l31 = lane & 31, kh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed (own DMAs), everyone's has, and everyone is done reading the other buffer (tile kt - 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) GB_ISSUE(kt + 1);
+    const float* As = smem + (kt & 1) * GB_STAGE_FLOATS;
+    const float* Bs = As + GB_TILE_FLOATS;
+    // reads in the order the MFMA steps need them (piece q of all four fragments, then q + 1): the first 16 MFMAs can
+    // start behind four reads instead of thirteen
+    float4 fa[2][GB_BK / 8], fb[2][GB_BK / 8];
+#pragma unroll
+    for (int q = 0; q < GB_BK / 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i][q] = frag4_big(As, wm * 64 + i * 32 + l31, kh, q);
+        fb[i][q] = frag4_big(Bs, wn * 64 + i * 32 + l31, kh, q);
+      }
+#pragma unroll
+    for (int q = 0; q < GB_BK / 8; ++q) {
+#define GB_STEP(E)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].E, fb[j][q].E, acc[i][j], 0, 0, 0);
+      GB_STEP(x) GB_STEP(y) GB_STEP(z) GB_STEP(w)
+#undef GB_STEP
+    }
+  }
+#undef GB_ISSUE
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): a half-wave stores one
+  // 128-B row piece per instruction
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gn = n0 + wn * 64 + j * 32 + l31;
+    const float bias = p.bias != nullptr ? p.bias[gn] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float v = acc[i][j][r] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        p.C[(size_t)gm * p.ldc + gn] = v;
+      }
+  }
+}
+
+int g_f32_big = 1;  // dvt_tune_set(4, 10 / 11): the 128 x 128 kernel of dvt_linear_fwd_big off / on (A/B; results differ in summation order only)
 int g_f32_glds = 1;  // 0: always the register-staged kernel
 int g_f32_ex_stages = 2;  // LDS stages of the stage-2 GEMMs (dvt_gemm_f32_ex): 2 or 3
 extern int g_cfg_override;
@@ -750,6 +848,8 @@ extern "C" int dvt_tune_set(int key, int value) {
   if (key == 4) {
     if (value == 2 || value == 3)
       g_f32_ex_stages = value;  // stage-2 GEMMs: LDS stages
+    else if (value == 10 || value == 11)
+      g_f32_big = value == 11;  // fp32 extractor: 128 x 128 x 32 tile (11, default) / the 64 x 64 x 64 LDS-DMA kernel (10)
     else
       g_f32_glds = value;
     return 0;
@@ -868,6 +968,12 @@ int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s) {
 int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s) {
   if (!x || !w || !y || m <= 0 || n <= 0 || k <= 0 || (k & 3) || (n & 3)) return DVT_E_BADARG;
   const GemmArgs a = make_fwd(x, w, b, y, m, n, k, 0);
+  if (g_f32_big && a.M % 128 == 0 && a.N % 128 == 0 && a.K % GB_BK == 0 && a.mask == nullptr && !a.atomic) {
+    DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+    hipLaunchKernelGGL(gemm_f32_big_kernel, dim3(a.N / 128, a.M / 128), dim3(256), 0, s, a);
+    DVT_CHECK_LAUNCH();
+    return 0;
+  }
   if ((a.K % BK) == 0 && (a.kchunk % BK) == 0) {
     dim3 grid(dvt_cdiv(a.N, 64), dvt_cdiv(a.M, 64), 1);
     DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);

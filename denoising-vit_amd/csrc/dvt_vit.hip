@@ -104,6 +104,7 @@ struct GemmBArgs {
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
   double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
   unsigned* dbg;      // timing builds of the 8p kernel (dvt_vit_debug_buffer): 24 u32 per wave group and workgroup
+  int stagger_ticks;  // 8p: the first round of workgroups (one per CU) starts spread over this many 100-MHz ticks (0: together)
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -846,6 +847,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned long long entry_t_ = 0;
   if constexpr (SM >= 3) entry_t_ = __builtin_readcyclecounter();
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
+  // De-synchronised start (dvt_tune_set(1, -700 - pct)).  A launch begins with one workgroup per CU, all tiles cost the same,
+  // so the CUs walk through k-loop and epilogue in LOCK STEP for the whole launch: every ~26 us all 256 of them burst their
+  // 128 KB of output at the memory system together (the chip's store rate, 5-6 TB/s: the bias epilogue's 5.6 us) and then
+  // nobody stores for 20 us.  The workgroups of the first round therefore wait a hash-spread fraction of one tile time
+  // (s_memrealtime, 100 MHz); every later workgroup inherits its CU's phase.  Results do not depend on it.
+  if (p.stagger_ticks > 0 && blockIdx.x < 256) {
+    const unsigned h_ = ((unsigned)blockIdx.x * 2654435761u) >> 16;  // 16-bit hash of the block id
+    const unsigned long long wait_ = ((unsigned long long)p.stagger_ticks * h_) >> 16;
+    const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0_ < wait_) __builtin_amdgcn_s_sleep(16);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -1145,6 +1157,9 @@ int g_vit_fuse_ln = 1;
 // loop unrolled by two: 874-893 us against 908-928 us for mask 0 at 110 views (profiles/r03/r03i).  The product library
 // instantiates mask 15 only; lab builds select others with dvt_tune_set(1, -510 - mask).
 int g_vit_attn_mask = 15;
+// dvt_tune_set(1, -700 - pct): the first round of 8p workgroups starts spread over pct % of the modelled tile time (k-loop
+// 1.68 us per k-tile + epilogue); 0 = all together
+int g_vit_stagger_pct = 0;
 #ifdef DVT_LAB
 int g_vit_tpw = 0;           // 4w kernel: target tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = attention_kernel_v2, 1 = the round-2 kernel
@@ -1186,6 +1201,11 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.mblock = g_vit_mblock > 0 ? g_vit_mblock : (g >= 6 ? 4 : 1);
     a.nt_store = g_vit_nt_store;
     const dim3 grid8((a.M / 256) * nt);
+    if (g_vit_stagger_pct > 0 && grid8.x > 512) {  // (a launch of fewer than two rounds has nothing to de-synchronise)
+      const double epi_us = EPI == EPI_RESID ? 20.0 : (IS_GELU(EPI) ? 10.5 : 5.6);
+      const double tile_us = 1.68 * (a.K / GBK) + epi_us;
+      a.stagger_ticks = (int)(tile_us * 100.0 * g_vit_stagger_pct / 100.0);
+    }
 #ifdef DVT_LAB
     const int nk = a.K / GBK;
     if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU) {
@@ -1890,8 +1910,8 @@ int dvt_vit_tune(int v) {
     return 0;
   }
 #ifdef DVT_LAB
-  if (v <= -600 && v >= -600 - 65536) {  // -600 - n: the 4w GEMM's grid forced to n workgroups (0 = auto)
-    g_vit_w4_grid = -600 - v;
+  if ((v <= -600 && v > -700) || (v < -1100 && v >= -1100 - 65536)) {  // -600 - n (n < 100) / -1100 - n: the 4w GEMM's grid forced to n workgroups (0 = auto)
+    g_vit_w4_grid = v > -700 ? -600 - v : -1100 - v;
     return 0;
   }
   if (v <= -510 && v > -600) {
@@ -1918,6 +1938,10 @@ int dvt_vit_tune(int v) {
 #else
   if (v == -502 || v == -510 - 15) return 0;  // the one attention kernel / schedule mask the product library contains
 #endif
+  if (v <= -700 && v >= -1100) {  // -700 - pct: de-synchronised start of the 8p workgroups (see the kernel), 0 = off
+    g_vit_stagger_pct = -700 - v;
+    return 0;
+  }
   if (v <= -100 && v > -200) {  // -100 - b: M panels per block of the tile order
     g_vit_mblock = -100 - v;  // 0 = auto
     return 0;

@@ -173,7 +173,8 @@ def balanced_launch_views(n_views: int, max_batch: int) -> int:
 _PLAN_CACHE: dict = {}
 
 
-def plan_launches(n_views: int, max_batch: int, s_pad: int = 1408, dim: int = 768, mlp_dim: int = 3072) -> list[int]:
+def plan_launches(n_views: int, max_batch: int, s_pad: int = 1408, dim: int = 768, mlp_dim: int = 3072,
+                  fp32: bool = False) -> list[int]:
     """Views per extractor launch, TILE-ROUND aware (round 4).  Every GEMM of a launch runs (M / 256) x (N / 256) tiles of
     256 x 256 on 256 CUs, so its time is ceil(tiles / 256) ROUNDS: 110 views = 605 M panels give the N = 768 GEMMs (proj,
     fc2) 7.09 -> 8 rounds, 11 % of them idle, while 124 views (682 panels) give 23.98 / 31.97 / 7.99 / 7.99 rounds for qkv /
@@ -181,23 +182,33 @@ def plan_launches(n_views: int, max_batch: int, s_pad: int = 1408, dim: int = 76
     over a cost model in microseconds per tile round (k-loop 1.68 us per 64 k + the epilogue's 5.6 / 10.5 / 20 us: the
     measured 8p figures) plus the per-view kernels (attention, im2col): 769 views at a cap of 128 -> 124 x 5 + 103 + 46, at the
     default cap of 400 -> 398 + 371, modelled 4 % below 7 x 110.  Results do not depend on the split (tests).  DVT_VIT_BALANCE=1: equal launches (round 3),
-    0: plain chunks."""
+    0: plain chunks.
+    fp32 = True (round 5): the exact-fp32 extractor's GEMMs run 128 x 128 tiles, two workgroups per CU (512 slots per round,
+    ~0.126 us per k and round at ~130 TF/s); at the round-4 cap of 32 views the N = 768 GEMMs ran 4.1 -> 5 rounds."""
     max_batch = max(1, int(max_batch))
     mode = os.environ.get("DVT_VIT_BALANCE", "2")
     if mode != "2":
         step = balanced_launch_views(n_views, max_batch)
         return [min(step, n_views - b0) for b0 in range(0, n_views, step)]
-    key = (n_views, max_batch, s_pad, dim, mlp_dim)
+    key = (n_views, max_batch, s_pad, dim, mlp_dim, fp32)
     if key in _PLAN_CACHE:
         return list(_PLAN_CACHE[key])
-    kt = lambda k: 1.68 * (k / 64.0)  # noqa: E731
-    gemms = [(3 * dim // 256, kt(dim) + 5.6), (mlp_dim // 256, kt(dim) + 10.5), (dim // 256, kt(dim) + 20.0),
-             (dim // 256, kt(mlp_dim) + 10.0)]  # (N tiles, us per tile round): qkv, fc1, proj, fc2
-    per_view = 8.8 * (s_pad / 1408.0) ** 2 * (dim / 768.0)  # attention + the row-local kernels
+    if fp32:
+        tile, slots = 128, 512
+        kt = lambda k: 0.126 * k  # noqa: E731
+        gemms = [(3 * dim // tile, kt(dim) + 2.0), (mlp_dim // tile, kt(dim) + 2.0), (dim // tile, kt(dim) + 2.0),
+                 (dim // tile, kt(mlp_dim) + 2.0)]
+        per_view = 50.0 * (s_pad / 1408.0) ** 2 * (dim / 768.0)
+    else:
+        tile, slots = 256, 256
+        kt = lambda k: 1.68 * (k / 64.0)  # noqa: E731
+        gemms = [(3 * dim // 256, kt(dim) + 5.6), (mlp_dim // 256, kt(dim) + 10.5), (dim // 256, kt(dim) + 20.0),
+                 (dim // 256, kt(mlp_dim) + 10.0)]  # (N tiles, us per tile round): qkv, fc1, proj, fc2
+        per_view = 8.8 * (s_pad / 1408.0) ** 2 * (dim / 768.0)  # attention + the row-local kernels
 
     def cost(v):
-        mt = -(-v * s_pad // 256)
-        return per_view * v + sum(-(-mt * nt // 256) * w for nt, w in gemms) + 9.0  # + launch boundaries
+        mt = -(-v * s_pad // tile)
+        return per_view * v + sum(-(-mt * nt // slots) * w for nt, w in gemms) + 9.0  # + launch boundaries
 
     costs = [0.0] + [cost(v) for v in range(1, min(n_views, max_batch) + 1)]
     best = [(0.0, ())] + [None] * n_views
@@ -343,8 +354,11 @@ class HipViT:
     def launch_plan(self, n_views: int, max_batch: int = 128) -> list[int]:
         """Views of each extractor launch for `n_views` views (what forward_features will do)."""
         cfg = self.cfg
-        if self.dtype == "float32":
-            # fp32 activations: 32 views keep the scratch at ~1.3 GB (bf16x3: 64 views, 4.4 GB, for fuller GEMM launches)
-            max_batch = min(max_batch, 64 if self.x3 else 32)
+        if self.dtype == "float32" and self.x3:
+            max_batch = min(max_batch, 64)  # bf16x3: 64 views, 4.4 GB of scratch
+        elif self.dtype == "float32":
+            # exact fp32: 51 MB of scratch per ViT-B view; launches of up to 160 views (8 GB) so that the 128 x 128 tiles of
+            # the N = dim GEMMs fill whole rounds of 512 workgroup slots (round 4: 32 views, 4.1 -> 5 rounds, 18 % idle)
+            return plan_launches(n_views, min(max_batch, 160), cfg.s_pad, cfg.dim, cfg.mlp_dim, fp32=True)
         return plan_launches(n_views, max_batch, cfg.s_pad, cfg.dim, cfg.mlp_dim)
 
