@@ -1,8 +1,8 @@
 """The developer build of the library (csrc/lab/, -DDVT_LAB -> csrc/libdvt_hip_lab.so, `python tools/build_lab.py`) held to the
 same checks as the product kernels: superseded GEMM schedules (0, 2), the 8p re-schedules (5 "8m", 10 "8h": bit-identical),
-the 4-wave persistent GEMM (6..9), the round-2 attention loop and the other attention schedule masks.  SKIPPED when that
-library has not been built -- `__graft_entry__.build()` builds the product library only, and nothing under
-denoising-vit_amd/dvt_amd loads the lab build."""
+the 4-wave persistent GEMM (6..9), the round-2 attention loop and the other attention schedule masks.  The module's
+fixture builds that library on demand (`__graft_entry__.build()` builds the product library only, and nothing under
+denoising-vit_amd/dvt_amd loads the lab build); without a working hipcc these tests are skipped."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -17,8 +17,10 @@ pytestmark = pytest.mark.gpu
 def L():
     import dvt_amd.vit  # noqa: F401 registers signatures
     from dvt_amd import _lib
-    if not _lib.LAB_LIB_PATH.exists():
-        pytest.skip("developer library not built (python tools/build_lab.py)")
+    try:  # built on demand (about a minute: the 4-wave kernel's ablation builds dominate); never by __graft_entry__.build()
+        _lib.build(lab=True)
+    except Exception as exc:  # no hipcc on this box: the product suite does not depend on the developer library
+        pytest.skip(f"developer library could not be built ({exc!r}); python tools/build_lab.py")
     h = _lib.open_library(_lib.LAB_LIB_PATH)
     assert h.dvt_vit_is_lab_build() == 1
     return h
