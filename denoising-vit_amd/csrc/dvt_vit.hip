@@ -328,13 +328,64 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   const int g = lane >> 4, lc = lane & 15;
   // LayerNorm folded into this GEMM (see ln_fold): the accumulators are x . W'^T of the UN-normalised rows
   const bool ln = (IS_QKV(EPI) || IS_GELU(EPI)) && p.ln_stats != nullptr;
-  if (IS_QKV(EPI) && n0 >= 2 * p.dim) {  // V tiles keep the direct transposed store
-    if (ln) ln_fold<4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
-    gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
-    return;
-  }
   float* blk = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
   const int nb = n0 + wn * 64;
+  if (IS_QKV(EPI) && n0 >= 2 * p.dim) {
+    // V tiles: vt[b][h][d][s] wants the TOKENS contiguous.  Round 5: the block goes through LDS transposed -- image
+    // [64 features d][64 tokens] (pitch EP_LD), written as ONE ds_write_b128 per accumulator tuple (a lane's 4 rows are 4
+    // consecutive tokens of one feature), read back as 8 tokens per lane and stored as 16 B per lane, 8 lanes = one whole
+    // 128-B line of a feature row.  Before, every lane stored its tuples straight from the accumulators as 8-byte pieces (64
+    // store instructions per block on 32-B segments) behind 32 scattered (mean, rstd) loads: a V tile's epilogue took ~15 us
+    // against 3.6 us for a q / k tile, i.e. the qkv GEMM paid +4 us per tile on average (profiles/r05/README.md).
+    const int mbv = m0 + wm * 64;
+    const int tc = lane & 7, dl = lane >> 3;  // 8-token chunk of the block, feature within a pass of 8
+    // folded LayerNorm: (mean, rstd) of this lane's 8 tokens -- 64 B per lane, coalesced, requested before the LDS traffic
+    float4 stq[4];
+    if (ln) {
+      const float4* sp = reinterpret_cast<const float4*>(p.ln_stats + mbv + tc * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) stq[q] = sp[q];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bias = (p.bias != nullptr && !ln) ? p.bias[nb + j * 16 + lc] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 t4 = make_float4(acc[i][j][0] + bias, acc[i][j][1] + bias, acc[i][j][2] + bias, acc[i][j][3] + bias);
+        *reinterpret_cast<float4*>(blk + (j * 16 + lc) * EP_LD + i * 16 + 4 * g) = t4;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // each wave re-reads its own block only
+    const int f0 = nb - 2 * p.dim, hh = f0 >> 6;        // (the block is one head's 64 features: dim_ok_sq / 64-aligned)
+    const int bimg = mbv / p.s_pad, s0 = mbv - bimg * p.s_pad + tc * 8;
+    bf16_t* const vrow = p.vt + ((size_t)(bimg * p.heads + hh) * 64) * p.s_pad + s0;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+      const int d = it * 8 + dl;
+      const float4 a = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8);
+      const float4 b = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8 + 4);
+      float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      if (ln) {  // rstd * (acc - mean * cs) + b'
+        const float cs = p.ln_cs[nb + d], bf = p.bias[nb + d];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[2 * q] = fmaf(stq[q].y, v[2 * q] - stq[q].x * cs, bf);
+          v[2 * q + 1] = fmaf(stq[q].w, v[2 * q + 1] - stq[q].z * cs, bf);
+        }
+      }
+      typedef unsigned u32x4v_t __attribute__((ext_vector_type(4)));
+      const u32x4v_t hi = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+      *reinterpret_cast<u32x4v_t*>(vrow + (size_t)d * p.s_pad) = hi;
+      if constexpr (EPI == EPI_QKV_X3) {
+        u32x4v_t lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          lo[q] = pack2(v[2 * q] - __uint_as_float(hi[q] << 16), v[2 * q + 1] - __uint_as_float(hi[q] & 0xffff0000u));
+        *reinterpret_cast<u32x4v_t*>(p.vt_lo + (vrow - p.vt) + (size_t)d * p.s_pad) = lo;
+      }
+    }
+    return;
+  }
   // (mean, rstd) of the block's 64 rows: ONE coalesced load per lane, requested now and parked in the padding
   // columns of the LDS block with the accumulators (as 32 loads per lane at the top of the epilogue they cost a full
   // memory latency per tile)
