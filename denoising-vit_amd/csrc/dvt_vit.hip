@@ -341,10 +341,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     const int tc = lane & 7, dl = lane >> 3;  // 8-token chunk of the block, feature within a pass of 8
     // folded LayerNorm: (mean, rstd) of this lane's 8 tokens -- 64 B per lane, coalesced, requested before the LDS traffic
     float4 stq[4];
+    float csd[8], bfd[8];  // ... and the column sums / biases of its 8 features (one per pass)
     if (ln) {
       const float4* sp = reinterpret_cast<const float4*>(p.ln_stats + mbv + tc * 8);
 #pragma unroll
       for (int q = 0; q < 4; ++q) stq[q] = sp[q];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        csd[it] = p.ln_cs[nb + it * 8 + dl];
+        bfd[it] = p.bias[nb + it * 8 + dl];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -359,14 +365,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     const int f0 = nb - 2 * p.dim, hh = f0 >> 6;        // (the block is one head's 64 features: dim_ok_sq / 64-aligned)
     const int bimg = mbv / p.s_pad, s0 = mbv - bimg * p.s_pad + tc * 8;
     bf16_t* const vrow = p.vt + ((size_t)(bimg * p.heads + hh) * 64) * p.s_pad + s0;
-#pragma unroll 2
+#pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int d = it * 8 + dl;
       const float4 a = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8);
       const float4 b = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8 + 4);
       float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       if (ln) {  // rstd * (acc - mean * cs) + b'
-        const float cs = p.ln_cs[nb + d], bf = p.bias[nb + d];
+        const float cs = csd[it], bf = bfd[it];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           v[2 * q] = fmaf(stq[q].y, v[2 * q] - stq[q].x * cs, bf);
@@ -391,6 +397,17 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   // memory latency per tile)
   float2 st_row = make_float2(0.f, 0.f);
   if (ln) st_row = p.ln_stats[m0 + wm * 64 + lane];
+  // ... and so are the folded LayerNorm's column sums / biases of the lane's 8 output columns (round 5; before, they were
+  // requested after the LDS round trip, right in front of the loop that needs them.  Same-box A/B: no difference -- the other
+  // waves of the CU cover that latency -- kept here because it is the natural place)
+  const int c8_ln = (lane & 7) * 8;
+  float4 cs0 = make_float4(0.f, 0.f, 0.f, 0.f), cs1 = cs0, bf0 = cs0, bf1 = cs0;
+  if (ln && EPI != EPI_RESID && EPI != EPI_EMBED && EPI != EPI_F32) {
+    cs0 = *reinterpret_cast<const float4*>(p.ln_cs + nb + c8_ln);
+    cs1 = *reinterpret_cast<const float4*>(p.ln_cs + nb + c8_ln + 4);
+    bf0 = *reinterpret_cast<const float4*>(p.bias + nb + c8_ln);
+    bf1 = *reinterpret_cast<const float4*>(p.bias + nb + c8_ln + 4);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float bias = (p.bias != nullptr && !ln) ? p.bias[nb + j * 16 + lc] : 0.f;
@@ -444,13 +461,6 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     const int c8 = (lane & 7) * 8;  // 8 lanes x 8 columns = one row; 8 rows per pass
     // (GELU: one row at a time -- four rows of erf polynomials in flight took the fc1 kernel to 254 VGPRs,
     // and at 2 x 256 registers per SIMD no wave of the fit's streaming kernels can share the CU)
-    float4 cs0, cs1, bf0, bf1;
-    if (ln) {
-      cs0 = *reinterpret_cast<const float4*>(p.ln_cs + nb + c8);
-      cs1 = *reinterpret_cast<const float4*>(p.ln_cs + nb + c8 + 4);
-      bf0 = *reinterpret_cast<const float4*>(p.bias + nb + c8);
-      bf1 = *reinterpret_cast<const float4*>(p.bias + nb + c8 + 4);
-    }
 #pragma unroll(IS_GELU(EPI) ? 1 : 4)
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3);
