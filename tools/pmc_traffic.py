@@ -49,8 +49,9 @@ for k in sorted(set(fetch) | set(write)):
             p["bytes"] += (2.0 * f + w) * 1024.0
             p["launches"] += n
             break
-doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_target.py (110-view extractor "
-                 "launch = the bench's batching, + 60 fit steps)",
+views = sys.argv[3] if len(sys.argv) > 3 else "385"
+doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_target.py (ONE extractor launch of "
+                 f"{views} views -- the bench runs 398 + 371 per image -- + 60 fit steps; DVT_PMC_ARGS={views} bash tools/gpu.sh pmc)",
        "formula": "(FETCH_SIZE x 2 + WRITE_SIZE) x 1024 B / dispatches",
        "probes": {k: {"bytes_per_launch": v["bytes"] / v["launches"], "launches": v["launches"]} for k, v in probes.items()},
        "kernels": kernels}
