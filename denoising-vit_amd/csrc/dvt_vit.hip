@@ -170,20 +170,27 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, in
   return t;
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU(), timm Mlp) = max(x, 0) - 0.5 |x| E(|x|), where
-// E(|x|) = erfc(|x| / sqrt 2) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
-// rounding of the output): one v_rcp_f32 + one v_exp_f32 + 9 FMAs instead of libm erff's ~45
-// instructions (the fc1 epilogue was +27 % on top of the GEMM).
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU(), timm Mlp) = max(x, 0) - 0.5 |x| E(|x|), E = erfc(|x| / sqrt 2).
+// Round 5: E by Abramowitz-Stegun 7.1.28, erfc(z) = (1 + a1 z + ... + a6 z^6)^-16 (|abs err| <= 3e-7; measured in fp32
+// against fp64: 7.1e-7 on gelu over [-12, 12], i.e. fp32 rounding at |x| ~ 4, far below the bf16 rounding of the output), with
+// the powers of 1 / sqrt 2 folded into the coefficients: 6 FMAs + 4 squarings + ONE v_rcp_f32.  Rounds 1-4 used 7.1.26
+// (1.5e-7): one v_rcp_f32 AND one v_exp_f32 + 9 FMAs; transcendentals issue at a quarter of the FMA rate and the fc1
+// epilogue is VALU-bound (96 of its ~120 cycles per element-wave were this function).  Overflow: the 16th power reaches inf
+// beyond |x| ~ 27, v_rcp_f32(inf) = 0, the result is max(x, 0) exactly.  (libm's erff costs ~45 instructions.)
 __device__ __forceinline__ float gelu_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
-  float q = fmaf(t, 1.061405429f, -1.453152027f);
-  q = fmaf(q, t, 1.421413741f);
-  q = fmaf(q, t, -0.284496736f);
-  q = fmaf(q, t, 0.254829592f);
-  q *= t;
-  const float e = __builtin_amdgcn_exp2f(ax * ax * (-0.5f * 1.4426950408889634f));
-  return fmaf(-0.5f * ax, q * e, fmaxf(x, 0.f));
+  float p = fmaf(ax, 5.3829749049e-06f, 4.8890637117e-05f);
+  p = fmaf(p, ax, 3.8003574446e-05f);
+  p = fmaf(p, ax, 3.2776263542e-03f);
+  p = fmaf(p, ax, 2.1141005680e-02f);
+  p = fmaf(p, ax, 4.9867346883e-02f);
+  p = fmaf(p, ax, 1.0f);
+  p *= p;
+  p *= p;
+  p *= p;
+  p *= p;
+  const float e = __builtin_amdgcn_rcpf(p);
+  return fmaf(-0.5f * ax, e, fmaxf(x, 0.f));
 }
 
 // Fused epilogues.  acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*(lane>>4) + r][n0 + wn*64 + j*16 + (lane&15)]
