@@ -351,11 +351,12 @@ def main():
     full_fp32 = None
     if not a.no_fp32_fit and world == 1 and a.model in IMAGE_CEILINGS:
         # the reference's DEFAULT precision end to end (--dtype float32: fp32 extractor + fp32 fit), the same pipelined
-        # driver inside the same timed bracket, 3 images (exact-fp32 matrix cores: 1/16 of the bf16 rate)
+        # driver inside the same timed bracket, 5 images (exact-fp32 matrix cores: 1/16 of the bf16 rate; 3 images until
+        # round 4 -- with ~2 s per image the pipeline's fill + drain weighed 4 % of a 3-image bracket)
         set_fit_dtype("float32")
         st.extract_dtype = "float32"
         st.run(jobs(1))  # builds the fp32 weight copies / workspace, warms the pipeline
-        n3, el3, _ = D.timed(lambda: st.run(jobs(3), on_result=write_pair), device)
+        n3, el3, _ = D.timed(lambda: st.run(jobs(5), on_result=write_pair), device)
         st.process(lambda slot: None)
         t = st.timings[-1]
         full_fp32 = {"images_per_s": n3 / el3, "images_timed": n3, "flow": f"pipelined (depth {a.pipeline_depth})",
