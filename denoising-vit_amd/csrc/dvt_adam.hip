@@ -77,9 +77,9 @@ struct AdamPtrs {  // per fit of a batched launch (blockIdx.y)
 // (two 232-register waves per SIMD) leaves free -- one Adam wave per SIMD then shares the CU with it and the
 // HBM-bound update overlaps the MFMA-bound GEMM instead of time-slicing whole CUs (at 52 registers, with the
 // gather path compiled in, nothing fitted and the pipelined image time was t_extract + 0.96 t_fit).
-struct AdamShadow {  // bf16 shadow copies of the MLP weights, maintained by the dense sweep itself (SHADOW = true)
+struct AdamShadow {  // shadow copies (bf16 or fp32: L.f32) of the MLP weights, maintained by the dense sweep itself (SHADOW = true)
   DvtShadowLayout L;
-  uint16_t* sh[DVT_FIT_BATCH_MAX];
+  void* sh[DVT_FIT_BATCH_MAX];
 };
 
 template <bool GATHER, bool SHADOW = false>
@@ -349,7 +349,7 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
                     float* const* g, uint32_t* const* touched, hipStream_t stream,
                     const DvtAdamRowGather* gather, int reverse, const DvtAdamLazy* lazy_next, int lazy_target,
                     const uint32_t* const* lazy_ukeys, const int32_t* const* lazy_ucount, const DvtShadowLayout* shadow_L,
-                    uint16_t* const* shadow) {
+                    void* const* shadow) {
   if (!h || k < 1 || k > DVT_FIT_BATCH_MAX || h->n_segs < 0 || h->n_segs > DVT_ADAM_MAX_SEGS)
     return DVT_E_BADARG;
   if (h->sparse_end & 255) return DVT_E_BADARG;

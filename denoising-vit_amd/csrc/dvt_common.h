@@ -93,17 +93,18 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
                     const DvtAdamRowGather* gather = nullptr, int reverse = 0, const DvtAdamLazy* lazy_next = nullptr,
                     int lazy_target = 0, const uint32_t* const* lazy_ukeys = nullptr,
                     const int32_t* const* lazy_ucount = nullptr, const struct DvtShadowLayout* shadow_L = nullptr,
-                    uint16_t* const* shadow = nullptr);  // + (with lazy_next) the bf16 weight shadow stored by the sweep
+                    void* const* shadow = nullptr);  // + (with lazy_next) the weight shadow stored by the sweep
 // offs [steps, lattice + 1] / perm [steps, batch] for steps [0, steps) of idx [steps, batch]; lattice <= 8192,
 // batch <= 65535
 int dvt_build_row_lists(const int32_t* idx, int steps, int batch, int lattice, int32_t* offs,
                         uint16_t* perm, hipStream_t stream);
 
 // ---- fused row kernel of the fit (dvt_fit_fused.hip) ----
-// bf16 SHADOW copies of the five MLP weight matrices (W1, W2, Wh1, Wh2, Wh3), rebuilt from the fp32
+// SHADOW copies of the five MLP weight matrices (W1, W2, Wh1, Wh2, Wh3), rebuilt from the fp32
 // master weights after every Adam step: [N][K] (forward operand) and, where a data gradient flows back
-// through the layer, [K][N] (dgrad operand), both in MFMA-fragment-major order (dvt_frag_off) so that
-// every B fragment of the fused kernel is one fully coalesced 16-byte-per-lane global load.
+// through the layer, [K][N] (dgrad operand), both in MFMA-fragment-major order (dvt_frag_off / dvt_frag_off32) so that
+// every B fragment of the fused kernel is one fully coalesced 16-byte-per-lane global load.  Element type: bf16 in the
+// bf16-operand mode (v_mfma_f32_16x16x32_bf16), fp32 in the fp32-operand mode (round 5: v_mfma_f32_16x16x4_f32; f32 = 1).
 #define DVT_SHADOW_MATS 5
 struct DvtShadowLayout {
   int n;                         // matrices present (0: no shadow maintained)
@@ -113,17 +114,18 @@ struct DvtShadowLayout {
   long long direct[DVT_SHADOW_MATS];  // shadow element offset of the [N][K] copy
   long long transp[DVT_SHADOW_MATS];  // shadow element offset of the [K][N] copy, -1: none
   long long lo, hi;              // arena float range covering all matrices (quick wave-uniform reject)
-  long long total;               // bf16 elements
+  long long total;               // elements (2 bytes each, or 4 with f32)
+  int f32;                       // element type of the copies: 0 bf16, 1 fp32
 };
 int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* out);
 
 // (re)build the shadow copies of the matrices inside arena floats [lo, hi) from the fp32 master weights: the
 // whole range at the start of a run, the ranges Adam just stepped after every step (a 2-3 us launch; inside
 // the Adam kernel the extra scalar registers cost its streaming loop a wave per SIMD, ~10 % bandwidth)
-int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, uint16_t* const* shadow,
+int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, void* const* shadow,
                        long long lo, long long hi, hipStream_t s);
-// Operands of the weight-gradient GEMMs, written by the row kernel as bf16 [cols][batch] matrices in
-// fragment-major order (dvt_frag_off with K = batch): the batch index is the contraction index there.
+// Operands of the weight-gradient GEMMs, written by the row kernel as bf16 (fp32 with f32 operands) [cols][batch]
+// matrices in fragment-major order (dvt_frag_off / dvt_frag_off32 with K = batch): the batch index is the contraction index.
 enum { DVT_T_DF = 0, DVT_T_H1, DVT_T_DH1, DVT_T_ENC, DVT_T_RAW, DVT_T_R1, DVT_T_R2, DVT_T_DH, DVT_T_DR2, DVT_T_DR1, DVT_T_COUNT };
 struct DvtTLayout {
   long long off[DVT_T_COUNT];  // element offsets
@@ -136,8 +138,8 @@ struct DvtFusedFit {  // per fit: inputs, arena, shadow weights and what the row
   const int32_t* ridx;
   const float* feat;
   const float* params;
-  const uint16_t* shadow;
-  uint16_t* T;        // transposed bf16 operand copies (DvtTLayout) -> weight-gradient kernel
+  const void* shadow;  // bf16 or fp32 elements (DvtShadowLayout.f32)
+  void* T;            // transposed operand copies (DvtTLayout; element type as the shadow's) -> weight-gradient kernel
   float *F, *Hres;    // fp32 rows the loss stage reads back
   float *dF;          // fp32 d(pred) rows -> Adam gathers the gradient of G from them
   float *denc;        // fp32 d(enc) rows -> grid backward
@@ -169,16 +171,36 @@ __device__ __forceinline__ uint32_t dvt_pack_bf16x2(float a, float b) {
 __host__ __device__ __forceinline__ long long dvt_frag_off(int n, int k, int K) {
   return ((long long)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + (((((k >> 3) & 3) << 4) + (n & 15)) << 3) + (k & 7);
 }
-// The four consecutive arena floats v at float offset e (e % 4 == 0) -> their bf16 shadow copies, when e
+// The fp32 twin for v_mfma_f32_16x16x4_f32, read four MFMA steps at a time: the 16 x 16 block (tile n / 16, super-step
+// k / 16) is one contiguous 1-KB piece, lane = 16 * ((k % 16) / 4) + n % 16 holds the 4 consecutive k of its k-group --
+// component j of a lane's float4 is its B (or A) value of sub-step j, whose MFMA contracts k = 16 S + 4 g + j over the four
+// lane groups g.  (Any partition of k into MFMA steps is valid as long as both operands use the same one.)
+__host__ __device__ __forceinline__ long long dvt_frag_off32(int n, int k, int K) {
+  return ((long long)(n >> 4) * (K >> 4) + (k >> 4)) * 256 + (((((k >> 2) & 3) << 4) + (n & 15)) << 2) + (k & 3);
+}
+// The four consecutive arena floats v at float offset e (e % 4 == 0) -> their shadow copies, when e
 // lies inside one of the shadowed matrices (row-major [N][K], K % 4 == 0: the four share a row).
-__device__ __forceinline__ void dvt_shadow_store(const DvtShadowLayout& L, uint16_t* __restrict__ sh, long long e,
+__device__ __forceinline__ void dvt_shadow_store(const DvtShadowLayout& L, void* __restrict__ shv, long long e,
                                                  float4 v) {
+  uint16_t* __restrict__ sh = static_cast<uint16_t*>(shv);
 #pragma unroll
   for (int i = 0; i < DVT_SHADOW_MATS; ++i) {
     const long long rel64 = e - L.begin[i];
     const int N = L.N[i], K = L.K[i];
     if (rel64 >= 0 && rel64 < (long long)N * K) {
       const int rel = (int)rel64, n = rel / K, k = rel - n * K;
+      if (L.f32) {  // (wave-uniform) fp32 copies: the four k share a lane's float4 in the direct copy
+        float* __restrict__ sf = static_cast<float*>(shv);
+        *reinterpret_cast<float4*>(sf + L.direct[i] + dvt_frag_off32(n, k, K)) = v;
+        if (L.transp[i] >= 0) {
+          float* t = sf + L.transp[i];
+          t[dvt_frag_off32(k + 0, n, N)] = v.x;
+          t[dvt_frag_off32(k + 1, n, N)] = v.y;
+          t[dvt_frag_off32(k + 2, n, N)] = v.z;
+          t[dvt_frag_off32(k + 3, n, N)] = v.w;
+        }
+        continue;
+      }
       const uint32_t lo = dvt_pack_bf16x2(v.x, v.y), hi = dvt_pack_bf16x2(v.z, v.w);
       // forward operand W[n][k..k+3]: four consecutive k stay inside one lane's 8-element run
       *reinterpret_cast<uint2*>(sh + L.direct[i] + dvt_frag_off(n, k, K)) = make_uint2(lo, hi);

@@ -38,8 +38,8 @@ struct Work {
   float *enc, *h1, *F, *raw, *dF, *dh1, *denc, *rows, *r1, *r2, *Hres, *dH, *dr2, *dr1;
   int32_t* g_offs;   // [num_iters, lattice + 1] row lists of the G gradient (nullptr: atomics path)
   uint16_t* g_perm;  // [num_iters, batch]
-  uint16_t* shadow;  // bf16 shadow copies of the MLP weights for the fused row kernel (nullptr: shapes not eligible)
-  uint16_t* T;       // transposed bf16 operand copies for the weight-gradient kernel (with `shadow`)
+  void* shadow;      // shadow copies (bf16 or fp32) of the MLP weights for the fused row kernel (nullptr: shapes not eligible)
+  void* T;           // transposed operand copies for the weight-gradient kernel (with `shadow`)
   // sorted grid-corner lists of the current chunk of GS_CHUNK steps (dvt_grid_dev.h; nullptr: atomics path)
   uint32_t* gs_keys;
   uint16_t* gs_pay;
@@ -60,7 +60,7 @@ bool row_lists_ok(const DvtFitConfig* c) { return c->lattice <= 8192 && c->batch
 // sorted lists / lazy Adam are available where their buffers were carved (dvt_fit_fused_shapes_ok), in both operand
 // precisions; dvt_tune_set(6, 0) (fused step off) leaves them to the bf16 layer-by-layer A/B as before
 bool g_fit_fused_enable_lists(const DvtFitConfig* c) {
-  return dvt_fit_fused_shapes_ok(c) && (!c->mlp_bf16 || dvt_fit_fused_ok(c));
+  return dvt_fit_fused_shapes_ok(c) && (!c->mlp_bf16 || dvt_fit_fused_ok(c));  // (fp32 operands: fused or not)
 }
 
 bool lazy_range(const DvtFitConfig* c, uint32_t* e0, int* l0) {
@@ -113,10 +113,12 @@ int64_t carve(const DvtFitConfig* c, float* base, Work* w) {
     DvtShadowLayout L;
     if (dvt_shadow_layout(c, &L) == 0) {
       fused_bufs = true;
-      t.shadow = reinterpret_cast<uint16_t*>(take((L.total + 1) / 2));
+      // sized for fp32 elements whatever the mode of this run: the operand precision may change between runs on one
+      // workspace (bench.py switches it), and the carving must not depend on it
+      t.shadow = take(L.total);
       DvtTLayout TL;
       dvt_t_layout(c, &TL);
-      t.T = reinterpret_cast<uint16_t*>(take((TL.total + 1) / 2));
+      t.T = take(TL.total);
     }
   }
   t.gs_keys = nullptr;
@@ -289,7 +291,7 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
   auto launch = [&]() { return dvt_linear_group(ops, n_ops, s, c->mlp_bf16); };
   const bool fused = dvt_fit_fused_ok(c) && ws[0].shadow != nullptr && ws[0].g_offs != nullptr;
   DvtShadowLayout shl{};
-  uint16_t* shadow[KM] = {nullptr, nullptr, nullptr, nullptr};
+  void* shadow[KM] = {nullptr, nullptr, nullptr, nullptr};
   DvtFusedFit ff[KM];
   if (fused) {
     // ---- ONE launch for everything row-local: gather, grid forward, MLP forward, loss, dgrad chain ----
@@ -507,7 +509,7 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
     int rc = dvt_shadow_layout(c, &L);
     if (rc) return rc;
     const float* pp[DVT_FIT_BATCH_MAX];
-    uint16_t* ss[DVT_FIT_BATCH_MAX];
+    void* ss[DVT_FIT_BATCH_MAX];
     for (int j = 0; j < k; ++j) {
       pp[j] = bufs[j]->params;
       ss[j] = w[j].shadow;

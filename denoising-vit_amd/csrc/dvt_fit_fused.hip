@@ -5,8 +5,14 @@
 // Reference: the body of the inner loop, main_img_denoising.py:73-88, through
 // dvt/models/neural_feature_field.py:46-49 (enc -> Linear/ReLU/Linear) and
 // dvt/models/offline_denoiser.py:96-140 (G lookup, residual predictor, losses) and autograd's
-// backward of the same.  bf16-operand mode only (DvtFitConfig.mlp_bf16, the reference's
-// `--dtype bfloat16`): operands are rounded to bf16, accumulation / bias / ReLU / losses stay fp32.
+// backward of the same.  Two operand precisions (template parameter F32 of everything below):
+//   bf16 (DvtFitConfig.mlp_bf16, the reference's `--dtype bfloat16`): operands rounded to bf16, v_mfma_f32_16x16x32_bf16,
+//        accumulation / bias / ReLU / losses fp32;
+//   fp32 (round 5; the reference's default `--dtype float32`): fp32 operands end to end on v_mfma_f32_16x16x4_f32 -- the
+//        exact-fp32 matrix instruction, an fmaf chain per output -- read FOUR steps at a time, so that LDS images, weight
+//        fragments and transposed copies keep the bf16 path's geometry: 16 bytes per lane and step group, 1 KB per
+//        (tile, step group); a step group covers 16 k instead of 32 (dvt_common.h: dvt_frag_off32).  C <= 768 (the
+//        phase-2 LDS images of C = 1024 are 206 KB); until round 4 this mode ran five layer-GEMM launches per step.
 //
 // Why this shape.  With B = 2048 sampled rows the step used to be 5 dependent grouped-GEMM launches +
 // the loss, each latency-bound (65 TF/s = 2.6 % of the bf16 MFMA peak) with every activation
@@ -41,9 +47,18 @@ constexpr int FW8 = 8;   // waves per workgroup (template parameter FW of the ke
                          // workgroup of the extractor has left -- see profiles/r04/r04p_pipeline_timeline.txt)
 constexpr int FE = 128;  // encoding width: 16 levels x 8 features
 
-// LDS row pitch of a [16][K] bf16 activation image: +16 B so that the 16 rows of an A-fragment read
+// operand element: bytes, and k values per 16-byte fragment piece of ONE lane group (= k per step group / 4)
+template <bool F32>
+struct Op {
+  static constexpr int ES = F32 ? 4 : 2;    // bytes per element
+  static constexpr int KS = F32 ? 16 : 32;  // k per step group (four lane groups x 16 B)
+};
+typedef unsigned u32x4f __attribute__((ext_vector_type(4)));  // one 16-byte fragment piece, either element type
+
+// LDS row pitch of a [16][K] activation image: +16 B so that the 16 rows of an A-fragment read
 // (ds_read_b128, 16 B per lane) fall on distinct 16-byte bank slots
-__host__ __device__ constexpr int apitch(int K) { return K * 2 + 16; }
+template <bool F32>
+__host__ __device__ constexpr int apitch(int K) { return K * Op<F32>::ES + 16; }
 
 struct FusedArgs {
   DvtGridTable T;
@@ -57,85 +72,113 @@ struct FusedArgs {
 
 __device__ __forceinline__ uint16_t bf16_of(float v) { return (uint16_t)(dvt_pack_bf16x2(v, 0.f) & 0xffffu); }
 
-// One [16][NC] bf16 LDS image (pitch apitch(NC)) -> its slice of the transposed, fragment-major operand copy
-// dstT = [NC][B]: for every column the 16 batch rows of this workgroup are two 16-byte pieces (8 rows each)
-// of the 1-KB fragment block (tile col / 16, k-step b0 / 32).  Adjacent threads take adjacent columns.
-template <int NC, int FR, int FW>
-__device__ __forceinline__ void store_T(const char* img, uint16_t* __restrict__ dstT, int B, int b0, int tid) {
-  // FR / 8 groups of 8 batch rows per column; group `grp` = batch rows b0 + 8 grp .. + 7 = lane group g of k-step
-  for (int item = tid; item < NC * (FR / 8); item += 64 * FW) {
+// One [FR][NC] LDS image (pitch apitch(NC)) -> its slice of the transposed, fragment-major operand copy
+// dstT = [NC][B]: for every column the FR batch rows of this workgroup are 16-byte pieces (8 rows each in bf16, 4 in fp32)
+// of the 1-KB fragment block (tile col / 16, step group b0 / 32 or b0 / 16).  Adjacent threads take adjacent columns.
+template <int NC, int FR, int FW, bool F32>
+__device__ __forceinline__ void store_T(const char* img, void* __restrict__ dstTv, int B, int b0, int tid) {
+  constexpr int RPP = F32 ? 4 : 8;  // batch rows per 16-byte piece
+  for (int item = tid; item < NC * (FR / RPP); item += 64 * FW) {
     const int grp = item / NC, col = item - grp * NC;
-    const int brow = b0 + grp * 8, kstep = brow >> 5, g = (brow >> 3) & 3;
-    const char* src = img + grp * 8 * apitch(NC) + col * 2;
-    uint32_t w[4];
+    const int brow = b0 + grp * RPP;
+    const char* src = img + grp * RPP * apitch<F32>(NC) + col * Op<F32>::ES;
+    if constexpr (F32) {
+      const int sg = brow >> 4, g = (brow >> 2) & 3;
+      float4 v;
+      v.x = *reinterpret_cast<const float*>(src);
+      v.y = *reinterpret_cast<const float*>(src + apitch<F32>(NC));
+      v.z = *reinterpret_cast<const float*>(src + 2 * apitch<F32>(NC));
+      v.w = *reinterpret_cast<const float*>(src + 3 * apitch<F32>(NC));
+      const long long off = ((long long)(col >> 4) * (B >> 4) + sg) * 256 + (((g << 4) + (col & 15)) << 2);
+      *reinterpret_cast<float4*>(static_cast<float*>(dstTv) + off) = v;
+    } else {
+      const int kstep = brow >> 5, g = (brow >> 3) & 3;
+      uint32_t w[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t lo = *reinterpret_cast<const uint16_t*>(src + (2 * j) * apitch(NC));
-      const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * j + 1) * apitch(NC));
-      w[j] = lo | (hi << 16);
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = *reinterpret_cast<const uint16_t*>(src + (2 * j) * apitch<F32>(NC));
+        const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * j + 1) * apitch<F32>(NC));
+        w[j] = lo | (hi << 16);
+      }
+      const long long off = ((long long)(col >> 4) * (B >> 5) + kstep) * 512 + (((g << 4) + (col & 15)) << 3);
+      *reinterpret_cast<uint4*>(static_cast<uint16_t*>(dstTv) + off) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    const long long off = ((long long)(col >> 4) * (B >> 5) + kstep) * 512 + (((g << 4) + (col & 15)) << 3);
-    *reinterpret_cast<uint4*>(dstT + off) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 
 // out[16][N] = act(A[16][K] . W[N][K]^T + bias)  (optionally masked by mask[16][N] > 0)
-//   actA    LDS bf16 image [16][K], pitch apitch(K)
-//   W       global bf16 shadow copy of the [N][K] weight matrix in fragment-major order (dvt_frag_off)
-//   act_out LDS bf16 image [16][N] for the next layer (may alias `mask`: every element is read, then
+//   actA    LDS image [16][K] (bf16 or fp32), pitch apitch(K)
+//   W       global shadow copy of the [N][K] weight matrix in fragment-major order (dvt_frag_off / dvt_frag_off32):
+//           1 KB per (tile, step group), 16 B per lane, either element type
+//   act_out LDS image [16][N] for the next layer (may alias `mask`: every element is read, then
 //           written, by the one lane that owns it), or nullptr
 //   gout    global fp32 [16][N] (this workgroup's rows), or nullptr
-template <int K, int N, bool RELU, bool MASK, int RB, int FW>
-__device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __restrict__ W,
+template <int K, int N, bool RELU, bool MASK, int RB, int FW, bool F32>
+__device__ __forceinline__ void mlp_layer(const char* actA, const void* __restrict__ Wv,
                                           const float* __restrict__ bias, char* act_out,
                                           float* __restrict__ gout, const char* mask, int wave, int lane) {
-  // RB = row blocks of 16 (FR / 16): every weight fragment fetched from L2 is used for RB MFMAs
-  constexpr int NTILES = N / 16, NT = (NTILES + FW - 1) / FW, S = K / 32;
-  // k-steps of weights in flight per wave: ~24 x 1 KB.  The weights are L2 hits at best and memory-side
+  // RB = row blocks of 16 (FR / 16): every weight fragment fetched from L2 is used for RB MFMAs (x 4 sub-steps in fp32)
+  constexpr int KS = Op<F32>::KS, ES = Op<F32>::ES;
+  constexpr int NTILES = N / 16, NT = (NTILES + FW - 1) / FW, S = K / KS;
+  // step groups of weights in flight per wave: ~24 x 1 KB.  The weights are L2 hits at best and memory-side
   // cache hits on first touch (every kernel starts with a cold L2), i.e. 0.3-2 us of latency: with 6 loads
   // in flight per wave the first version of this kernel streamed its 1.3 MB at 24 GB/s per CU (54 us).
   constexpr int INFL = FW == 8 ? 24 : 16;  // (4-wave shape: 16, which keeps the phase-2 kernel at C = 768 under the 272 VGPRs one
                                            // attention workgroup leaves per SIMD; a CU's L2 fill rate saturates far below either)
   constexpr int PD0 = INFL / NT > 16 ? 16 : (INFL / NT < 1 ? 1 : INFL / NT);
   constexpr int PD = PD0 < S ? PD0 : S;
-  static_assert(K % 32 == 0 && N % 16 == 0, "layer shape");
+  static_assert(K % KS == 0 && N % 16 == 0, "layer shape");
   const int lc = lane & 15, g = lane >> 4;
   f32x4 acc[RB][NT];
-  const uint16_t* wp[NT];
+  const char* wp[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[rb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int t = wave + FW * i;
     const int tt = (NTILES % FW == 0 || t < NTILES) ? t : 0;  // surplus tiles compute tile 0 again, never stored
-    wp[i] = W + (size_t)tt * S * 512 + lane * 8;  // fragment-major copy: 1 KB per (tile, k-step), lane-linear
+    wp[i] = static_cast<const char*>(Wv) + (size_t)tt * S * 1024 + lane * 16;  // 1 KB per (tile, step group), lane-linear
   }
-  bf16x8 b[PD][NT];
+  u32x4f b[PD][NT];
 #pragma unroll
   for (int p = 0; p < PD; ++p)
 #pragma unroll
-    for (int i = 0; i < NT; ++i) b[p][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 512 * p);
+    for (int i = 0; i < NT; ++i) b[p][i] = *reinterpret_cast<const u32x4f*>(wp[i] + 1024 * p);
   // The order below is pinned with sched_barrier: left alone, the scheduler sinks every prefetch to just
   // before its use (register pressure) and the kernel runs with ~6 loads in flight per wave instead of PD*NT.
   __builtin_amdgcn_sched_barrier(0);
-  const char* ap = actA + lc * apitch(K) + g * 16;
+  const char* ap = actA + lc * apitch<F32>(K) + g * 16;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    bf16x8 av[RB];
+    u32x4f av[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) av[rb] = *reinterpret_cast<const bf16x8*>(ap + rb * 16 * apitch(K) + s * 64);
+    for (int rb = 0; rb < RB; ++rb) av[rb] = *reinterpret_cast<const u32x4f*>(ap + rb * 16 * apitch<F32>(K) + s * 64);
+    if constexpr (F32) {
+      // four exact-fp32 steps: component j of both pieces is sub-step j's operand value.  Sub-step outermost: consecutive
+      // MFMAs go to DIFFERENT accumulators (v_mfma_f32_16x16x4_f32: 32 cycles of issue, 40 of dependent latency)
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-        acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rb], b[s % PD][i], acc[rb][i], 0, 0, 0);
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb)
+            acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[rb][j]), __uint_as_float(b[s % PD][i][j]),
+                                                              acc[rb][i], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[rb]),
+                                                               __builtin_bit_cast(bf16x8, b[s % PD][i]), acc[rb][i], 0, 0, 0);
+    }
     if (s + PD < S) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i) b[s % PD][i] = *reinterpret_cast<const bf16x8*>(wp[i] + 512 * (s + PD));
+      for (int i = 0; i < NT; ++i) b[s % PD][i] = *reinterpret_cast<const u32x4f*>(wp[i] + 1024 * (s + PD));
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+  // C/D layout of the 16x16 MFMAs (both): col = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int t = wave + FW * i;
@@ -149,34 +192,46 @@ __device__ __forceinline__ void mlp_layer(const char* actA, const uint16_t* __re
         const int row = rb * 16 + 4 * g + r;
         float v = acc[rb][i][r] + bv;
         if (RELU) v = fmaxf(v, 0.f);
-        if (MASK) {
-          const uint16_t m = *reinterpret_cast<const uint16_t*>(mask + row * apitch(N) + n * 2);
-          v = (m != 0 && !(m & 0x8000u)) ? v : 0.f;  // ReLU output > 0
+        if (MASK) {  // ReLU output > 0
+          if constexpr (F32) {
+            v = *reinterpret_cast<const float*>(mask + row * apitch<F32>(N) + n * ES) > 0.f ? v : 0.f;
+          } else {
+            const uint16_t m = *reinterpret_cast<const uint16_t*>(mask + row * apitch<F32>(N) + n * ES);
+            v = (m != 0 && !(m & 0x8000u)) ? v : 0.f;
+          }
         }
-        if (act_out != nullptr) *reinterpret_cast<uint16_t*>(act_out + row * apitch(N) + n * 2) = bf16_of(v);
+        if (act_out != nullptr) {
+          if constexpr (F32) *reinterpret_cast<float*>(act_out + row * apitch<F32>(N) + n * ES) = v;
+          else *reinterpret_cast<uint16_t*>(act_out + row * apitch<F32>(N) + n * ES) = bf16_of(v);
+        }
         if (gout != nullptr) gout[(size_t)row * N + n] = v;
       }
   }
 }
 
-template <int C, bool PH2, int FR>
+template <int C, bool PH2, int FR, bool F32 = false>
 struct FusedLds {
   static constexpr int H = C / 2, R = C / 4;
   static constexpr int O_ENC = 0;
-  static constexpr int O_H1 = O_ENC + FR * apitch(FE);   // h1, later dh1 in place
-  static constexpr int O_DF = O_H1 + FR * apitch(H);     // d(pred)
-  static constexpr int O_RAW = O_DF + FR * apitch(C);    // phase 2: raw rows, later d(Hres)
-  static constexpr int O_R1 = O_RAW + FR * apitch(C);    // phase 2: r1
-  static constexpr int O_R2 = O_R1 + FR * apitch(R);     // phase 2: r2, later dr2 in place
-  static constexpr int TOTAL = PH2 ? O_R2 + FR * apitch(R) : O_RAW;
+  static constexpr int O_H1 = O_ENC + FR * apitch<F32>(FE);   // h1, later dh1 in place
+  static constexpr int O_DF = O_H1 + FR * apitch<F32>(H);     // d(pred)
+  static constexpr int O_RAW = O_DF + FR * apitch<F32>(C);    // phase 2: raw rows, later d(Hres)
+  static constexpr int O_R1 = O_RAW + FR * apitch<F32>(C);    // phase 2: r1
+  static constexpr int O_R2 = O_R1 + FR * apitch<F32>(R);     // phase 2: r2, later dr2 in place
+  static constexpr int TOTAL = PH2 ? O_R2 + FR * apitch<F32>(R) : O_RAW;
 };
+// the fp32-operand kernel exists where BOTH phases' images fit a CU's LDS at 16 rows per workgroup: C = 384, 768
+template <int C>
+constexpr bool fused_f32_fits() { return FusedLds<C, true, 16, true>::TOTAL <= 160 * 1024; }
 
-template <int C, bool PH2, int FR, int FW>
+template <int C, bool PH2, int FR, int FW, bool F32 = false>
 __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
-  using L = FusedLds<C, PH2, FR>;
+  using L = FusedLds<C, PH2, FR, F32>;
   constexpr int RB = FR / 16;
+  constexpr int ES = Op<F32>::ES;
   static_assert(FR == 16 || FR == 32, "rows per workgroup");
   static_assert(FW == 8 || (FW == 4 && FR == 16), "waves per workgroup");
+  static_assert(!F32 || (FR == 16 && FW == 8), "fp32 operands: 16 rows, 8 waves");
   static_assert(L::TOTAL <= 160 * 1024, "LDS images of the row kernel");
   constexpr int H = C / 2, R = C / 4, E = FE, cq = C / 4;
   __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
@@ -184,7 +239,7 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * FR;
-  const uint16_t* __restrict__ sh = f.shadow;
+  const char* __restrict__ sh = static_cast<const char*>(f.shadow);  // byte pointer: element offsets below are scaled by ES
   const float* __restrict__ P = f.params;
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(f.feat);
 
@@ -211,7 +266,7 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   {
     const int nslot = (int)gridDim.x >= 128 ? 16 : ((int)gridDim.x + 7) / 8;
     const int slot = ((int)blockIdx.x >> 3) % nslot;
-    const long long lines = ((PH2 ? a.S.total : a.S.direct[2]) * 2 + 127) / 128;
+    const long long lines = ((PH2 ? a.S.total : a.S.direct[2]) * ES + 127) / 128;
     const long long per = (lines + nslot - 1) / nslot;
     const long long l0 = slot * per, l1 = l0 + per < lines ? l0 + per : lines;
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(sh);
@@ -244,43 +299,53 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
       hi.z = fmaf(w[c], v.z, hi.z);
       hi.w = fmaf(w[c], v.w, hi.w);
     }
-    *reinterpret_cast<uint4*>(smem + L::O_ENC + r * apitch(E) + l * 16) =
-        make_uint4(dvt_pack_bf16x2(lo.x, lo.y), dvt_pack_bf16x2(lo.z, lo.w), dvt_pack_bf16x2(hi.x, hi.y),
-                   dvt_pack_bf16x2(hi.z, hi.w));
+    if constexpr (F32) {
+      *reinterpret_cast<float4*>(smem + L::O_ENC + r * apitch<F32>(E) + l * 32) = lo;
+      *reinterpret_cast<float4*>(smem + L::O_ENC + r * apitch<F32>(E) + l * 32 + 16) = hi;
+    } else {
+      *reinterpret_cast<uint4*>(smem + L::O_ENC + r * apitch<F32>(E) + l * 16) =
+          make_uint4(dvt_pack_bf16x2(lo.x, lo.y), dvt_pack_bf16x2(lo.z, lo.w), dvt_pack_bf16x2(hi.x, hi.y),
+                     dvt_pack_bf16x2(hi.z, hi.w));
+    }
   }
   if (PH2) {
     for (int i = tid; i < FR * cq; i += 64 * FW) {
       const int r = i / cq, q = i - r * cq;
       const float4 v = feat4[(size_t)f.ridx[row0 + r] * cq + q];
-      *reinterpret_cast<uint2*>(smem + L::O_RAW + r * apitch(C) + q * 8) =
-          make_uint2(dvt_pack_bf16x2(v.x, v.y), dvt_pack_bf16x2(v.z, v.w));
+      if constexpr (F32)
+        *reinterpret_cast<float4*>(smem + L::O_RAW + r * apitch<F32>(C) + q * 16) = v;
+      else
+        *reinterpret_cast<uint2*>(smem + L::O_RAW + r * apitch<F32>(C) + q * 8) =
+            make_uint2(dvt_pack_bf16x2(v.x, v.y), dvt_pack_bf16x2(v.z, v.w));
     }
   }
   __syncthreads();
 
   // ---- forward: field MLP (neural_feature_field.py:40-44, :49), residual predictor (offline_denoiser.py:107)
   const int B = a.n;
-  uint16_t* __restrict__ T = f.T;
-  mlp_layer<E, H, true, false, RB, FW>(smem + L::O_ENC, sh + a.S.direct[0], P + a.off_b1, smem + L::O_H1, nullptr,
+  char* __restrict__ T = static_cast<char*>(f.T);  // byte pointer, like `sh`
+#define SH(off) (sh + (size_t)(off) * ES)
+#define TT(idx) (T + (size_t)a.TL.off[idx] * ES)
+  mlp_layer<E, H, true, false, RB, FW, F32>(smem + L::O_ENC, SH(a.S.direct[0]), P + a.off_b1, smem + L::O_H1, nullptr,
                                nullptr, wave, lane);
   if (PH2)
-    mlp_layer<C, R, true, false, RB, FW>(smem + L::O_RAW, sh + a.S.direct[2], P + a.off_bh1, smem + L::O_R1, nullptr,
+    mlp_layer<C, R, true, false, RB, FW, F32>(smem + L::O_RAW, SH(a.S.direct[2]), P + a.off_bh1, smem + L::O_R1, nullptr,
                                  nullptr, wave, lane);
   __syncthreads();
-  mlp_layer<H, C, false, false, RB, FW>(smem + L::O_H1, sh + a.S.direct[1], P + a.off_b2, nullptr,
+  mlp_layer<H, C, false, false, RB, FW, F32>(smem + L::O_H1, SH(a.S.direct[1]), P + a.off_b2, nullptr,
                                 f.F + (size_t)row0 * C, nullptr, wave, lane);
   // operands of the weight gradients leave as transposed bf16 copies while their LDS images are stable
-  store_T<H, FR, FW>(smem + L::O_H1, T + a.TL.off[DVT_T_H1], B, row0, tid);
-  store_T<E, FR, FW>(smem + L::O_ENC, T + a.TL.off[DVT_T_ENC], B, row0, tid);
+  store_T<H, FR, FW, F32>(smem + L::O_H1, TT(DVT_T_H1), B, row0, tid);
+  store_T<E, FR, FW, F32>(smem + L::O_ENC, TT(DVT_T_ENC), B, row0, tid);
   if (PH2) {
-    mlp_layer<R, R, true, false, RB, FW>(smem + L::O_R1, sh + a.S.direct[3], P + a.off_bh2, smem + L::O_R2, nullptr,
+    mlp_layer<R, R, true, false, RB, FW, F32>(smem + L::O_R1, SH(a.S.direct[3]), P + a.off_bh2, smem + L::O_R2, nullptr,
                                  nullptr, wave, lane);
-    store_T<C, FR, FW>(smem + L::O_RAW, T + a.TL.off[DVT_T_RAW], B, row0, tid);
-    store_T<R, FR, FW>(smem + L::O_R1, T + a.TL.off[DVT_T_R1], B, row0, tid);
+    store_T<C, FR, FW, F32>(smem + L::O_RAW, TT(DVT_T_RAW), B, row0, tid);
+    store_T<R, FR, FW, F32>(smem + L::O_R1, TT(DVT_T_R1), B, row0, tid);
     __syncthreads();
-    mlp_layer<R, C, false, false, RB, FW>(smem + L::O_R2, sh + a.S.direct[4], P + a.off_bh3, nullptr,
+    mlp_layer<R, C, false, false, RB, FW, F32>(smem + L::O_R2, SH(a.S.direct[4]), P + a.off_bh3, nullptr,
                                   f.Hres + (size_t)row0 * C, nullptr, wave, lane);
-    store_T<R, FR, FW>(smem + L::O_R2, T + a.TL.off[DVT_T_R2], B, row0, tid);
+    store_T<R, FR, FW, F32>(smem + L::O_R2, TT(DVT_T_R2), B, row0, tid);
   }
   __syncthreads();  // F (and Hres) rows of this workgroup are visible to all of its waves
 
@@ -305,11 +370,13 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
 #pragma unroll
     for (int rr = r0; rr < r0 + NB; ++rr) {
       const int row = wave + FW * rr, gr = row0 + row;
+      char* const img_p = smem + L::O_DF + row * apitch<F32>(C);                     // d(pred) image of this row ...
+      char* const img_h = PH2 ? smem + L::O_RAW + row * apitch<F32>(C) : nullptr;  // ... d(Hres) over the raw row
       dvt_loss_row_compute<PH2>(lr[rr - r0], reinterpret_cast<float4*>(f.dF) + (size_t)gr * cq,
                                 nullptr, nullptr,
                                 f.rows + (size_t)gr * 8, a.n, cq, a.grad_scale, lane,
-                                reinterpret_cast<uint2*>(smem + L::O_DF + row * apitch(C)),
-                                PH2 ? reinterpret_cast<uint2*>(smem + L::O_RAW + row * apitch(C)) : nullptr);
+                                F32 ? nullptr : reinterpret_cast<uint2*>(img_p), F32 ? nullptr : reinterpret_cast<uint2*>(img_h),
+                                F32 ? reinterpret_cast<float4*>(img_p) : nullptr, F32 ? reinterpret_cast<float4*>(img_h) : nullptr);
     }
     }
   }
@@ -317,25 +384,27 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
 
   // ---- data gradients: dh1 = (dF . W2) * (h1 > 0), denc = dh1 . W1; dr2 = (dH . Wh3) * (r2 > 0),
   //      dr1 = (dr2 . Wh2) * (r1 > 0)  (the [K][N] shadow copies make these k-contiguous as well)
-  mlp_layer<C, H, false, true, RB, FW>(smem + L::O_DF, sh + a.S.transp[1], nullptr, smem + L::O_H1, nullptr,
+  mlp_layer<C, H, false, true, RB, FW, F32>(smem + L::O_DF, SH(a.S.transp[1]), nullptr, smem + L::O_H1, nullptr,
                                smem + L::O_H1, wave, lane);
-  store_T<C, FR, FW>(smem + L::O_DF, T + a.TL.off[DVT_T_DF], B, row0, tid);
+  store_T<C, FR, FW, F32>(smem + L::O_DF, TT(DVT_T_DF), B, row0, tid);
   if (PH2) {
-    mlp_layer<C, R, false, true, RB, FW>(smem + L::O_RAW, sh + a.S.transp[4], nullptr, smem + L::O_R2, nullptr,
+    mlp_layer<C, R, false, true, RB, FW, F32>(smem + L::O_RAW, SH(a.S.transp[4]), nullptr, smem + L::O_R2, nullptr,
                                  smem + L::O_R2, wave, lane);
-    store_T<C, FR, FW>(smem + L::O_RAW, T + a.TL.off[DVT_T_DH], B, row0, tid);
+    store_T<C, FR, FW, F32>(smem + L::O_RAW, TT(DVT_T_DH), B, row0, tid);
   }
   __syncthreads();
-  mlp_layer<H, E, false, false, RB, FW>(smem + L::O_H1, sh + a.S.transp[0], nullptr, nullptr,
+  mlp_layer<H, E, false, false, RB, FW, F32>(smem + L::O_H1, SH(a.S.transp[0]), nullptr, nullptr,
                                 f.denc + (size_t)row0 * E, nullptr, wave, lane);
-  store_T<H, FR, FW>(smem + L::O_H1, T + a.TL.off[DVT_T_DH1], B, row0, tid);
+  store_T<H, FR, FW, F32>(smem + L::O_H1, TT(DVT_T_DH1), B, row0, tid);
   if (PH2) {
-    mlp_layer<R, R, false, true, RB, FW>(smem + L::O_R2, sh + a.S.transp[3], nullptr, smem + L::O_R1, nullptr,
+    mlp_layer<R, R, false, true, RB, FW, F32>(smem + L::O_R2, SH(a.S.transp[3]), nullptr, smem + L::O_R1, nullptr,
                                  smem + L::O_R1, wave, lane);
-    store_T<R, FR, FW>(smem + L::O_R2, T + a.TL.off[DVT_T_DR2], B, row0, tid);
+    store_T<R, FR, FW, F32>(smem + L::O_R2, TT(DVT_T_DR2), B, row0, tid);
     __syncthreads();
-    store_T<R, FR, FW>(smem + L::O_R1, T + a.TL.off[DVT_T_DR1], B, row0, tid);
+    store_T<R, FR, FW, F32>(smem + L::O_R1, TT(DVT_T_DR1), B, row0, tid);
   }
+#undef SH
+#undef TT
   // keeps the warm-up loads alive (a.n is never negative)
   if (a.n < 0) f.rows[tid] = __uint_as_float(warm[0] ^ warm[1] ^ warm[2] ^ warm[3] ^ warm[4]);
 }
@@ -343,10 +412,10 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
 // one float4 of the arena per thread -> its bf16 shadow copies
 __global__ __launch_bounds__(256) void shadow_build_kernel(DvtShadowLayout L, const float* const p0,
                                                            const float* const p1, const float* const p2,
-                                                           const float* const p3, uint16_t* s0, uint16_t* s1,
-                                                           uint16_t* s2, uint16_t* s3, long long q_lo, long long q_hi) {
+                                                           const float* const p3, void* s0, void* s1,
+                                                           void* s2, void* s3, long long q_lo, long long q_hi) {
   const float* p = blockIdx.y == 0 ? p0 : (blockIdx.y == 1 ? p1 : (blockIdx.y == 2 ? p2 : p3));
-  uint16_t* sh = blockIdx.y == 0 ? s0 : (blockIdx.y == 1 ? s1 : (blockIdx.y == 2 ? s2 : s3));
+  void* sh = blockIdx.y == 0 ? s0 : (blockIdx.y == 1 ? s1 : (blockIdx.y == 2 ? s2 : s3));
   const long long q = q_lo + (long long)blockIdx.x * 256 + threadIdx.x;
   if (q >= q_hi) return;
   dvt_shadow_store(L, sh, q * 4, reinterpret_cast<const float4*>(p)[q]);
@@ -355,8 +424,9 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(DvtShadowLayout L, co
 
 // ======================================================================================================
 // Weight gradients of the step: dW[m][n] += sum_b dY[b][m] * X[b][n] for every layer, one launch.
-// Both operands arrive as bf16 [cols][batch] fragment-major copies (store_T above), so A and B fragments of
-// v_mfma_f32_16x16x32_bf16 are single coalesced 16-byte-per-lane loads, straight to VGPRs: every WAVE owns
+// Both operands arrive as [cols][batch] fragment-major copies (store_T above; bf16, or fp32 in the fp32-operand mode), so A
+// and B fragments of v_mfma_f32_16x16x32_bf16 (four steps of v_mfma_f32_16x16x4_f32) are single coalesced 16-byte-per-lane
+// loads, straight to VGPRs: every WAVE owns
 // a 32 x 32 block of one dW and one quarter of the batch (16 loads in flight); the four quarter sums of a
 // block meet in LDS and ONE wave stores the total with plain stores into the zeroed gradient arena -- no
 // atomics, deterministic sums (see wgrad_block; round 1 used 4 fp32 atomics per element).
@@ -366,8 +436,8 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(DvtShadowLayout L, co
 // ======================================================================================================
 constexpr int WG_MAX_PROB = 5 * DVT_FIT_BATCH_MAX;
 struct WgradProb {
-  const uint16_t* AT;  // dY^T [M][B]
-  const uint16_t* BT;  // X^T  [N][B]
+  const char* AT;  // dY^T [M][B]: fragment-major, 1 KB per (tile, step group) in either element type
+  const char* BT;  // X^T  [N][B]
   float* dW;           // [M][N] fp32, += (atomics)
   float* db;           // [M] or nullptr
   int M, N;
@@ -392,7 +462,7 @@ struct WgradArgs {
 // element, this half and the grid backward were both bound by the L2 atomic rate: side by side in one launch
 // they took exactly the sum of their stand-alone times.)
 constexpr int WG_PART_FLOATS = 32 * 32 + 32;  // a wave's partial block + its bias partials
-template <int SLOTS>  // units per workgroup: 4 (16 waves) or 2 (8 waves, dvt_tune_set(14, 1))
+template <int SLOTS, bool F32>  // units per workgroup: 4 (16 waves) or 2 (8 waves, dvt_tune_set(14, 1)); operand element type
 __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int blk, int wave, int lane, float* red) {
   constexpr int PD = 4;
   const int slot = wave >> 2, ks = wave & 3;
@@ -417,13 +487,13 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int blk, int wav
     const int local = unit - a.unit0[pi], nbn = p.N >> 5;
     mb = local / nbn;
     nb = local - mb * nbn;
-    const int ksteps = a.B >> 5, S = ksteps >> 2, s_begin = ks * S;  // S % PD == 0 (host)
-    const uint16_t* ap[2];
-    const uint16_t* bp[2];
+    const int ksteps = a.B / Op<F32>::KS, S = ksteps >> 2, s_begin = ks * S;  // step groups of the batch; S % PD == 0 (host)
+    const char* ap[2];
+    const char* bp[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ap[i] = p.AT + ((size_t)(mb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
-      bp[i] = p.BT + ((size_t)(nb * 2 + i) * ksteps + s_begin) * 512 + lane * 8;
+      ap[i] = p.AT + ((size_t)(mb * 2 + i) * ksteps + s_begin) * 1024 + lane * 16;
+      bp[i] = p.BT + ((size_t)(nb * 2 + i) * ksteps + s_begin) * 1024 + lane * 16;
     }
     f32x4 acc[2][2];
 #pragma unroll
@@ -432,34 +502,55 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int blk, int wav
       for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     do_bias = p.db != nullptr && nb == 0;  // wave-uniform
     float bsum[2] = {0.f, 0.f};
-    bf16x8 fa[PD][2], fb[PD][2];
+    u32x4f fa[PD][2], fb[PD][2];
 #pragma unroll
     for (int q = 0; q < PD; ++q)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * q);
-        fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * q);
+        fa[q][i] = *reinterpret_cast<const u32x4f*>(ap[i] + 1024 * q);
+        fb[q][i] = *reinterpret_cast<const u32x4f*>(bp[i] + 1024 * q);
       }
     __builtin_amdgcn_sched_barrier(0);
     for (int s0 = 0; s0 < S; s0 += PD) {
 #pragma unroll
       for (int q = 0; q < PD; ++q) {
+        if constexpr (F32) {  // sub-step outermost: four independent accumulators in rotation (see mlp_layer)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
-        if (do_bias) {
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[q][i][e]), __uint_as_float(fb[q][j][e]),
+                                                                 acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((uint32_t)(uint16_t)fa[q][i][e]) << 16);
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[q][i]),
+                                                                  __builtin_bit_cast(bf16x8, fb[q][j]), acc[i][j], 0, 0, 0);
+        }
+        if (do_bias) {  // column sums of dY: every batch row of the step group sits in exactly one lane group's piece
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (F32) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(fa[q][i][e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {  // (element order as in rounds 2-4: the sums stay bit-identical)
+                bsum[i] += __uint_as_float(fa[q][i][e] << 16);
+                bsum[i] += __uint_as_float(fa[q][i][e] & 0xffff0000u);
+              }
+            }
+          }
         }
         if (s0 + q + PD < S) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            fa[q][i] = *reinterpret_cast<const bf16x8*>(ap[i] + 512 * (s0 + q + PD));
-            fb[q][i] = *reinterpret_cast<const bf16x8*>(bp[i] + 512 * (s0 + q + PD));
+            fa[q][i] = *reinterpret_cast<const u32x4f*>(ap[i] + 1024 * (s0 + q + PD));
+            fb[q][i] = *reinterpret_cast<const u32x4f*>(bp[i] + 1024 * (s0 + q + PD));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -538,7 +629,7 @@ struct BackwardArgs {
   int n, grid_blocks_per_fit, k, wg_blocks;
   WgradArgs w;
 };
-template <int WAVES>
+template <int WAVES, bool F32 = false>
 __global__ __launch_bounds__(64 * WAVES) void fit_backward_kernel(BackwardArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[WAVES * WG_PART_FLOATS];  // 66 KB at 16 waves: grid half uses the first 8.2 KB
   // weight-gradient blocks FIRST: the grid half alone is more blocks than the chip holds at once, behind
@@ -556,7 +647,7 @@ __global__ __launch_bounds__(64 * WAVES) void fit_backward_kernel(BackwardArgs a
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  wgrad_block<WAVES / 4>(a.w, (int)blockIdx.x, wave, threadIdx.x & 63, smem);
+  wgrad_block<WAVES / 4, F32>(a.w, (int)blockIdx.x, wave, threadIdx.x & 63, smem);
 }
 
 // FR = 32 rows per workgroup halves the weight stream per row (every fragment feeds two MFMAs) and the number of
@@ -567,6 +658,16 @@ __global__ __launch_bounds__(64 * WAVES) void fit_backward_kernel(BackwardArgs a
 // wherever it fits (the parity tests run both).
 template <int C>
 int launch_rows(const FusedArgs& a, int k, bool phase2, hipStream_t s) {
+  if (a.S.f32) {  // fp32 operands: 16 rows, 8 waves (the shapes the LDS images fit: dvt_fit_fused_ok)
+    if constexpr (fused_f32_fits<C>()) {
+      dim3 grid(a.n / 16, k), block(64 * FW8);
+      if (phase2) hipLaunchKernelGGL((fit_rows_kernel<C, true, 16, FW8, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((fit_rows_kernel<C, false, 16, FW8, true>), grid, block, 0, s, a);
+      DVT_CHECK_LAUNCH();
+      return 0;
+    }
+    return DVT_E_BADARG;
+  }
   const bool fits32 = phase2 ? (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) : (FusedLds<C, false, 32>::TOTAL <= 160 * 1024);
   const bool r32 = fits32 && a.n % 32 == 0 && (g_fit_rows32 == 2 || (g_fit_rows32 == 1 && k >= 4));
   const bool small = g_fit_small_wg && !r32;
@@ -600,6 +701,7 @@ int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* L) {
   const bool tr[DVT_SHADOW_MATS] = {true, true, false, true, true};  // no data gradient flows into `raw`
   long long o = 0;
   L->n = DVT_SHADOW_MATS;
+  L->f32 = c->mlp_bf16 ? 0 : 1;  // element type of the copies = the operand precision of the step
   L->lo = begins[0];
   L->hi = 0;
   for (int i = 0; i < DVT_SHADOW_MATS; ++i) {
@@ -619,11 +721,11 @@ int dvt_shadow_layout(const DvtFitConfig* c, DvtShadowLayout* L) {
   return 0;
 }
 
-int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, uint16_t* const* shadow,
+int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* params, void* const* shadow,
                        long long lo, long long hi, hipStream_t s) {
   if (!L || k < 1 || k > DVT_FIT_BATCH_MAX || L->n <= 0) return DVT_E_BADARG;
   const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
-  uint16_t* sh[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* sh[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int f = 0; f < k; ++f) {
     if (!params[f] || !shadow[f]) return DVT_E_BADARG;
     p[f] = params[f];
@@ -640,8 +742,13 @@ int dvt_shadow_build_k(const DvtShadowLayout* L, int k, const float* const* para
 int g_fit_fused_enable = 1;  // dvt_tune_set(6, 0): the unfused launch sequence (same results, A/B timing + parity)
 int g_fit_sorted_grid = 1;  // 0: the fused step scatters the grid gradient with atomics (round-2a path)
 
+int g_fit_fused_f32 = 1;  // dvt_tune_set(6, 2 / 3): fp32-operand fused step off / on (A/B against the layer-by-layer launches)
+
 bool dvt_fit_fused_ok(const DvtFitConfig* c) {
-  return g_fit_fused_enable && c && c->mlp_bf16 && dvt_fit_fused_shapes_ok(c);
+  if (!g_fit_fused_enable || !c || !dvt_fit_fused_shapes_ok(c)) return false;
+  if (c->mlp_bf16) return true;
+  // fp32 operands (round 5): where the fp32 LDS images of both phases fit a CU at 16 rows per workgroup
+  return g_fit_fused_f32 && (c->feat_dim == 384 || c->feat_dim == 768);
 }
 
 bool dvt_fit_fused_shapes_ok(const DvtFitConfig* c) {
@@ -706,13 +813,15 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
   a.B = c->batch;
   const int ksteps = a.B / 32;
   a.ksplit = 4;  // batch quarters = the 4 waves of a unit; S = ksteps / 4 must be a multiple of the prefetch depth 4
-  if (ksteps % 16) return DVT_E_BADARG;
+  if (ksteps % 16) return DVT_E_BADARG;  // (fp32 operands: step groups of 16 rows, twice as many: the same condition)
   int units = 0;
   double flops = 0.0;
+  const bool f32 = !c->mlp_bf16;
+  const size_t es = f32 ? 4 : 2;  // bytes per element of the transposed operand copies
   auto add = [&](const DvtFusedFit& f, int tA, int tB, long long ow, long long ob, int M, int N) {
     WgradProb& p = a.p[a.n_prob];
-    p.AT = f.T + TL.off[tA];
-    p.BT = f.T + TL.off[tB];
+    p.AT = static_cast<const char*>(f.T) + (size_t)TL.off[tA] * es;
+    p.BT = static_cast<const char*>(f.T) + (size_t)TL.off[tB] * es;
     p.dW = f.grads + ow;
     p.db = f.grads + ob;
     p.M = M;
@@ -754,7 +863,7 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
   ba.grid_blocks_per_fit = ba.plan.n_lds_blocks + dvt_cdiv(direct_threads, 1024);
   bool sorted = g_fit_sorted_grid && dvt_grid_sorted_ok(&c->grid, c->batch);
   for (int f = 0; f < k; ++f) sorted = sorted && fits[f].gs_keys && fits[f].gs_pay && fits[f].gs_w;
-  const bool small = g_fit_small_wg && sorted;  // 8-wave workgroups, 2 units each
+  const bool small = g_fit_small_wg && sorted && !f32;  // 8-wave workgroups, 2 units each
   if (sorted) {
     ba.gs.nt = 4 * c->batch;
     ba.gs.bitmap_end = fits[0].gs_bitmap_end;
@@ -775,7 +884,9 @@ int dvt_fit_backward_k(const DvtFitConfig* c, int k, const DvtFusedFit* fits, bo
   const int wg_blocks = dvt_cdiv((long long)units + dvt_cdiv((long long)a.n_gather * a.lattice, 4), small ? 2 : 4);
   ba.wg_blocks = wg_blocks;
   DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, flops);
-  if (small)
+  if (f32)
+    hipLaunchKernelGGL((fit_backward_kernel<16, true>), dim3(ba.grid_blocks_per_fit * k + wg_blocks), dim3(1024), 0, s, ba);
+  else if (small)
     hipLaunchKernelGGL(fit_backward_kernel<8>, dim3(ba.grid_blocks_per_fit * k + wg_blocks), dim3(512), 0, s, ba);
   else
     hipLaunchKernelGGL(fit_backward_kernel<16>, dim3(ba.grid_blocks_per_fit * k + wg_blocks), dim3(1024), 0, s, ba);

@@ -830,6 +830,7 @@ namespace {
 extern int g_cfg_override;
 }
 extern int g_fit_fused_enable;
+extern int g_fit_fused_f32;
 extern int g_fit_sorted_grid;
 extern int g_fit_lazy_adam;
 extern int g_fit_lazy_refresh;
@@ -864,7 +865,10 @@ extern "C" int dvt_tune_set(int key, int value) {
     return 0;
   }
   if (key == 6) {
-    g_fit_fused_enable = value != 0;
+    if (value == 2 || value == 3)
+      g_fit_fused_f32 = value == 3;  // fp32-operand fused step off / on (default on)
+    else
+      g_fit_fused_enable = value != 0;
     return 0;
   }
   if (key == 7) {

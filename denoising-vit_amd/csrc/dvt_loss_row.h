@@ -36,11 +36,13 @@ __device__ __forceinline__ void dvt_loss_row_load(DvtLossRowRegs<HAS_RES>& x, co
 //   d_G             : fp32 atomics into the lattice row of the G gradient
 //   row_sums        : {sse, cos, res_sse, res_abs, ...} of this row (lane 0)
 //   b_pred / b_hres : the same gradient rows rounded to bf16 (4 values = 8 B per float4), e.g. in LDS
+//   f_pred / f_hres : the same gradient rows as fp32 (e.g. the LDS images of the fp32-operand row kernel)
 template <bool HAS_RES>
 __device__ __forceinline__ void dvt_loss_row_compute(const DvtLossRowRegs<HAS_RES>& x, float4* __restrict__ d_pred,
                                                      float4* __restrict__ d_hres, float* __restrict__ d_G,
                                                      float* __restrict__ row_sums, int n, int cq, float grad_scale,
-                                                     int lane, uint2* b_pred, uint2* b_hres) {
+                                                     int lane, uint2* b_pred, uint2* b_hres, float4* f_pred = nullptr,
+                                                     float4* f_hres = nullptr) {
   float4 vp[DVT_LOSS_MAXQ], vr[DVT_LOSS_MAXQ], vh[DVT_LOSS_MAXQ], vfg[DVT_LOSS_MAXQ];
   float sse = 0.f, dot = 0.f, np = 0.f, nr = 0.f, rsse = 0.f, rabs = 0.f;
 #pragma unroll
@@ -89,7 +91,7 @@ __device__ __forceinline__ void dvt_loss_row_compute(const DvtLossRowRegs<HAS_RE
     row_sums[2] = rsse;
     row_sums[3] = rabs;
   }
-  if (d_pred == nullptr && b_pred == nullptr) return;
+  if (d_pred == nullptr && b_pred == nullptr && f_pred == nullptr) return;
   const float inv_nc = 1.0f / ((float)n * (float)(cq * 4));
   const float inv_n = 1.0f / (float)n;
   // d/dp [mse] = 2 (p - r) / (n c);  d/dp [1 - mean cos] = -(1/n) (r/denom - cos * p / |p|^2)
@@ -109,6 +111,7 @@ __device__ __forceinline__ void dvt_loss_row_compute(const DvtLossRowRegs<HAS_RE
       d.w = grad_scale * (c_mse * (p.w - r.w) + a_r * r.w + a_p * p.w);
       if (d_pred != nullptr) d_pred[q] = d;
       if (b_pred != nullptr) b_pred[q] = make_uint2(dvt_pack_bf16x2(d.x, d.y), dvt_pack_bf16x2(d.z, d.w));
+      if (f_pred != nullptr) f_pred[q] = d;
       if (d_G != nullptr) {
         float* g = d_G + q * 4;
         atomic_add_f32(g + 0, d.x);
@@ -116,7 +119,7 @@ __device__ __forceinline__ void dvt_loss_row_compute(const DvtLossRowRegs<HAS_RE
         atomic_add_f32(g + 2, d.z);
         atomic_add_f32(g + 3, d.w);
       }
-      if (HAS_RES && (d_hres != nullptr || b_hres != nullptr)) {
+      if (HAS_RES && (d_hres != nullptr || b_hres != nullptr || f_hres != nullptr)) {
         const float4 h = vh[s], fg = vfg[s];
         const float c_res = 0.1f * 2.0f * inv_nc, c_abs = 0.02f * inv_nc;
         float4 e;
@@ -126,6 +129,7 @@ __device__ __forceinline__ void dvt_loss_row_compute(const DvtLossRowRegs<HAS_RE
         e.w = grad_scale * (c_res * (h.w - (r.w - fg.w)) + c_abs * dvt_sgn(h.w));
         if (d_hres != nullptr) d_hres[q] = e;
         if (b_hres != nullptr) b_hres[q] = make_uint2(dvt_pack_bf16x2(e.x, e.y), dvt_pack_bf16x2(e.z, e.w));
+        if (f_hres != nullptr) f_hres[q] = e;
       }
     }
   }

@@ -25,6 +25,7 @@ import time
 import numpy as np
 import torch
 
+from . import _lib
 from . import dist as D
 from . import views as V
 from ._lib import DvtError
@@ -278,6 +279,13 @@ class Stage1:
         order (numpy RNG) -- the draws of the reference's sequential loop."""
         engines = self.engines[:len(group)]
         C = self.feat_dim
+        if engines[0].s.mlp_dtype == "float32" and self.depth > 1:
+            # fp32-operand fit beside a running extractor: the fused row kernel (round 5: 3 launches per step, 157 KB of LDS
+            # per workgroup) against the layer-by-layer launches (10 per step, 17 KB each) -- alone they take the same 200 us
+            # per step.  Beside the bf16 extractor (one 136-KB GEMM workgroup per CU) either waits for whole CUs and fewer
+            # launches win (+2.5 % images/s); beside the fp32 extractor (two 64-KB GEMM workgroups per CU) the small kernels
+            # slip in and the fused one costs 2.6 % (profiles/r05/r05f_*): the driver picks per mode.
+            _lib.check(_lib.lib().dvt_tune_set(6, 2 if self.extract_dtype == "float32" else 3), "dvt_tune_set(6)")
         idxs = self._next_indices(len(group))
         for e in engines:
             e.reset(self.gen)

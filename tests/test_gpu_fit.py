@@ -589,3 +589,46 @@ def test_fp32_lazy_adam_vs_dense_sweep(built_lib):
           f"final loss {ll[T - 1]['loss']:.5f} vs {ld[T - 1]['loss']:.5f}, saved-tensor cosine min {cos.min():.6f}")
     assert cos.min() > 0.99
     assert float(lazy.grads.abs().max()) == 0.0 and int(lazy.touched.abs().max()) == 0
+
+
+@pytest.mark.parametrize("C,V", [(768, 6), (384, 6)])
+def test_fp32_fused_row_kernel_equals_layer_by_layer(built_lib, C, V):
+    """Round 5: the fp32-operand mode (the reference's default `--dtype float32`) takes the fused row kernel too -- fp32 LDS
+    images, fp32 fragment-major weight shadow, four v_mfma_f32_16x16x4_f32 steps per 16-byte fragment piece, fp32 transposed
+    operand copies for the weight gradients -- instead of five layer-GEMM launches per step (dvt_tune_set(6, 2) restores
+    those).  Both are exact fp32 fmaf chains, only the order of the k terms differs, so 16 steps across the phase switch
+    must agree far tighter than in the bf16 test above: a layout bug in any of the new fragment formats cannot hide here."""
+    from dvt_amd.fit import FitEngine, FitSettings
+    H = W = 37
+    feats, xy = synthetic_image(V, H, W, C, seed=C + 1)
+    n_rows = V * H * W
+    T = 16
+    s = FitSettings(feat_dim=C, num_iters=T, warmup_iters=2, mlp_dtype="float32")
+    idx = np.random.RandomState(C).randint(0, n_rows, (T, s.pixel_bsz)).astype(np.int32)
+    f, c = feats.reshape(-1, C).to(DEV), xy.reshape(-1, 2).to(DEV)
+    res = {}
+    try:
+        for fused in (3, 2):
+            assert built_lib.dvt_tune_set(6, fused) == 0
+            eng = FitEngine(s, n_rows, DEV)
+            eng.reset(torch.Generator(device=DEV).manual_seed(1))
+            eng.fit(f, c, idx, log_every=1)
+            torch.cuda.synchronize()
+            res[fused] = (eng.params.clone(), eng.loss_log(), eng.infer(xy[-1].to(DEV)).cpu())
+            assert float(eng.grads.abs().max()) == 0.0 and int(eng.touched.abs().max()) == 0
+            del eng
+    finally:
+        built_lib.dvt_tune_set(6, 3)
+    (p1, l1, o1), (p0, l0, o0) = res[3], res[2]
+    worst = 0.0
+    for step in range(T):
+        for k, v in l0[step].items():
+            worst = max(worst, abs(l1[step][k] - v) / max(1.0, abs(v)))
+            assert abs(l1[step][k] - v) <= 5e-5 * max(1.0, abs(v)), (step, k, l1[step][k], v)
+    assert "residual_loss" in l1[T - 1] and l1[T - 1]["residual_loss"] != 0.0
+    d = (p1 - p0).abs()
+    print(f"fp32 fused vs layer-by-layer (C={C}): worst per-step loss rel diff {worst:.2e}; params max |diff| {float(d.max()):.3e} "
+          f"(scale {float(p0.abs().max()):.2f}), mean {float(d.mean()):.3e}")
+    # (Adam turns a sign flip of a near-zero gradient into a step of ~2 lr: single elements may differ, the bulk must not)
+    assert float(d.mean()) < 2e-6 and float(d.max()) < 0.05
+    assert per_patch_cos(o1, o0).min() > 0.99999
