@@ -289,8 +289,11 @@ class Stage1:
         idxs = self._next_indices(len(group))
         for e in engines:
             e.reset(self.gen)
-        fit_many(engines, [sl.features.view(-1, C) for sl in group],
-                 [sl.coords.view(-1, 2) for sl in group], idxs, log_every=log_every)
+        try:
+            fit_many(engines, [sl.features.view(-1, C) for sl in group],
+                     [sl.coords.view(-1, 2) for sl in group], idxs, log_every=log_every)
+        finally:
+            _lib.lib().dvt_tune_set(6, 3)  # (the launches are enqueued: the library's default for whoever comes next)
         for e, sl in zip(engines, group):
             sl.range_flag = e.range_flag  # travels with the image; the engine moves on to the next one
         return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]

@@ -283,7 +283,10 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);
  * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
  *         2 / 3 = LDS stages of the stage-2 GEMMs (2, default: two workgroups per CU);
- * key 6 = bf16-mode fit step: 1 (default) the fused row kernel (dvt_fit_fused.hip), 0 = one launch per layer;
+ * key 6 = fit step: 1 (default) the fused row kernel (dvt_fit_fused.hip), 0 = one launch per layer (both operand
+ *         precisions); 3 (default) / 2 = the same switch for the fp32-operand mode only (round 5: fp32 row kernel on
+ *         v_mfma_f32_16x16x4_f32 where its LDS images fit, feat_dim 384 / 768; results agree with the layer-by-layer launches to
+ *         1e-7, the same 200 us per step alone; dvt_amd.stage1 selects 2 beside the fp32 extractor, profiles/r05/r05f_*);
  * key 7 = fit step (both operand precisions since round 4): 1 (default) hash-grid gradient gathered from per-step sorted
  *         corner lists, 0 = scattered with atomics;
  * key 9 = fit step (both precisions): 1 (default) lazy Adam over the fine hash-grid levels -- with fp32 operands always the
