@@ -417,8 +417,9 @@ def main():
                 "fit_step": ("bfloat16: fused row kernel, hash-grid gradient gathered from per-step sorted lists, dense Adam "
                              "for coarse grid levels + MLPs + G, lazy Adam (same recurrence applied on demand, refresh every 32 "
                              "steps; replay arithmetic v_rcp / v_sqrt, 1 ulp each, unless --tune 10=1 selects the IEEE replay) for the fine "
-                             "grid levels; float32: layer-by-layer kernels, "
-                             "dense Adam"),
+                             "grid levels; float32: the same step with exact-fp32 operands (v_mfma_f32_16x16x4_f32 row kernel beside "
+                             "the bf16 extractor, layer-by-layer exact-fp32 GEMMs beside the fp32 extractor; sorted lists; lazy Adam "
+                             "with the IEEE replay)"),
                 "extractor": "LayerNorm folded into the qkv / fc1 GEMMs (bf16 path); LayerNorm kernels in the fp32 path",
                 "weights": "random init (no network for checkpoints)",
                 "t_extract_s_serial": split["t_extract"], "t_fit_s_serial": split["t_fit"],
