@@ -78,6 +78,8 @@ def parse():
     p.add_argument("--no-fp32-fit", action="store_true", help="skip the second timed region (fp32-operand fit)")
     p.add_argument("--no-vit-large", action="store_true",
                    help="skip the BASELINE configs[2] leg (ViT-L/14 + 4 concurrent fits, value_vit_large_k4)")
+    p.add_argument("--no-stage2", action="store_true",
+                   help="skip the BASELINE configs[4] leg (stage-2 Denoiser training step, value_stage2_samples_per_s)")
     p.add_argument("--vit-cus-per-32", type=int, default=32,
                    help="CUs (of every 32) the extractor stream may use; <32 keeps some free for the fit")
     p.add_argument("--tune", type=str, default="", help="developer knobs: key=value,... for dvt_tune_set")
@@ -244,6 +246,45 @@ def vit_large_leg(a, device, rank, D, V, Stage1, PretrainedViTWrapper):
     return out
 
 
+def stage2_leg(device, D):
+    """BASELINE configs[4] on ONE GPU (stage 2 had no driver-side number): the generalizable Denoiser's
+    training step -- one timm Block on [32, 1369, 768] feature maps, MSE + cosine loss, exact-fp32 HIP forward + backward +
+    AdamW (csrc/dvt_stage2.hip) -- on synthetic (raw, denoised) pairs resident in HBM: 3 untimed + 20 timed steps.  The
+    data-parallel form adds ONE flat all-reduce of the gradient arena per step (tools/bench_stage2.py under torchrun)."""
+    from dvt_amd.models import Denoiser
+    batch, grid, dim, steps = 32, 37, 768, 20
+    m = Denoiser(grid, grid, dim, None, True, 1, device=device, seed=0)
+    g = torch.Generator(device=device).manual_seed(0)
+    x = torch.randn(batch, grid, grid, dim, device=device, generator=g)
+    t = torch.randn(batch, grid, grid, dim, device=device, generator=g)
+
+    def step():
+        loss = m.training_step(x, t)
+        m.engine.adamw_step(1e-4, 1e-5, grad_scale=1.0)
+        return loss
+
+    for _ in range(3):
+        step()
+
+    def region():
+        for _ in range(steps):
+            step()
+        return steps * batch
+
+    n, el, _ = D.timed(region, device)
+    C, T, F, H = dim, grid * grid, 4 * dim, dim // 64
+    lin = 2.0 * batch * T * (3 * C * C + C * C + 2 * C * F)  # forward linear layers
+    att = 4.0 * batch * H * T * T * 64                       # q k^T and P v
+    flops = 3.0 * lin + (att + 1.5 * att * 2)                # backward: 2 x linear, 4 attention products (tools/bench_stage2.py)
+    out = {"samples_per_s": n / el, "ms_per_step": 1e3 * el / steps, "batch": batch, "steps": steps,
+           "achieved_tflops": flops * steps / el / 1e12, "frac_of_fp32_mfma_peak": flops * steps / el / 1e12 / MFMA_F32_PEAK_TF,
+           "workload": "BASELINE configs[4] on one GPU: Denoiser (1 Block, dim 768, 37 x 37 tokens) training step, batch 32, "
+                       "exact fp32, synthetic pairs; no DDP in this leg"}
+    del m, x, t
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     from dvt_amd import dist as D
@@ -389,6 +430,12 @@ def main():
         except Exception as exc:  # an extra leg must never take the bench line down
             large = {"error": repr(exc)}
 
+    s2 = None
+    if not a.no_stage2 and world == 1 and a.model in IMAGE_CEILINGS:
+        try:
+            s2 = stage2_leg(device, D)
+        except Exception as exc:  # an extra leg must never take the bench line down
+            s2 = {"error": repr(exc)}
     if rank == 0:
         out = {
             "metric": "stage-1 images denoised/sec (DINOv2-B/14, 518px, 1k Adam steps)",
@@ -434,6 +481,9 @@ def main():
             key = "value_fp32_fit" if other == "float32" else "value_bf16_fit"
             out[key] = second["images_per_s"]
             out["config"][key + "_detail"] = second
+        if s2 is not None:
+            out["value_stage2_samples_per_s"] = s2.get("samples_per_s")
+            out["config"]["value_stage2_detail"] = s2
         if large is not None:
             out["value_vit_large_k4"] = large.get("images_per_s")
             out["config"]["value_vit_large_k4_detail"] = large

@@ -127,3 +127,16 @@ def test_ranks_pin_disjoint_host_cpu_slices():
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
         info = json.loads(out.strip().splitlines()[-1])
         assert info["pinned"] and info["local_rank"] == 1 and set(info["affinity"]) == seen[1], (extra, info)
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """`bench.py --gpus N` must never run on fewer ranks than it reports.  Standalone (WORLD_SIZE unset = 1)
+    with --gpus 2 it stops before touching a device; the message names the torchrun command."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "--gpus 2 but WORLD_SIZE=1" in r.stderr and "torch.distributed.run" in r.stderr
+    assert '"metric"' not in r.stdout
