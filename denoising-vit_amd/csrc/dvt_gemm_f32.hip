@@ -43,6 +43,10 @@ struct GemmArgs {
   int relu;
   int kchunk;  // K range per blockIdx.z (multiple of BK)
   int atomic;  // accumulate into C with atomics
+  // gemm_f32_big_kernel only (the fp32 extractor's fused epilogues): 1 = exact-erf GELU of (acc + bias); 2 = residual,
+  // C[m][n] += gamma[n] * (acc + bias[n]) (timm Block: x = x + ls(f(norm(x))))
+  int epi;
+  const float* gamma;
 };
 
 // Operand tile of R rows x BK: R*BK/4 float4, spread over NT threads.  BK is a template
@@ -596,6 +600,7 @@ __device__ __forceinline__ float4 frag4_big(const float* __restrict__ S, int row
   return *reinterpret_cast<const float4*>(S + row * GB_BK + (((kh * (GB_BK / 8) + q) ^ ((row >> 1) & 7)) << 2));
 }
 
+template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * GB_STAGE_FLOATS];  // 64 KB, one LDS object
   const int tid = threadIdx.x, lane = tid & 63;
@@ -649,18 +654,28 @@ __global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmArgs p) {
 #undef GB_ISSUE
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): a half-wave stores one
   // 128-B row piece per instruction
+  // EPI (round 5, the fp32 extractor): the exact-erf GELU of fc1 and the LayerScale + residual of proj / fc2 happen HERE, on
+  // the accumulators, instead of in a separate pass that re-read and re-wrote the fp32 [tokens, 3072] / [tokens, 768] tensors
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int gn = n0 + wn * 64 + j * 32 + l31;
     const float bias = p.bias != nullptr ? p.bias[gn] : 0.f;
+    const float gm_n = EPI == 2 ? p.gamma[gn] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         float v = acc[i][j][r] + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.C[(size_t)gm * p.ldc + gn] = v;
+        float* c = p.C + (size_t)gm * p.ldc + gn;
+        if constexpr (EPI == 1) {
+          v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // nn.GELU(): exact erf form (as gelu_f32_kernel)
+        } else if constexpr (EPI == 2) {
+          v = *c + gm_n * v;  // (as resid_f32_kernel: o += g * v)
+        } else {
+          if (p.relu) v = fmaxf(v, 0.f);
+        }
+        *c = v;
       }
   }
 }
@@ -967,14 +982,31 @@ int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s) {
   return 0;
 }
 
-// Forward linear for LARGE m (the fp32 extractor: m = views x 1408 tokens): always the 3-stage LDS-DMA kernel
-// when the shape is eligible, whatever the co-residency knob of the fit says.
+// the 128 x 128 x 32 kernel takes this shape (and with it the fused GELU / residual epilogues below)
+bool dvt_linear_big_ok(int m, int n, int k) { return g_f32_big && m > 0 && m % 128 == 0 && n % 128 == 0 && k % GB_BK == 0; }
+
+// y = epi(x . w^T + b) on the 128 x 128 x 32 kernel ONLY (dvt_linear_big_ok): epi 1 = exact-erf GELU, epi 2 = y += gamma (.) (.)
+int dvt_linear_fwd_big_epi(const float* x, const float* w, const float* b, float* y, int m, int n, int k, int epi,
+                           const float* gamma, hipStream_t s) {
+  if (!x || !w || !y || !dvt_linear_big_ok(m, n, k) || (epi != 1 && epi != 2) || (epi == 2 && !gamma)) return DVT_E_BADARG;
+  GemmArgs a = make_fwd(x, w, b, y, m, n, k, 0);
+  a.epi = epi;
+  a.gamma = gamma;
+  DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+  if (epi == 1) hipLaunchKernelGGL(gemm_f32_big_kernel<1>, dim3(a.N / 128, a.M / 128), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gemm_f32_big_kernel<2>, dim3(a.N / 128, a.M / 128), dim3(256), 0, s, a);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Forward linear for LARGE m (the fp32 extractor: m = views x 1408 tokens): the 128 x 128 x 32 kernel where the shape is
+// eligible, else the 64 x 64 LDS-DMA kernel, whatever the co-residency knob of the fit says.
 int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s) {
   if (!x || !w || !y || m <= 0 || n <= 0 || k <= 0 || (k & 3) || (n & 3)) return DVT_E_BADARG;
   const GemmArgs a = make_fwd(x, w, b, y, m, n, k, 0);
-  if (g_f32_big && a.M % 128 == 0 && a.N % 128 == 0 && a.K % GB_BK == 0 && a.mask == nullptr && !a.atomic) {
+  if (dvt_linear_big_ok(m, n, k)) {
     DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
-    hipLaunchKernelGGL(gemm_f32_big_kernel, dim3(a.N / 128, a.M / 128), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_f32_big_kernel<0>, dim3(a.N / 128, a.M / 128), dim3(256), 0, s, a);
     DVT_CHECK_LAUNCH();
     return 0;
   }

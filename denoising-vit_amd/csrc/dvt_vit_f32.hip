@@ -21,6 +21,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
 
 int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s);
+bool dvt_linear_big_ok(int m, int n, int k);
+int dvt_linear_fwd_big_epi(const float* x, const float* w, const float* b, float* y, int m, int n, int k, int epi,
+                           const float* gamma, hipStream_t s);
 // bf16 GEMM kernels of dvt_vit.hip (fp32 accumulation), used by the bf16x3 mode below
 extern "C" int dvt_vit_gemm_f32out(const void* a, const void* w, const float* b, float* y, int m, int n, int k, void* stream);
 extern "C" int dvt_vit_gemm_residual(const void* a, const void* w, const float* b, const float* gamma, float* x, int m,
@@ -537,21 +540,33 @@ extern "C" int dvt_vit_forward_f32(const DvtVitConfig* c, const DvtVitWeights* w
     DVT_CHECK_LAUNCH();
     DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.qkv_w, bw.qkv_b, k.qkv, T, 3 * D, D, s));
     DVT_TRY(dvt_vit_attention_f32(k.qkv, k.ao, batch, c->heads, c->s_pad, c->n_tokens, s));
-    DVT_TRY(dvt_linear_fwd_big(k.ao, (const float*)bw.proj_w, bw.proj_b, k.tmp, T, D, D, s));
-    hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
-                       (const float4*)bw.ls1, nqD, D / 4);
-    DVT_CHECK_LAUNCH();
+    // round 5: where the 128 x 128 GEMM kernel takes the shapes, LayerScale + residual and the exact-erf GELU are its epilogues
+    // (three passes over fp32 [T, dim] / [T, mlp_dim] tensors per block less); otherwise the separate kernels as before
+    const bool fuse = dvt_linear_big_ok(T, D, D) && dvt_linear_big_ok(T, c->mlp_dim, D) && dvt_linear_big_ok(T, D, c->mlp_dim);
+    if (fuse) {
+      DVT_TRY(dvt_linear_fwd_big_epi(k.ao, (const float*)bw.proj_w, bw.proj_b, k.x, T, D, D, 2, bw.ls1, s));
+    } else {
+      DVT_TRY(dvt_linear_fwd_big(k.ao, (const float*)bw.proj_w, bw.proj_b, k.tmp, T, D, D, s));
+      hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
+                         (const float4*)bw.ls1, nqD, D / 4);
+      DVT_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(layernorm_f32_kernel<false>, dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm2_w,
                        bw.norm2_b, k.xn, T, D, c->ln_eps, 0, 0, 0);
     DVT_CHECK_LAUNCH();
-    DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, T, c->mlp_dim, D, s));
-    hipLaunchKernelGGL(gelu_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.hid,
-                       (long long)T * c->mlp_dim / 4);
-    DVT_CHECK_LAUNCH();
-    DVT_TRY(dvt_linear_fwd_big(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.tmp, T, D, c->mlp_dim, s));
-    hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
-                       (const float4*)bw.ls2, nqD, D / 4);
-    DVT_CHECK_LAUNCH();
+    if (fuse) {
+      DVT_TRY(dvt_linear_fwd_big_epi(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, T, c->mlp_dim, D, 1, nullptr, s));
+      DVT_TRY(dvt_linear_fwd_big_epi(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.x, T, D, c->mlp_dim, 2, bw.ls2, s));
+    } else {
+      DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, T, c->mlp_dim, D, s));
+      hipLaunchKernelGGL(gelu_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.hid,
+                         (long long)T * c->mlp_dim / 4);
+      DVT_CHECK_LAUNCH();
+      DVT_TRY(dvt_linear_fwd_big(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.tmp, T, D, c->mlp_dim, s));
+      hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
+                         (const float4*)bw.ls2, nqD, D / 4);
+      DVT_CHECK_LAUNCH();
+    }
   }
 #undef DVT_TRY
   const int out_rows = batch * (c->n_tokens - c->n_prefix);
