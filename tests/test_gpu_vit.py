@@ -545,6 +545,30 @@ def test_vit_large_launch_beyond_2p31_elements(L):
     assert cos.min() > 0.999, float(cos.min())
 
 
+def test_gemm_staggered_start_does_not_change_results(L):
+    """dvt_tune_set(1, -700 - pct): the first round of 8p workgroups starts spread over pct % of a tile time (a measured null,
+    profiles/r05/r05c_*; default off).  It only delays workgroups: the output must equal the default launch bit for bit, on a
+    launch of more than two rounds of tiles (below that the knob is not applied)."""
+    m, n, k = 256 * 72, 2304, 768  # 72 x 9 = 648 tiles
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = (torch.rand(m, k, device=DEV, generator=g) * 2 - 1).bfloat16()
+    w = ((torch.rand(n, k, device=DEV, generator=g) * 2 - 1) / k ** 0.5).bfloat16()
+    b = torch.randn(n, device=DEV, generator=g)
+    outs = {}
+    try:
+        for pct in (0, 100, 250):
+            assert L.dvt_tune_set(1, -700 - pct) == 0
+            y = torch.full((m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
+            assert L.dvt_vit_gemm_bias(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k, _s()) == 0
+            torch.cuda.synchronize()
+            outs[pct] = y
+    finally:
+        L.dvt_tune_set(1, -700)
+    assert bool(torch.isfinite(outs[0].float()).all())
+    for pct in (100, 250):
+        assert torch.equal(outs[pct].view(torch.int16), outs[0].view(torch.int16)), pct
+
+
 def test_product_library_rejects_lab_knobs(L):
     """the product library carries no superseded / experimental / timing kernel, and dvt_tune_set refuses every
     value that would have selected one (before: `dvt_tune_set(1, -301)` made a product entry point return wrong numbers with

@@ -217,3 +217,17 @@ def test_explicit_extract_bsz_bounds_the_launches():
     assert cap(["--extract_bsz", "64"]) == (64, 64)
     assert cap(["--extract_bsz", "1000"]) == (1000, 400)
     assert cap(["--extract_bsz", "16", "--extract_launch_views", "128"]) == (16, 128)
+
+
+def test_launch_views_planning_fp32_tiles():
+    """Round 5: the exact-fp32 extractor's GEMMs run 128 x 128 tiles on 512 workgroup slots (two per CU); its launches are
+    planned for THAT geometry below a cap of 160 views (8 GB of fp32 scratch for ViT-B): 769 views -> five launches whose
+    N = 768 GEMMs fill whole rounds (at the round-4 cap of 32 views they ran 4.1 -> 5 rounds, 18 % idle)."""
+    from dvt_amd.vit import plan_launches
+    plan = plan_launches(769, 160, 1408, 768, 3072, fp32=True)
+    assert sum(plan) == 769 and max(plan) <= 160 and len(plan) == 5, plan
+    for v in plan:  # proj / fc2: M tiles x 6 N tiles over 512 slots: the last round at least three quarters full
+        tiles = -(-v * 1408 // 128) * 6
+        assert (tiles % 512 == 0) or (tiles % 512) / 512 >= 0.2, (v, tiles % 512)
+    assert plan_launches(64, 160, 1408, 768, 3072, fp32=True) == [64]
+    assert plan_launches(769, 400) == [398, 371]  # the bf16 plan is untouched
