@@ -25,9 +25,11 @@ namespace {
 // to keep the fine levels' gradient lines cache-resident for the next step's atomics.
 // Measured: no effect on the grid backward (189.8 vs 189.4 us) and +30 us on Adam -> off.
 int g_adam_zero_all = 0;
+int g_adam_nt = 0;  // dvt_tune_set(3, 10 / 11): non-temporal p / m / v streams in the dense sweep off / on
 
 struct AdamKArgs {
   int zero_all;
+  int nt;  // stream p / m / v with the non-temporal hint (dvt_tune_set(3, 10 / 11))
   int reverse;  // sweep the chunks from the end: consecutive steps alternate, see dvt_adam_step_k
   float one_m_b1, beta2, one_m_b2, eps, wd;
   long long q_sparse_end;  // float4 index
@@ -82,6 +84,8 @@ struct AdamShadow {  // shadow copies (bf16 or fp32: L.f32) of the MLP weights, 
   void* sh[DVT_FIT_BATCH_MAX];
 };
 
+typedef float adam_f4 __attribute__((ext_vector_type(4)));  // (the non-temporal builtins take clang vectors, not HIP's float4)
+
 template <bool GATHER, bool SHADOW = false>
 __device__ __forceinline__ void adam_dense_body(const AdamKArgs& a, const AdamPtrs& q, const AdamGather& gr, int bx,
                                                 int nbx, int fit, const AdamShadow* shw = nullptr) {
@@ -113,7 +117,16 @@ __device__ __forceinline__ void adam_dense_body(const AdamKArgs& a, const AdamPt
       word = touched[q0 >> 6];
       has = (word >> (lane >> 1)) & 1u;
     }
-    float4 p = P[q], m = M[q], v = V[q];
+    float4 p, m, v;
+    if (a.nt) {  // (wave-uniform) every element of the dense part is read once and written once per step
+      p = __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(&P[q])));
+      m = __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(&M[q])));
+      v = __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(&V[q])));
+    } else {
+      p = P[q];
+      m = M[q];
+      v = V[q];
+    }
     const bool gathered = GATHER && q0 >= gr.q_begin && q0 < gr.q_end;  // wave-uniform: chunk inside G
     if (GATHER && gathered) {
       // dG[row] = sum of the d_pred rows of this step's samples on lattice row `row`
@@ -138,9 +151,15 @@ __device__ __forceinline__ void adam_dense_body(const AdamKArgs& a, const AdamPt
     adam1(p.y, m.y, v.y, g.y, a.wd, one_m_b1, a.beta2, one_m_b2, bc2s, a.eps, neg_step);
     adam1(p.z, m.z, v.z, g.z, a.wd, one_m_b1, a.beta2, one_m_b2, bc2s, a.eps, neg_step);
     adam1(p.w, m.w, v.w, g.w, a.wd, one_m_b1, a.beta2, one_m_b2, bc2s, a.eps, neg_step);
-    P[q] = p;
-    M[q] = m;
-    V[q] = v;
+    if (a.nt) {
+      __builtin_nontemporal_store(__builtin_bit_cast(adam_f4, p), reinterpret_cast<adam_f4*>(&P[q]));
+      __builtin_nontemporal_store(__builtin_bit_cast(adam_f4, m), reinterpret_cast<adam_f4*>(&M[q]));
+      __builtin_nontemporal_store(__builtin_bit_cast(adam_f4, v), reinterpret_cast<adam_f4*>(&V[q]));
+    } else {
+      P[q] = p;
+      M[q] = m;
+      V[q] = v;
+    }
     if constexpr (SHADOW) {  // wave-uniform: the chunk lies inside the shadowed matrices or not
       if (q0 * 4 >= shw->L.lo && q0 * 4 < shw->L.hi) dvt_shadow_store(shw->L, shw->sh[fit], q * 4, p);
     }
@@ -330,8 +349,9 @@ __global__ __launch_bounds__(256) void adam_dense_lazy_shadow_kernel(AdamKArgs a
 
 }  // namespace
 
-int dvt_adam_tune(int zero_all) {
-  g_adam_zero_all = zero_all;
+int dvt_adam_tune(int v) {
+  if (v == 10 || v == 11) g_adam_nt = v == 11;
+  else g_adam_zero_all = v;
   return 0;
 }
 
@@ -380,6 +400,7 @@ int dvt_adam_step_k(const DvtAdamArgs* h, int k, float* const* p, float* const* 
   }
   AdamKArgs a{};
   a.zero_all = g_adam_zero_all;
+  a.nt = g_adam_nt;
   // Direction of the sweep over the arena.  p + m + v (258 MB) is a hair larger than the 256-MB memory-side
   // cache: a forward sweep every step evicts each line just before it is needed again (LRU streaming
   // pathology, 0 % hits); alternating the direction lets a step START on the lines the previous step touched

@@ -307,7 +307,9 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * key 14 = fit step, bf16 operands: workgroup shape of fit_rows / fit_backward -- 0 (default) 8 / 16 waves, 1 = 4 / 8 waves (one /
  *          two waves per SIMD, the footprint one attention workgroup of the extractor leaves; same arithmetic, same results);
  * key 8 = Adam sweeps the arena in alternating directions on consecutive steps (1, default) or always forward (0);
- * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0). */
+ * key 3 = Adam zero-writes the whole sparse gradient region every step (1, default) or only touched entries (0);
+ *         10 (default) / 11 = the dense sweep's p / m / v streams without / with the non-temporal hint (round 5: measured
+ *         no effect on the pipelined rate; same results). */
 int dvt_tune_set(int key, int value);
 
 /* ------------------------------------------------------------------------------------
