@@ -1,8 +1,8 @@
 """The developer build of the library (csrc/lab/, -DDVT_LAB -> csrc/libdvt_hip_lab.so, `python tools/build_lab.py`) held to the
 same checks as the product kernels: superseded GEMM schedules (0, 2), the 8p re-schedules (5 "8m", 10 "8h": bit-identical),
 the 4-wave persistent GEMM (6..9), the round-2 attention loop and the other attention schedule masks.  The module's
-fixture builds that library on demand (`__graft_entry__.build()` builds the product library only, and nothing under
-denoising-vit_amd/dvt_amd loads the lab build); without a working hipcc these tests are skipped."""
+fixture (re)builds that library when it is missing or stale (`__graft_entry__.build()` builds it too, after the product
+library; nothing under denoising-vit_amd/dvt_amd loads it); without it and without a working hipcc these tests are skipped."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def L():
     import dvt_amd.vit  # noqa: F401 registers signatures
     from dvt_amd import _lib
-    try:  # built on demand (about a minute: the 4-wave kernel's ablation builds dominate); never by __graft_entry__.build()
+    try:  # (re)built when missing or stale: about a minute, the 4-wave kernel's ablation builds dominate
         _lib.build(lab=True)
     except Exception as exc:  # no hipcc on this box: the product suite does not depend on the developer library
         pytest.skip(f"developer library could not be built ({exc!r}); python tools/build_lab.py")
