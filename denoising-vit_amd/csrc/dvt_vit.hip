@@ -828,35 +828,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //        (both groups) have retired at the second barrier of phase p.
 //   RAW  a half-tile is read one phase after the phase whose L segment waited for it: the waits
 //        of both groups precede the second barrier of that phase.
-template <int MODE, int SM>  // 0 steady state, 1 tile nk-2 (no issue in P3/P4), 2 tile nk-1 (no issue)
+template <int MODE>  // 0 steady state, 1 tile nk-2 (no issue in P3/P4), 2 tile nk-1 (no issue)
 struct P8Wait;
-template <> struct P8Wait<0, 0> { static constexpr int w1 = 8, w2 = 8, w4 = 8; };
-template <> struct P8Wait<1, 0> { static constexpr int w1 = 8, w2 = 8, w4 = 4; };
-template <> struct P8Wait<2, 0> { static constexpr int w1 = 2, w2 = 0, w4 = -1; };
-#ifdef DVT_LAB
-// SM = 1 ("8m", lab build, dvt_tune_set(1, 5)): the half-tile of a phase is staged in the MIDDLE OF ITS MFMA SEGMENT instead of in the load
-// segment, i.e. AFTER the phase's counted wait instead of before it -- the same issue order, every wait one stage (2
-// instructions) tighter.  WAR: the slot is re-staged even later than before.  RAW: unchanged (the waits still precede the
-// second barrier of the phase before the one that reads).  SM = 2 "8h": see P8H_TILE.  SM = 3, 6..9: timing builds.
-template <> struct P8Wait<0, 1> { static constexpr int w1 = 6, w2 = 6, w4 = 6; };
-template <> struct P8Wait<1, 1> { static constexpr int w1 = 6, w2 = 6, w4 = 4; };
-template <> struct P8Wait<2, 1> { static constexpr int w1 = 2, w2 = 0, w4 = -1; };
-template <> struct P8Wait<0, 3> : P8Wait<0, 0> {};
-template <> struct P8Wait<1, 3> : P8Wait<1, 0> {};
-template <> struct P8Wait<2, 3> : P8Wait<2, 0> {};
-template <> struct P8Wait<0, 6> : P8Wait<0, 0> {};
-template <> struct P8Wait<1, 6> : P8Wait<1, 0> {};
-template <> struct P8Wait<2, 6> : P8Wait<2, 0> {};
-template <> struct P8Wait<0, 7> : P8Wait<0, 0> {};
-template <> struct P8Wait<1, 7> : P8Wait<1, 0> {};
-template <> struct P8Wait<2, 7> : P8Wait<2, 0> {};
-template <> struct P8Wait<0, 8> : P8Wait<0, 0> {};
-template <> struct P8Wait<1, 8> : P8Wait<1, 0> {};
-template <> struct P8Wait<2, 8> : P8Wait<2, 0> {};
-template <> struct P8Wait<0, 9> : P8Wait<0, 0> {};
-template <> struct P8Wait<1, 9> : P8Wait<1, 0> {};
-template <> struct P8Wait<2, 9> : P8Wait<2, 0> {};
-#endif
+template <> struct P8Wait<0> { static constexpr int w1 = 8, w2 = 8, w4 = 8; };
+template <> struct P8Wait<1> { static constexpr int w1 = 8, w2 = 8, w4 = 4; };
+template <> struct P8Wait<2> { static constexpr int w1 = 2, w2 = 0, w4 = -1; };
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -886,34 +862,13 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
 
-// the same 16 MFMAs with MID (a DMA stage, or nothing) between the two k-steps
-#define P8_MFMA2(IB, JB, AF, BF, MID)                                                             \
-  do {                                                                                            \
-    __builtin_amdgcn_s_setprio(1);                                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-        acc[IB + i][JB + j] =                                                                     \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][0], BF[j][0], acc[IB + i][JB + j], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    MID;                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-        acc[IB + i][JB + j] =                                                                     \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][1], BF[j][1], acc[IB + i][JB + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                \
-  } while (0)
-
 // 226-232 VGPRs (hipcc 7.2, per epilogue), not the 256 that two waves per SIMD would allow: 2 x 232 leaves 48
 // registers per SIMD, room for one wave of the fit's leanest streaming kernels beside the two GEMM waves; at 254
 // nothing else fitted and the HBM-bound fit could only time-slice whole CUs with the MFMA-bound extractor.
-// SM: 0 = the product schedule, the ONLY instantiation of the product library.  SM != 0 are the re-schedules (1 "8m", 2 "8h")
-// and timing builds (3 cycle stamps, 6..9 ablations with WRONG results) of lab builds: they must share this body to mean
-// anything, so they stay `if constexpr` branches here and are instantiated by launch_gemm under DVT_LAB only.
-template <int EPI, int SM = 0>
+// (The re-schedules "8m" / "8h" and the cycle-stamp / ablation builds of this body live in lab/dvt_vit_gemm8p_lab.inc, developer
+// library only.)
+template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
-  unsigned long long entry_t_ = 0;
-  if constexpr (SM >= 3) entry_t_ = __builtin_readcyclecounter();
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
   // De-synchronised start (dvt_tune_set(1, -700 - pct)).  A launch begins with one workgroup per CU, all tiles cost the same,
   // so the CUs walk through k-loop and epilogue in LOCK STEP for the whole launch: every ~26 us all 256 of them burst their
@@ -972,110 +927,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   P8_STAGE(srcA[1], 0, OFF_A1);
   P8_STAGE(srcA[0], 1, BUF + OFF_A0);
   P8_STAGE(srcB[0], 1, BUF + OFF_B0);
-  if constexpr (SM == 2) wait_vm<6>();  // (its first load segment reads B1 of tile 0 as well)
-  else wait_vm<8>();
+  wait_vm<8>();
   P8_BAR();
   if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on
 
   bf16x8 a[4][2], b0[2][2], b1[2][2];
-  // SM >= 6: ablation builds for tools/lab_gemm8p_stamps.py (timing only, results wrong): 6 = no LDS-DMA inside the k-loop, 7 = 6 +
-  // the ring parity frozen (compile-time fragment-read addresses), 8 = the kernel as it is (k-loop cycles only), 9 = no fragment reads
-  constexpr bool NO_DMA = SM == 6 || SM == 7, NO_PARITY = SM == 7, NO_READS = SM == 9;
-  if constexpr (NO_READS) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i][0] = a[i][1] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b0[j][0] = b0[j][1] = b1[j][0] = b1[j][1] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
-  }
-  // SM == 3, the timing build: s_memtime after each of the 8 barriers of k-tiles 4 and 5 (shader cycles; wave-uniform SGPRs)
-  unsigned st[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) st[i] = 0u;
-#define P8_STAMP(t, i)                                                              \
-  do {                                                                              \
-    if constexpr (SM == 3) {                                                        \
-      unsigned long long t64_;                                                      \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_)::"memory");   \
-      __builtin_amdgcn_sched_barrier(0);                                            \
-      const unsigned now_ = (unsigned)t64_;                                         \
-      st[i] = (t) == 4 ? now_ : st[i];                                              \
-      if ((i) == 0) st[13] = (t) == 5 ? now_ : st[13];                              \
-    }                                                                               \
-  } while (0)
 #define P8_TILE(MODE, t)                                                                          \
-  do {                                                                                            \
-    const int bo_ = NO_PARITY ? 0 : ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                             \
-    const char* base_ = smem + bo_;                                                               \
-    /* P1 */                                                                                      \
-    if (!NO_READS) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
-      b0[j][0] = P8_RD(base_ + OFF_B0 + j * 2048, ob0);                                           \
-      b0[j][1] = P8_RD(base_ + OFF_B0 + j * 2048, ob1);                                           \
-    }                                                                                             \
-    if (!NO_READS) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
-      a[i][0] = P8_RD(base_ + OFF_A0 + i * 2048, oa0);                                            \
-      a[i][1] = P8_RD(base_ + OFF_A0 + i * 2048, oa1);                                            \
-    }                                                                                             \
-    if (MODE == 0) P8_STAMP(t, 8);  /* (its lgkmcnt(0): the 12 fragment reads have COMPLETED) */   \
-    if (MODE <= 1 && SM != 1 && !NO_DMA) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                               \
-    if (MODE == 0) P8_STAMP(t, 9);                                                                \
-    if (!NO_DMA) wait_vm<P8Wait<MODE, SM>::w1>();                                                                  \
-    if (MODE == 0) P8_STAMP(t, 10);                                                               \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 0);                                                            \
-    P8_LGKM0();                                                                                   \
-    if constexpr (SM == 1 && MODE <= 1) P8_MFMA2(0, 0, a, b0, P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1)); \
-    else P8_MFMA(0, 0, a, b0);                                                                    \
-    if (MODE == 0) P8_STAMP(t, 11);  /* 16 MFMAs issued */                                         \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 1);                                                            \
-    /* P2 */                                                                                      \
-    if (!NO_READS) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
-      b1[j][0] = P8_RD(base_ + OFF_B1 + j * 2048, ob0);                                           \
-      b1[j][1] = P8_RD(base_ + OFF_B1 + j * 2048, ob1);                                           \
-    }                                                                                             \
-    if (MODE <= 1 && SM != 1 && !NO_DMA) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                               \
-    if (!NO_DMA) wait_vm<P8Wait<MODE, SM>::w2>();                                                                  \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 2);                                                            \
-    P8_LGKM0();                                                                                   \
-    if constexpr (SM == 1 && MODE <= 1) P8_MFMA2(0, 2, a, b1, P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1)); \
-    else P8_MFMA(0, 2, a, b1);                                                                    \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 3);                                                            \
-    /* P3 */                                                                                      \
-    if (!NO_READS) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
-      a[i][0] = P8_RD(base_ + OFF_A1 + i * 2048, oa0);                                            \
-      a[i][1] = P8_RD(base_ + OFF_A1 + i * 2048, oa1);                                            \
-    }                                                                                             \
-    if (MODE == 0 && SM != 1 && !NO_DMA) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                               \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 4);                                                            \
-    P8_LGKM0();                                                                                   \
-    if constexpr (SM == 1 && MODE == 0) P8_MFMA2(4, 2, a, b1, P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0)); \
-    else P8_MFMA(4, 2, a, b1);                                                                    \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 5);                                                            \
-    /* P4 */                                                                                      \
-    if (MODE == 0 && SM != 1 && !NO_DMA) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                               \
-    if (!NO_DMA) wait_vm<P8Wait<MODE, SM>::w4>();                                                                  \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 6);                                                            \
-    if constexpr (SM == 1 && MODE == 0) P8_MFMA2(4, 0, a, b0, P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0)); \
-    else P8_MFMA(4, 0, a, b0);                                                                    \
-    P8_BAR();                                                                                     \
-    if (MODE == 0) P8_STAMP(t, 7);                                                            \
-  } while (0)
-
-// SM == 2 ("8h", dvt_tune_set(1, 10)): the same ring and the same issue order on TWO phases per k-tile instead of
-// four -- X = {reads B0 B1 A0; stage B1(t+1) A1(t+1); wait [A1(t)]} 32 MFMAs (A0,B0) (A0,B1);  Y = {reads A1; stage A0(t+2)
-// B0(t+2); wait [B1(t+1) and older]} 32 MFMAs (A1,B1) (A1,B0) -- i.e. four barriers per k-tile and MFMA segments of 512 cycles.
-// Hazards as in the four-phase walk: a slot is re-staged a full phase (two barriers) or more after the load segments that read
-// it; a half-tile is read in the load segment after the one whose counted wait covered it.
-#define P8H_TILE(MODE, t)                                                                         \
   do {                                                                                            \
     const int bo_ = ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                                             \
     const char* base_ = smem + bo_;                                                               \
-    /* X */                                                                                       \
+    /* P1 */                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
       b0[j][0] = P8_RD(base_ + OFF_B0 + j * 2048, ob0);                                           \
       b0[j][1] = P8_RD(base_ + OFF_B0 + j * 2048, ob1);                                           \
@@ -1084,70 +945,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       a[i][0] = P8_RD(base_ + OFF_A0 + i * 2048, oa0);                                            \
       a[i][1] = P8_RD(base_ + OFF_A0 + i * 2048, oa1);                                            \
     }                                                                                             \
+    if (MODE <= 1) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                                      \
+    wait_vm<P8Wait<MODE>::w1>();                                                                  \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(0, 0, a, b0);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P2 */                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
       b1[j][0] = P8_RD(base_ + OFF_B1 + j * 2048, ob0);                                           \
       b1[j][1] = P8_RD(base_ + OFF_B1 + j * 2048, ob1);                                           \
     }                                                                                             \
-    if (MODE <= 1) {                                                                              \
-      P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                                                   \
-      P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                                                   \
-      wait_vm<8>();                                                                               \
-    } else {                                                                                      \
-      wait_vm<0>();                                                                               \
-    }                                                                                             \
+    if (MODE <= 1) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                                      \
+    wait_vm<P8Wait<MODE>::w2>();                                                                  \
     P8_BAR();                                                                                     \
     P8_LGKM0();                                                                                   \
-    P8_MFMA(0, 0, a, b0);                                                                         \
     P8_MFMA(0, 2, a, b1);                                                                         \
     P8_BAR();                                                                                     \
-    /* Y */                                                                                       \
+    /* P3 */                                                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
       a[i][0] = P8_RD(base_ + OFF_A1 + i * 2048, oa0);                                            \
       a[i][1] = P8_RD(base_ + OFF_A1 + i * 2048, oa1);                                            \
     }                                                                                             \
-    if (MODE == 0) {                                                                              \
-      P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                                                   \
-      P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                                                   \
-      wait_vm<6>();                                                                               \
-    } else if (MODE == 1) {                                                                       \
-      wait_vm<2>();                                                                               \
-    }                                                                                             \
+    if (MODE == 0) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                                      \
     P8_BAR();                                                                                     \
     P8_LGKM0();                                                                                   \
     P8_MFMA(4, 2, a, b1);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P4 */                                                                                      \
+    if (MODE == 0) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                                      \
+    wait_vm<P8Wait<MODE>::w4>();                                                                  \
+    P8_BAR();                                                                                     \
     P8_MFMA(4, 0, a, b0);                                                                         \
     P8_BAR();                                                                                     \
   } while (0)
 
-  unsigned long long loop_t0_ = 0;
-  if constexpr (SM >= 3) loop_t0_ = __builtin_readcyclecounter();
   int t = 0;
-  if constexpr (SM == 2) {
-    for (; t < nk - 2; ++t) P8H_TILE(0, t);
-    P8H_TILE(1, t);
-    ++t;
-    P8H_TILE(2, t);
-  } else {
-    for (; t < nk - 2; ++t) P8_TILE(0, t);
-    P8_TILE(1, t);
-    ++t;
-    P8_TILE(2, t);
-  }
-#undef P8H_TILE
+  for (; t < nk - 2; ++t) P8_TILE(0, t);
+  P8_TILE(1, t);
+  ++t;
+  P8_TILE(2, t);
 #undef P8_TILE
 #undef P8_STAGE
 #undef P8_RD
-#undef P8_STAMP
-  if constexpr (SM >= 3) {
-    const unsigned loop_cyc_ = (unsigned)(__builtin_readcyclecounter() - loop_t0_);
-    if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
-      unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 2 + wm) * 24;  // 24 u32 per (workgroup, wave group): 0..13 stamps, 16..21 below
-#pragma unroll
-      for (int i = 0; i < 14; ++i) d_[i] = st[i];
-      d_[20] = loop_cyc_;  // the whole k-loop of this tile (nk k-tiles)
-      d_[21] = (unsigned)nk;
-    }
-  }
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
   __syncthreads();        // operand buffers become epilogue space
   if constexpr (EPI == EPI_RESID) {
@@ -1159,17 +999,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
-  if constexpr (SM >= 3) {  // ticks from kernel entry to the last store issued AND retired
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned total_ = (unsigned)(__builtin_readcyclecounter() - entry_t_);
-    if (p.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
-      unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 2 + wm) * 24;
-      d_[19] = total_;
-      d_[18] = (unsigned)entry_t_;                                    // absolute tick of the kernel entry (low 32 bits)
-      d_[17] = __builtin_amdgcn_s_getreg((31 << 11) | 4);             // HW_REG_HW_ID: wave / simd / cu / sh / se
-      d_[16] = __builtin_amdgcn_s_getreg((31 << 11) | 20);            // HW_REG_XCC_ID
-    }
-  }
 }
 
 // (Rounds 3 / 4 built two persistent variants of this kernel -- "8q": register epilogue + tile loop, removed; "4w": four
@@ -1205,6 +1034,7 @@ __device__ __forceinline__ TileMap map_tile_id(int id, int mt, int nt, int group
 
 
 #include "lab/dvt_vit_gemm4w.inc"
+#include "lab/dvt_vit_gemm8p_lab.inc"
 #include "lab/dvt_vit_lab.inc"
 #endif
 
@@ -1307,21 +1137,21 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       if (g_vit_gemm_variant == 5 && g_vit_8p_build != 0) {
         a.dbg = g_vit_dbg;
         switch (g_vit_8p_build) {
-          case 3: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 3>), grid8, dim3(512), 0, s, a); break;
-          case 6: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 6>), grid8, dim3(512), 0, s, a); break;
-          case 7: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 7>), grid8, dim3(512), 0, s, a); break;
-          case 8: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 8>), grid8, dim3(512), 0, s, a); break;
-          default: hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 9>), grid8, dim3(512), 0, s, a); break;
+          case 3: hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 3>), grid8, dim3(512), 0, s, a); break;
+          case 6: hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 6>), grid8, dim3(512), 0, s, a); break;
+          case 7: hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 7>), grid8, dim3(512), 0, s, a); break;
+          case 8: hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 8>), grid8, dim3(512), 0, s, a); break;
+          default: hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 9>), grid8, dim3(512), 0, s, a); break;
         }
         lab_done = true;
       }
     }
     if (lab_done) {
     } else if (g_vit_gemm_variant == 10) {
-      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 2>), grid8, dim3(512), 0, s, a);
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 2>), grid8, dim3(512), 0, s, a);
       lab_done = true;
     } else if (g_vit_gemm_variant == 5) {
-      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 1>), grid8, dim3(512), 0, s, a);
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 1>), grid8, dim3(512), 0, s, a);
       lab_done = true;
     } else if (g_vit_gemm_variant == 0) {
       hipLaunchKernelGGL((gemm_bf16_kernel_sq<EPI>), grid8, dim3(512), 0, s, a);
@@ -1332,7 +1162,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       return 0;
     }
 #endif
-    hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, 0>), grid8, dim3(512), 0, s, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI>), grid8, dim3(512), 0, s, a);
     DVT_CHECK_LAUNCH();
     return 0;
   }

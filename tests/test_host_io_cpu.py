@@ -176,7 +176,7 @@ def test_pipe_timeline_tool_on_a_synthetic_trace(tmp_path, capsys):
         for launch in range(2):
             rows.append(("im2col_kernel(float const*)", t, t + 100, 64)); t += 100
             for blk in range(2):
-                rows.append(("void gemm_bf16_kernel_8p<1, 0>(GemmBArgs)", t, t + 2000, 512)); t += 2000
+                rows.append(("void gemm_bf16_kernel_8p<1>(GemmBArgs)", t, t + 2000, 512)); t += 2000
                 rows.append(("void attention_kernel_v2<15>(...)", t, t + 3000, 1024)); t += 3000
         if img == 0:
             t += 2000000  # the extractor waits once (2 ms)
