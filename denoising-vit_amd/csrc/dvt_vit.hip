@@ -193,6 +193,35 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaf(-0.5f * ax, e, fmaxf(x, 0.f));
 }
 
+// Two elements at a time on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: both halves are IEEE fma / mul, so every
+// result is bit-identical to gelu_erf).  The compiler packs the LayerNorm affine in front of it by itself but leaves the
+// polynomial scalar; written as 2-vectors it is 17 VALU issues per PAIR (2 v_and for |x| -- VOP3P has no abs modifier --, 13
+// packed, 2 v_rcp_f32) instead of 36.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_erf_pair(float& x0, float& x1) {
+  const f32x2_t ax = {fabsf(x0), fabsf(x1)};
+  const auto k = [](float c) { return (f32x2_t){c, c}; };
+  f32x2_t p = __builtin_elementwise_fma(ax, k(5.3829749049e-06f), k(4.8890637117e-05f));
+  p = __builtin_elementwise_fma(p, ax, k(3.8003574446e-05f));
+  p = __builtin_elementwise_fma(p, ax, k(3.2776263542e-03f));
+  p = __builtin_elementwise_fma(p, ax, k(2.1141005680e-02f));
+  p = __builtin_elementwise_fma(p, ax, k(4.9867346883e-02f));
+  p = __builtin_elementwise_fma(p, ax, k(1.0f));
+  p *= p;
+  p *= p;
+  p *= p;
+  p *= p;
+  const f32x2_t e = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+  // max(x, 0) = 0.5 x + 0.5 |x| EXACTLY (x + x or x - x, then an exact halving): one packed FMA with a neg modifier instead
+  // of two v_max_f32 per element (fmaxf canonicalises its operand first)
+  const f32x2_t xv = {x0, x1};
+  const f32x2_t mh = ax * k(-0.5f);
+  const f32x2_t pos = __builtin_elementwise_fma(xv, k(0.5f), -mh);
+  const f32x2_t r = __builtin_elementwise_fma(mh, e, pos);
+  x0 = r.x;
+  x1 = r.y;
+}
+
 // Fused epilogues.  acc[i][j][r] = C[m0 + wm*64 + i*16 + 4*(lane>>4) + r][n0 + wn*64 + j*16 + (lane&15)]
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4][4], int m0, int n0,
@@ -247,8 +276,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4
         }
       } else {
         if (IS_GELU(EPI)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          gelu_erf_pair(v[0], v[1]);
+          gelu_erf_pair(v[2], v[3]);
         }
         const int ldo = (IS_QKV(EPI)) ? 2 * p.dim : p.N;
         // pair adjacent columns across lanes (l, l^1): even lanes store rows r=0,1 of the
@@ -486,14 +515,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
         b.w = fmaf(rs, b.w - mu * cs1.w, bf1.w);
       }
       if (IS_GELU(EPI)) {
-        a.x = gelu_erf(a.x);
-        a.y = gelu_erf(a.y);
-        a.z = gelu_erf(a.z);
-        a.w = gelu_erf(a.w);
-        b.x = gelu_erf(b.x);
-        b.y = gelu_erf(b.y);
-        b.z = gelu_erf(b.z);
-        b.w = gelu_erf(b.w);
+        gelu_erf_pair(a.x, a.y);
+        gelu_erf_pair(a.z, a.w);
+        gelu_erf_pair(b.x, b.y);
+        gelu_erf_pair(b.z, b.w);
       }
       uint4 pk;
       pk.x = pack2(a.x, a.y);
