@@ -196,7 +196,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // Two elements at a time on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: both halves are IEEE fma / mul, so every
 // result is bit-identical to gelu_erf).  The compiler packs the LayerNorm affine in front of it by itself but leaves the
 // polynomial scalar; written as 2-vectors it is 17 VALU issues per PAIR (2 v_and for |x| -- VOP3P has no abs modifier --, 13
-// packed, 2 v_rcp_f32) instead of 36.
+// packed, 2 v_rcp_f32) instead of 30 (15 per element: fmaxf also canonicalises its operand).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_erf_pair(float& x0, float& x1) {
   const f32x2_t ax = {fabsf(x0), fabsf(x1)};
