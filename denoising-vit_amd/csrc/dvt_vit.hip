@@ -194,7 +194,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // Two elements at a time on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: both halves are IEEE fma / mul, so every
-// result is bit-identical to gelu_erf).  The compiler packs the LayerNorm affine in front of it by itself but leaves the
+// result is bit-identical to gelu_erf for non-denormal x).  The compiler packs the LayerNorm affine in front of it by itself but leaves the
 // polynomial scalar; written as 2-vectors it is 17 VALU issues per PAIR (2 v_and for |x| -- VOP3P has no abs modifier --, 13
 // packed, 2 v_rcp_f32) instead of 30 (15 per element: fmaxf also canonicalises its operand).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -212,8 +212,9 @@ __device__ __forceinline__ void gelu_erf_pair(float& x0, float& x1) {
   p *= p;
   p *= p;
   const f32x2_t e = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
-  // max(x, 0) = 0.5 x + 0.5 |x| EXACTLY (x + x or x - x, then an exact halving): one packed FMA with a neg modifier instead
-  // of two v_max_f32 per element (fmaxf canonicalises its operand first)
+  // max(x, 0) = 0.5 x + 0.5 |x| EXACTLY for every x whose half is representable (all normal numbers >= 2^-125, +-0, +inf;
+  // tests/test_kernel_math_cpu.py): one packed FMA with a neg modifier instead of two v_max_f32 per element (fmaxf
+  // canonicalises its operand first).  A denormal x may lose its last bit (<= 2^-149), far below the bf16 store.
   const f32x2_t xv = {x0, x1};
   const f32x2_t mh = ax * k(-0.5f);
   const f32x2_t pos = __builtin_elementwise_fma(xv, k(0.5f), -mh);

@@ -1,0 +1,68 @@
+"""CPU statements of two pieces of arithmetic the bf16 extractor's fc1 epilogue relies on (csrc/dvt_vit.hip, gelu_erf /
+gelu_erf_pair); the kernels themselves are held against the oracle by tests/test_gpu_vit.py.
+
+1. erf-GELU through Abramowitz-Stegun 7.1.28 with the powers of 1/sqrt(2) folded into the coefficients:
+   GELU(x) = max(x, 0) - 0.5 |x| (1 + c1 |x| + ... + c6 |x|^6)^-16  (timm Mlp's nn.GELU(): reference vit_wrapper.py:105-120
+   builds the timm model whose blocks call it).
+2. max(x, 0) = 0.5 x + 0.5 |x| in fp32 arithmetic -- what lets the packed-fp32 version replace two v_max_f32 per element by
+   one half of a v_pk_fma_f32 without changing a bit.
+"""
+import numpy as np
+from scipy.special import erfc
+
+# the literals of gelu_erf (highest power first)
+C = [5.3829749049e-06, 4.8890637117e-05, 3.8003574446e-05, 3.2776263542e-03, 2.1141005680e-02, 4.9867346883e-02]
+
+
+def gelu_as(x):
+    ax = np.abs(x)
+    p = np.float64(np.float32(C[0])) * ax + np.float64(np.float32(C[1]))
+    for c in C[2:]:
+        p = p * ax + np.float64(np.float32(c))
+    p = p * ax + 1.0
+    return np.maximum(x, 0.0) - 0.5 * ax * p ** -16.0
+
+
+def test_folded_coefficients_are_abramowitz_stegun_7_1_28():
+    a = [0.0705230784, 0.0422820123, 0.0092705272, 0.0001520143, 0.0002765672, 0.0000430638]  # A-S 7.1.28, a1..a6
+    folded = [a[k] / np.sqrt(2.0) ** (k + 1) for k in range(6)]
+    assert np.allclose(folded[::-1], C, rtol=2e-7, atol=0)
+
+
+def test_gelu_formula_error_is_far_below_the_bf16_rounding_of_its_output():
+    x = np.linspace(-12.0, 12.0, 2_400_001)
+    want = 0.5 * x * erfc(-x / np.sqrt(2.0))
+    err = np.abs(gelu_as(x) - want)
+    assert err.max() < 6e-7, err.max()               # 3e-7 on erfc x 0.5 |x| at |x| ~ 2..4
+    # against half an ulp of the bf16 value it is stored as: never more than 1 % of it wherever GELU is not ~ 0
+    big = np.abs(want) > 1e-3
+    assert (err[big] / (np.abs(want[big]) * 2.0 ** -9)).max() < 0.35
+    # saturation: beyond |x| ~ 27 the 16th power overflows fp32, v_rcp_f32(inf) = 0 and the result is max(x, 0) exactly
+    p = np.float32(1.0)
+    ax = np.float32(30.0)
+    with np.errstate(over="ignore"):
+        q = np.float32(C[0]) * ax + np.float32(C[1])
+        for c in C[2:]:
+            q = q * ax + np.float32(c)
+        q = q * ax + p
+        for _ in range(4):
+            q = q * q
+    assert np.isinf(q)
+
+
+def test_relu_as_a_half_sum_is_exact_for_every_normal_fp32():
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2 ** 32, size=4_000_000, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x) & (np.abs(x) >= np.float32(2.0 ** -125))]   # halves of these are representable
+    half = np.float32(0.5)
+    got = half * x + half * np.abs(x)
+    want = np.maximum(x, np.float32(0.0))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for v in (0.0, -0.0, np.inf):
+        v = np.float32(v)
+        assert (half * v + half * np.abs(v)).view(np.uint32) == np.maximum(v, np.float32(0.0)).view(np.uint32)
+    # the one place it is NOT exact: a denormal with an odd last bit loses that bit in the halving (2^-149 -> 0).
+    # fc1 pre-activations of that size do not occur, and the difference (<= 2^-149) is far below the bf16 rounding.
+    tiny = np.uint32(1).view(np.float32)
+    assert half * tiny + half * np.abs(tiny) != tiny
