@@ -49,12 +49,15 @@ def _pmc_traffic():
     try:
         with open(files[-1]) as fh:
             doc = json.load(fh)
-        return {k: v.get("bytes_per_launch") for k, v in doc.get("probes", {}).items()}, os.path.relpath(files[-1], ROOT)
+        return ({k: v.get("bytes_per_launch") for k, v in doc.get("probes", {}).items()}, os.path.relpath(files[-1], ROOT),
+                doc.get("extract_launch_views"))
     except Exception:
-        return {}, None
+        return {}, None, None
 
 
-PMC_TRAFFIC_BYTES_PER_LAUNCH, PMC_TRAFFIC_SOURCE = _pmc_traffic()
+# PMC_TRAFFIC_VIEWS: views of the ONE extractor launch the PMC passes profiled (the ViT kernels' bytes are proportional to the
+# views of a launch: the bench line scales them to the launches it actually made, 769 views -> 398 + 371)
+PMC_TRAFFIC_BYTES_PER_LAUNCH, PMC_TRAFFIC_SOURCE, PMC_TRAFFIC_VIEWS = _pmc_traffic()
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA
@@ -96,6 +99,8 @@ def parse():
                                                      "directory under /dev/shm, removed afterwards)")
     p.add_argument("--extract-launch-views", type=int, default=0,
                    help="cap on the views per extractor launch (0 = 400: 769 views -> 398 + 371)")
+    p.add_argument("--rendezvous-only", action="store_true",
+                   help="test hook: join the N-rank process group over gloo, run the timed bracket on no work, print one line")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="images in flight per GPU (1 = strictly serial reference flow)")
     return p.parse_args()
@@ -285,14 +290,63 @@ def stage2_leg(device, D):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` as a PLAIN command (the shape the round-end driver uses; the reference's own multi-GPU form is N
+    independent processes, sample_scripts/stage1.sh:8-20): with N > 1 and no torch.distributed.run environment the process
+    re-launches itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...`
+    (one rank per GPU, RCCL) and returns that job's exit code; rank 0 of the job prints the ONE JSON line.  It refuses only when
+    fewer than N devices are visible.  Returns None when there is nothing to do (N = 1, or already a rank of a job)."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    if not a.rendezvous_only:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < a.gpus:
+            print(f"bench.py: {a.gpus} GPUs requested, {n_dev} visible", file=sys.stderr, flush=True)
+            return 2
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(a, D):
+    """--rendezvous-only: the process-group half of an N-rank run and nothing else (no device, no library): every rank joins over
+    gloo, passes the bench's own timed bracket (barrier, MAX over ranks, the one gather) with a unit of no work, rank 0 prints
+    one JSON line.  What tests/test_sharding_gloo.py drives on the CPU-only build container to cover the self-launch path."""
+    import torch.distributed as tdist
+    rank, world, _ = D.env_ranks()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    cpu = torch.device("cpu")
+    D.init(cpu, world)
+    n, el, per_rank = D.timed(lambda: 1, cpu)
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "dist_world_size": tdist.get_world_size() if world > 1 else 1,
+                          "dist_backend": tdist.get_backend() if world > 1 else None,
+                          "per_rank": [{"rank": i, "units": int(r[0])} for i, r in enumerate(per_rank)]}), flush=True)
+    D.finish()
+
+
 def main():
     a = parse()
+    rc = self_launch(a)
+    if rc is not None:
+        sys.exit(rc)
     from dvt_amd import dist as D
+    if a.rendezvous_only:
+        return rendezvous_only(a, D)
     rank, world, local = D.env_ranks()
-    # `--gpus N` IS the world size: N = 1 runs standalone, N > 1 only under torch.distributed.run with N ranks
-    # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N), never silently on fewer
-    assert world == a.gpus, (f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run "
-                             f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {a.gpus}`")
+    # `--gpus N` IS the world size: inside a job (self-launched above, or started by torch.distributed.run) the ranks check it
+    assert world == a.gpus, (f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N > 1 as `python bench.py --gpus {a.gpus}` or `python -m "
+                             f"torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port P "
+                             f"bench.py --gpus {a.gpus}`")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     D.init(device, world)
@@ -442,7 +496,8 @@ def main():
             "value": world * a.steps / elapsed, "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            # the arithmetic of `value`: bf16 operands / fp32 accumulation in the ViT always; the fit's MLP GEMMs by --fit-dtype
+            "dtype": "bf16" if a.fit_dtype == "bfloat16" else "bf16 extractor + f32 fit MLP operands", "data": "synthetic",
             # self-verifying N: ranks of the torch.distributed process group that ran this line (None/1 = standalone)
             "dist_world_size": dist_world, "dist_backend": dist_backend,
             "config": {
@@ -492,6 +547,15 @@ def main():
             out["value_fp32_matmul_high"] = full_fp32["matmul_high"]["images_per_s"]
             out["config"]["value_fp32_detail"] = full_fp32
 
+        def traffic_of(n):
+            """PMC bytes per launch of probe `n`; the ViT kernels' bytes scaled from the profiled launch's views to the mean
+            views of this run's launches (their traffic is proportional to the views of a launch)."""
+            t = PMC_TRAFFIC_BYTES_PER_LAUNCH.get(n)
+            if t is None or n not in ("vit_gemm", "vit_attn") or not PMC_TRAFFIC_VIEWS:
+                return t
+            lv = launch_views if isinstance(launch_views, (list, tuple)) else [launch_views]
+            return t * (sum(lv) / len(lv)) / PMC_TRAFFIC_VIEWS
+
         def kernel_table(pr, images):
             kern = {}
             for n, p in pr.items():
@@ -507,7 +571,7 @@ def main():
                     kern[n] = {"bound": "mfma", "achieved": p["work"] / sec / 1e12, "peak": peak,
                                "unit": "TFLOP/s"}
                 kern[n].update(frac=kern[n]["achieved"] / kern[n]["peak"],
-                               traffic=PMC_TRAFFIC_BYTES_PER_LAUNCH.get(n),
+                               traffic=traffic_of(n),
                                launches=p["launches"], avg_us=1e3 * p["total_ms"] / p["launches"],
                                ms_per_image=p["total_ms"] / images,
                                # work = ALGORITHMIC flops / bytes (1370 tokens, K = 588 patch): frac follows from it

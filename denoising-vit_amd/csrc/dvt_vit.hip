@@ -1061,6 +1061,7 @@ __device__ __forceinline__ TileMap map_tile_id(int id, int mt, int nt, int group
 
 #include "lab/dvt_vit_gemm4w.inc"
 #include "lab/dvt_vit_gemm8p_lab.inc"
+#include "lab/dvt_vit_gemm8b.inc"
 #include "lab/dvt_vit_lab.inc"
 #endif
 
@@ -1109,7 +1110,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.group = g;
   }
   DvtProbeScope probe(DVT_PROBE_VIT_GEMM, s, a.work > 0.0 ? a.work : 2.0 * a.M * a.N * a.K);
-  bool sq = g_vit_gemm_variant >= 4;
+  bool sq = g_vit_gemm_variant >= 4;  // (lab: 5..12 are variants of the same tile)
 #ifdef DVT_LAB
   sq = sq || g_vit_gemm_variant == 0;
 #endif
@@ -1173,6 +1174,10 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       }
     }
     if (lab_done) {
+    } else if ((g_vit_gemm_variant == 11 || g_vit_gemm_variant == 12) && nk % 2 == 0) {  // "8b": balanced reads, literal parity
+      if (g_vit_gemm_variant == 11) hipLaunchKernelGGL((gemm_bf16_kernel_8b<EPI, 0>), grid8, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gemm_bf16_kernel_8b<EPI, 1>), grid8, dim3(512), 0, s, a);
+      lab_done = true;
     } else if (g_vit_gemm_variant == 10) {
       hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 2>), grid8, dim3(512), 0, s, a);
       lab_done = true;
@@ -1875,7 +1880,7 @@ int dvt_vit_tune(int v) {
     return 0;
   }
 #ifdef DVT_LAB
-  if (v < 0 || v > 10) return DVT_E_BADARG;
+  if (v < 0 || v > 12) return DVT_E_BADARG;
   g_vit_abl4w = g_vit_8p_build = 0;  // an ablation / timing build never survives a change of schedule
 #else
   if (v != 1 && v != 3 && v != 4) return DVT_E_BADARG;

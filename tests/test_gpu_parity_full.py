@@ -371,6 +371,65 @@ def test_end_to_end_chain(built_lib):
         assert c.min() >= 0.95, float(c.min())
 
 
+def test_chain_metric_configuration_vs_oracle_fixture(built_lib):
+    """The WHOLE chain at the metric's literal configuration (reference main_img_denoising.py:309-352) against
+    ONE committed oracle run (tests/golden/make_chain769_golden.py): the demo image -> 768 crops + the original (the stored
+    boxes, rendered by the HIP resampler) -> HIP ViT-B/14, 12 blocks, 518 x 518 -> the 769 x 1369 = 1 052 761-row feature
+    store -> 1000 HIP Adam steps (B = 2048, warm-up 100, L = 16 / 2^20) from the oracle's initial parameters on the oracle's
+    index stream -> `denoised_feats`.  Three product chains: bf16 extractor -> bf16-operand fit (the bench's `value`), bf16
+    extractor -> fp32-operand fit (`value_fp32_fit`), fp32 extractor -> fp32 fit (the reference's default `--dtype float32`,
+    `value_fp32`).  Bar: per-patch cosine mean >= 0.999, min >= 0.99 (north star: mean >= 0.99) -- next to the oracle's OWN
+    sensitivity on this input (its initial fit parameters perturbed by 1e-6: fixture `perturbed_cos`), printed."""
+    from dvt_amd import views as Vw
+    from tests.golden import make_chain769_golden as G
+    z = np.load(G.OUT)
+    V, T, WARM, B, C = (int(v) for v in z["meta"][:5])
+    assert (V, T, WARM, B, C) == (768, 1000, 100, 2048, 768)
+    _, img_u8 = _cat_image()
+    sd = G.vit_weights()
+    assert abs(G.checksum(sd.values()) - float(z["vit_checksum"])) <= 1e-6 * float(z["vit_checksum"]), \
+        "torch CPU generator differs from the build container's: the fixture's ViT weights are not reproducible here"
+    d_o, f_o = G.fresh_modules()
+    assert abs(G.checksum(list(d_o.parameters()) + list(f_o.parameters())) - float(z["init_checksum"])) \
+        <= 1e-6 * float(z["init_checksum"])
+    boxes = z["boxes"]
+    assert boxes.shape[0] == V + 1
+    coords = torch.stack([Vw.crop_coords(i, j, h, w, 518, 518, 37, 37, bool(fl)) for i, j, h, w, fl in boxes[:-1]]
+                         + [Vw.make_patch_coordinates(37, 37, 0.0, 1.0)]).to(DEV)
+    n_rows = (V + 1) * 37 * 37
+    idx = G.index_stream()
+    want = torch.from_numpy(z["denoised_f16"].astype(np.float32))
+    raw_o = torch.from_numpy(z["raw_orig_f16_sub"].astype(np.float32))
+    raw_0 = torch.from_numpy(z["raw_view0_f16_sub"].astype(np.float32))
+    tab = z["losses"]
+    res = {}
+    for ext, fits in (("bfloat16", ("bfloat16", "float32")), ("float32", ("float32",))):
+        _, feats = _hip_features(sd, img_u8, boxes, dtype=ext)
+        c_o = per_patch_cos(feats[-1, :, :, ::8].cpu(), raw_o)
+        c_0 = per_patch_cos(feats[0, :, :, ::8].cpu(), raw_0)
+        print(f"[chain769, {ext} extractor] raw features (every 8th channel) vs oracle fp32 ViT: original view cos mean "
+              f"{c_o.mean():.6f} min {c_o.min():.6f}; view 0 mean {c_0.mean():.6f} min {c_0.min():.6f}")
+        assert c_o.mean() > 0.999 and c_0.mean() > 0.999
+        for mode in fits:
+            eng = hip_engine_from(d_o, f_o, n_rows, T, WARM, mode)
+            eng.fit(feats.reshape(-1, C), coords.reshape(-1, 2), idx, log_every=1)
+            got = eng.infer(coords[-1]).cpu()
+            log = eng.loss_log()
+            del eng
+            cos = per_patch_cos(got, want)
+            res[(ext, mode)] = cos
+            rel = max(abs(log[s_]["loss"] - tab[s_, 0]) / abs(tab[s_, 0]) for s_ in (0, 1, 99, 100, 499, 500, 999))
+            print(f"[chain769, {ext} extractor -> {mode} fit] loss {log[0]['loss']:.4f} -> {log[T - 1]['loss']:.5f} (oracle "
+                  f"{tab[0, 0]:.4f} -> {tab[-1, 0]:.5f}; worst rel diff at steps 0/1/99/100/499/500/999: {rel:.2e}); "
+                  f"denoised_feats per-patch cosine mean {cos.mean():.6f} min {cos.min():.6f} (oracle vs its 1e-6-perturbed "
+                  f"self: {z['perturbed_cos'][0]:.6f} / {z['perturbed_cos'][1]:.6f})")
+            assert abs(log[0]["loss"] - tab[0, 0]) <= 2e-2 * abs(tab[0, 0])
+        del feats
+        torch.cuda.empty_cache()
+    for key, cos in res.items():
+        assert cos.mean() >= 0.999 and cos.min() >= 0.99, (key, float(cos.mean()), float(cos.min()))
+
+
 def test_cat_demo_golden(built_lib):
     """BASELINE configs[0] (demo/cat.jpg, plumbing): the committed CPU-oracle output vs the HIP chain."""
     from dvt_amd.vit import random_state_dict

@@ -53,6 +53,7 @@ views = sys.argv[3] if len(sys.argv) > 3 else "385"
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_target.py (ONE extractor launch of "
                  f"{views} views -- the bench runs 398 + 371 per image -- + 60 fit steps; DVT_PMC_ARGS={views} bash tools/gpu.sh pmc)",
        "formula": "(FETCH_SIZE x 2 + WRITE_SIZE) x 1024 B / dispatches",
+       "extract_launch_views": int(views),  # bench.py scales the ViT kernels' bytes to the views of ITS launches
        "probes": {k: {"bytes_per_launch": v["bytes"] / v["launches"], "launches": v["launches"]} for k, v in probes.items()},
        "kernels": kernels}
 open(dst, "w").write(json.dumps(doc, indent=1))
