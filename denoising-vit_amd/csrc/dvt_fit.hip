@@ -234,7 +234,9 @@ int check_bufs(const DvtFitConfig* c, const DvtFitBuffers* b, int step_begin, in
 // launch covers all k fits (blockIdx.y = fit; the grouped GEMM launch simply carries k x the
 // problems).  k = 1 is the reference's per-image loop.
 int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const Work* ws, int step,
-             int gs_local, uint32_t lazy_e0, const DvtAdamLazy* lazy_next, int lazy_target, hipStream_t s) {
+             int gs_local, uint32_t lazy_e0, const DvtAdamLazy* lazy_next, int lazy_target, bool fused, hipStream_t s) {
+  // fused: the row-kernel step -- decided ONCE per dvt_fit_run_batched call (which builds the weight shadow the row kernel
+  // reads), never re-read from the process-global knob between steps
   // gs_local: index of `step` inside the current chunk of sorted grid lists, or -1;  lazy_e0: first grid entry the lazy
   // Adam kernels own (0xffffffff: none, dense Adam steps everything);  lazy_next: run the catch-up of step + 1 (same
   // chunk of lists, relative step count lazy_target) inside this step's Adam launch
@@ -289,7 +291,6 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
   DvtLinearOp ops[4 * KM];  // <= 16 problems per grouped launch (MULTI_MAX)
   int n_ops;
   auto launch = [&]() { return dvt_linear_group(ops, n_ops, s, c->mlp_bf16); };
-  const bool fused = dvt_fit_fused_ok(c) && ws[0].shadow != nullptr && ws[0].g_offs != nullptr;
   DvtShadowLayout shl{};
   void* shadow[KM] = {nullptr, nullptr, nullptr, nullptr};
   DvtFusedFit ff[KM];
@@ -502,7 +503,11 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
       if (rc) return rc;
     }
   }
-  if (dvt_fit_fused_ok(c) && w[0].shadow != nullptr && w[0].g_offs != nullptr && step_end > step_begin) {
+  // Latched for the whole call: dvt_tune_set(6, .) is process-global and another thread / engine may flip it
+  // while these steps are being enqueued; a step that found it newly "on" would run the row kernel on a shadow that was
+  // never built (or is stale, since Adam keeps it current only while the step is fused).
+  const bool fused = dvt_fit_fused_ok(c) && w[0].shadow != nullptr && w[0].g_offs != nullptr;
+  if (fused && step_end > step_begin) {
     // the fp32 arena may have been (re)initialised by the caller: rebuild the bf16 shadow of the MLP
     // weights once; from here on the Adam kernel keeps it current
     DvtShadowLayout L;
@@ -608,7 +613,7 @@ extern "C" int dvt_fit_run_batched(const DvtFitConfig* c, int k, const DvtFitBuf
     const int rel_next = step + 1 - step_begin;
     merged_catchup = lazy && g_fit_lazy_merge && step + 1 < step_end && gs_local + 1 < GS_CHUNK &&
                      rel_next % g_fit_lazy_refresh != 0;
-    int rc = fit_step(c, k, bufs, w, step, gs_local, lazy_e0, merged_catchup ? &lz : nullptr, rel_next, (hipStream_t)stream);
+    int rc = fit_step(c, k, bufs, w, step, gs_local, lazy_e0, merged_catchup ? &lz : nullptr, rel_next, fused, (hipStream_t)stream);
     if (rc) return rc;
   }
   if (lazy) {  // the arena is exact at every call boundary: every lazy entry through the last step of this call

@@ -888,19 +888,42 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
 
-// 226-232 VGPRs (hipcc 7.2, per epilogue), not the 256 that two waves per SIMD would allow: 2 x 232 leaves 48
-// registers per SIMD, room for one wave of the fit's leanest streaming kernels beside the two GEMM waves; at 254
-// nothing else fitted and the HBM-bound fit could only time-slice whole CUs with the MFMA-bound extractor.
-// (The re-schedules "8m" / "8h" and the cycle-stamp / ablation builds of this body live in lab/dvt_vit_gemm8p_lab.inc, developer
-// library only.)
+// ---- round 6: the walk of the ring ("8b").  The table above is round 5's walk (12 / 4 / 8 / 0 fragment reads per phase, ring
+// parity a run-time value); it lives on in lab/dvt_vit_gemm8p_lab.inc as the developer library's schedule 13, bit-identical to
+// this one (tests/test_gpu_lab.py).  Round 4's per-barrier stamps (profiles/r04/r04w_*) showed seven of a k-tile's eight
+// half-phases at 325-345 cycles -- the partner group's 16 MFMAs + two barriers -- and the eighth, the load segment of P1, at
+// 570-590: it carried 12 of the k-tile's 24 ds_read_b128 (B0 and A0) behind the k-tile boundary's address arithmetic (VALU:
+// the parity offset of 12 read addresses and four 64-bit DMA source pointers), while P4's load segment read nothing.  Now:
+//   * the k-loop is unrolled by two, so the parity of every slot is a literal: fragment-read addresses are loop-invariant
+//     registers + instruction offsets, the DMA goes through two buffer descriptors (SGPRs) with one 32-bit lane offset per pass
+//     and the half / k-tile in the scalar offset -- no VALU instruction in any load segment;
+//   * B0 of k-tile t+1 is read in the load segment of P4(t), into the B registers that died with P3's MFMAs: the phases read
+//     8 / 4 / 8 / 4 fragments (A0 | B1 | A1 | B0'), and the two B register sets swap roles every k-tile (hence the unroll);
+//   * B0 is therefore needed one phase earlier: the stages are issued in the order B1(t+1) A1(t+1) B0(t+2) A0(t+2), one per
+//     phase, and EVERY phase waits vmcnt(8) (four stages in flight, as before).
+//   phase   ds_read (-> regs)    MFMA quadrant    LDS-DMA issued   s_waitcnt vmcnt(8) retires
+//   P1(t)   A0(t)                (A0, B0)         B1(t+1)          B1(t)
+//   P2(t)   B1(t)    -> bx       (A0, B1)         A1(t+1)          A1(t)
+//   P3(t)   A1(t)                (A1, B1)         B0(t+2)          B0(t+1)
+//   P4(t)   B0(t+1)  -> bx       (A1, B0)         A0(t+2)          A0(t+1)
+// Hazards: a slot is re-staged three phases after the phase that read it (round 5: two); a half-tile is read one phase after
+// the phase whose load segment waited for it; the waits of both groups precede the second barrier of that phase.
+// Measured (profiles/r06/r06b_*, 398 views, random operands, interleaved with round 5's walk): qkv -0.6 %, proj -0.7 %,
+// fc1 -1.7 %, fc2 (48 k-tiles: the k-loop itself) -3.4 %.  Issuing the stage inside the MFMA segment instead ("8m"
+// placement on this walk) LOSES 1-7 %.  K / 64 must be even (launch_gemm).
+template <int MODE>  // 0 steady state, 1 k-tile nk-2 (nothing to issue in P3 / P4), 2 k-tile nk-1 (nothing to issue)
+struct P8BWait;
+template <> struct P8BWait<0> { static constexpr int w1 = 8, w2 = 8, w3 = 8, w4 = 8; };
+template <> struct P8BWait<1> { static constexpr int w1 = 8, w2 = 8, w3 = 6, w4 = 4; };
+template <> struct P8BWait<2> { static constexpr int w1 = 2, w2 = 0, w3 = -1, w4 = -1; };
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
-  // De-synchronised start (dvt_tune_set(1, -700 - pct)).  A launch begins with one workgroup per CU, all tiles cost the same,
-  // so the CUs walk through k-loop and epilogue in LOCK STEP for the whole launch: every ~26 us all 256 of them burst their
-  // 128 KB of output at the memory system together (the chip's store rate, 5-6 TB/s: the bias epilogue's 5.6 us) and then
-  // nobody stores for 20 us.  The workgroups of the first round therefore wait a hash-spread fraction of one tile time
-  // (s_memrealtime, 100 MHz); every later workgroup inherits its CU's phase.  Results do not depend on it.
+  // De-synchronised start (dvt_tune_set(1, -700 - pct); round 5: null except proj, default off): the workgroups of the first
+  // round wait a hash-spread fraction of one tile time (s_memrealtime, 100 MHz).  Results do not depend on it.
   if (p.stagger_ticks > 0 && blockIdx.x < 256) {
     const unsigned h_ = ((unsigned)blockIdx.x * 2654435761u) >> 16;  // 16-bit hash of the block id
     const unsigned long long wait_ = ((unsigned long long)p.stagger_ticks * h_) >> 16;
@@ -919,99 +942,120 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / GBK;
-  // DMA sources: [half][pass]; one pass = 512 threads x 16 B = 64 rows of a half-tile
-  const bf16_t* srcA[2][2];
-  const bf16_t* srcB[2][2];
+  const int nk = p.K / GBK;  // even, >= 2 (launch_gemm checks)
+  // DMA sources through two buffer descriptors (SGPRs) based at the tile's A / W rows: per lane ONE 32-bit byte offset per
+  // pass (512 threads x 16 B = 64 rows of a half-tile), the half (h) and the k-tile in the scalar offset -- no 64-bit VALU
+  // address arithmetic in the load segments, 4 address registers instead of 16
+  int voA[2], voB[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int s_ = it * 512 + tid, r = s_ >> 3, c = (s_ & 7) ^ (r & 7);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      srcA[h][it] = p.A + (size_t)(m0 + (r >> 6) * 128 + h * 64 + (r & 63)) * p.lda + c * 8;
-      srcB[h][it] = p.W + (size_t)(n0 + (r >> 5) * 64 + h * 32 + (r & 31)) * p.ldw + c * 8;
-    }
+    voA[it] = (((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2;
+    voB[it] = (((r >> 5) * 64 + (r & 31)) * p.ldw + c * 8) * 2;
   }
+  const int hA = 64 * p.lda * 2, hB = 32 * p.ldw * 2;  // second half-tile: +64 A rows / +32 W rows
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
   constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
   char* const ldsw = smem + wave * 1024;
-#define P8_STAGE(SRC, kt, off)                                   \
-  do {                                                           \
-    glds16(SRC[0] + (size_t)(kt) * GBK, ldsw + (off));           \
-    glds16(SRC[1] + (size_t)(kt) * GBK, ldsw + (off) + 8192);    \
+// stage half H (0 / 1) of operand X (A / B) of k-tile kt into the slot at byte offset off
+#define P8_STAGE(X, H, kt, off)                                                                                          \
+  do {                                                                                                                   \
+    const int so_ = (kt) * (GBK * 2) + (H) * h##X;                                                                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs##X, (lds_ptr_t)(ldsw + (off)), 16, vo##X[0], so_, 0, 0);                 \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs##X, (lds_ptr_t)(ldsw + (off) + 8192), 16, vo##X[1], so_, 0, 0);          \
   } while (0)
-  // fragment read offsets inside a half-tile: row*128 + ((ks*4 + cg) ^ (row & 7))*16
   const int cg = lane >> 4;
   const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
   const int oa0 = ra * 128 + (((0 + cg) ^ (ra & 7)) << 4), oa1 = ra * 128 + (((4 + cg) ^ (ra & 7)) << 4);
   const int ob0 = rb * 128 + (((0 + cg) ^ (rb & 7)) << 4), ob1 = rb * 128 + (((4 + cg) ^ (rb & 7)) << 4);
+  // the same four offsets into the ring's second parity, as registers of their own (opaque to the compiler): ds_read's
+  // instruction offset is 16 bits, the ring 128 KB -- left alone hipcc forms one address register per READ of parity 1 (12)
+  int oa0q = oa0 + 65536, oa1q = oa1 + 65536, ob0q = ob0 + 65536, ob1q = ob1 + 65536;
+  asm volatile("" : "+v"(oa0q), "+v"(oa1q), "+v"(ob0q), "+v"(ob1q));
 #define P8_RD(base, off) (*reinterpret_cast<const bf16x8*>((base) + (off)))
 
-  // prologue: A0 B0 B1 A1 of tile 0, A0 B0 of tile 1 -- the order the steady state continues
-  P8_STAGE(srcA[0], 0, OFF_A0);
-  P8_STAGE(srcB[0], 0, OFF_B0);
-  P8_STAGE(srcB[1], 0, OFF_B1);
-  P8_STAGE(srcA[1], 0, OFF_A1);
-  P8_STAGE(srcA[0], 1, BUF + OFF_A0);
-  P8_STAGE(srcB[0], 1, BUF + OFF_B0);
-  wait_vm<8>();
+  // prologue: the whole k-tile 0 in the order it is needed, then what P3 / P4 of "k-tile -1" would have issued
+  P8_STAGE(B, 0, 0, OFF_B0);
+  P8_STAGE(A, 0, 0, OFF_A0);
+  P8_STAGE(B, 1, 0, OFF_B1);
+  P8_STAGE(A, 1, 0, OFF_A1);
+  P8_STAGE(B, 0, 1, BUF + OFF_B0);
+  P8_STAGE(A, 0, 1, BUF + OFF_A0);
+  wait_vm<8>();  // B0(0), A0(0) have landed
   P8_BAR();
   if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on
 
-  bf16x8 a[4][2], b0[2][2], b1[2][2];
-#define P8_TILE(MODE, t)                                                                          \
+  bf16x8 a[4][2], be[2][2], bo[2][2];
+  // "P4 of k-tile -1": B0(0) -> the even k-tiles' B0 registers
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    be[j][0] = P8_RD(smem + OFF_B0 + j * 2048, ob0);
+    be[j][1] = P8_RD(smem + OFF_B0 + j * 2048, ob1);
+  }
+
+// k-tile t of parity PAR (a literal); BC: the B registers that hold B0(t), BX: the other set
+#define P8B_TILE(MODE, PAR, t, BC, BX)                                                            \
   do {                                                                                            \
-    const int bo_ = ((t) & 1) * BUF, bn_ = bo_ ^ BUF;                                             \
-    const char* base_ = smem + bo_;                                                               \
+    constexpr int bo_ = (PAR) * BUF, bn_ = bo_ ^ BUF;                                             \
+    const int ra0_ = (PAR) ? oa0q : oa0, ra1_ = (PAR) ? oa1q : oa1;  /* this parity's A reads */   \
+    const int rb0_ = (PAR) ? ob0q : ob0, rb1_ = (PAR) ? ob1q : ob1;  /* ... B reads */             \
+    const int rn0_ = (PAR) ? ob0 : ob0q, rn1_ = (PAR) ? ob1 : ob1q;  /* the other parity's B0 */   \
     /* P1 */                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
-      b0[j][0] = P8_RD(base_ + OFF_B0 + j * 2048, ob0);                                           \
-      b0[j][1] = P8_RD(base_ + OFF_B0 + j * 2048, ob1);                                           \
-    }                                                                                             \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-      a[i][0] = P8_RD(base_ + OFF_A0 + i * 2048, oa0);                                            \
-      a[i][1] = P8_RD(base_ + OFF_A0 + i * 2048, oa1);                                            \
+      a[i][0] = P8_RD(smem + OFF_A0 + i * 2048, ra0_);                                            \
+      a[i][1] = P8_RD(smem + OFF_A0 + i * 2048, ra1_);                                            \
     }                                                                                             \
-    if (MODE <= 1) P8_STAGE(srcB[1], (t) + 1, bn_ + OFF_B1);                                      \
-    wait_vm<P8Wait<MODE>::w1>();                                                                  \
+    if (MODE <= 1) P8_STAGE(B, 1, (t) + 1, bn_ + OFF_B1);                                         \
+    wait_vm<P8BWait<MODE>::w1>();                                                                 \
     P8_BAR();                                                                                     \
     P8_LGKM0();                                                                                   \
-    P8_MFMA(0, 0, a, b0);                                                                         \
+    P8_MFMA(0, 0, a, BC);                                                                         \
     P8_BAR();                                                                                     \
     /* P2 */                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
-      b1[j][0] = P8_RD(base_ + OFF_B1 + j * 2048, ob0);                                           \
-      b1[j][1] = P8_RD(base_ + OFF_B1 + j * 2048, ob1);                                           \
+      BX[j][0] = P8_RD(smem + OFF_B1 + j * 2048, rb0_);                                           \
+      BX[j][1] = P8_RD(smem + OFF_B1 + j * 2048, rb1_);                                           \
     }                                                                                             \
-    if (MODE <= 1) P8_STAGE(srcA[1], (t) + 1, bn_ + OFF_A1);                                      \
-    wait_vm<P8Wait<MODE>::w2>();                                                                  \
+    if (MODE <= 1) P8_STAGE(A, 1, (t) + 1, bn_ + OFF_A1);                                         \
+    wait_vm<P8BWait<MODE>::w2>();                                                                 \
     P8_BAR();                                                                                     \
     P8_LGKM0();                                                                                   \
-    P8_MFMA(0, 2, a, b1);                                                                         \
+    P8_MFMA(0, 2, a, BX);                                                                         \
     P8_BAR();                                                                                     \
     /* P3 */                                                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-      a[i][0] = P8_RD(base_ + OFF_A1 + i * 2048, oa0);                                            \
-      a[i][1] = P8_RD(base_ + OFF_A1 + i * 2048, oa1);                                            \
+      a[i][0] = P8_RD(smem + OFF_A1 + i * 2048, ra0_);                                            \
+      a[i][1] = P8_RD(smem + OFF_A1 + i * 2048, ra1_);                                            \
     }                                                                                             \
-    if (MODE == 0) P8_STAGE(srcA[0], (t) + 2, bo_ + OFF_A0);                                      \
+    if (MODE == 0) P8_STAGE(B, 0, (t) + 2, bo_ + OFF_B0);                                         \
+    wait_vm<P8BWait<MODE>::w3>();                                                                 \
     P8_BAR();                                                                                     \
     P8_LGKM0();                                                                                   \
-    P8_MFMA(4, 2, a, b1);                                                                         \
+    P8_MFMA(4, 2, a, BX);                                                                         \
     P8_BAR();                                                                                     \
-    /* P4 */                                                                                      \
-    if (MODE == 0) P8_STAGE(srcB[0], (t) + 2, bo_ + OFF_B0);                                      \
-    wait_vm<P8Wait<MODE>::w4>();                                                                  \
+    /* P4: B0 of the NEXT k-tile -> BX (dead: P3's MFMAs have been issued) */                      \
+    if (MODE <= 1) {                                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+        BX[j][0] = P8_RD(smem + OFF_B0 + j * 2048, rn0_);                                         \
+        BX[j][1] = P8_RD(smem + OFF_B0 + j * 2048, rn1_);                                         \
+      }                                                                                           \
+    }                                                                                             \
+    if (MODE == 0) P8_STAGE(A, 0, (t) + 2, bo_ + OFF_A0);                                         \
+    wait_vm<P8BWait<MODE>::w4>();                                                                 \
     P8_BAR();                                                                                     \
-    P8_MFMA(4, 0, a, b0);                                                                         \
+    P8_MFMA(4, 0, a, BC);                                                                         \
     P8_BAR();                                                                                     \
   } while (0)
 
   int t = 0;
-  for (; t < nk - 2; ++t) P8_TILE(0, t);
-  P8_TILE(1, t);
-  ++t;
-  P8_TILE(2, t);
-#undef P8_TILE
+  for (; t < nk - 2; t += 2) {
+    P8B_TILE(0, 0, t, be, bo);
+    P8B_TILE(0, 1, t + 1, bo, be);
+  }
+  P8B_TILE(1, 0, t, be, bo);
+  P8B_TILE(2, 1, t + 1, bo, be);
+#undef P8B_TILE
 #undef P8_STAGE
 #undef P8_RD
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
@@ -1030,7 +1074,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (Rounds 3 / 4 built two persistent variants of this kernel -- "8q": register epilogue + tile loop, removed; "4w": four
 // waves, deferred epilogue, lab/dvt_vit_gemm4w.inc -- neither beat it: profiles/LOG.md 5 finding 3, profiles/r04/README.md.)
 #ifdef DVT_LAB
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(4))) GemmBArgs* kernarg_ptr_t;
 
 // tile of position `id` in the L2-aware order of map_tile (see there)
@@ -1061,7 +1104,6 @@ __device__ __forceinline__ TileMap map_tile_id(int id, int mt, int nt, int group
 
 #include "lab/dvt_vit_gemm4w.inc"
 #include "lab/dvt_vit_gemm8p_lab.inc"
-#include "lab/dvt_vit_gemm8b.inc"
 #include "lab/dvt_vit_lab.inc"
 #endif
 
@@ -1114,7 +1156,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
 #ifdef DVT_LAB
   sq = sq || g_vit_gemm_variant == 0;
 #endif
-  if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK && sq) {
+  if (a.M % 256 == 0 && a.N % 256 == 0 && a.dim_ok_sq && a.K >= 2 * GBK && (a.K / GBK) % 2 == 0 && sq) {  // (8p: k-tiles in pairs)
     const int nt = a.N / 256;
     // N tiles per group: W slices of a group stay L2-resident, but never fewer than 3 tiles share
     // an A panel (K = 3072: one tile per group re-read A three times from HBM, 1.03 -> 1.23 PF/s)
@@ -1174,9 +1216,8 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       }
     }
     if (lab_done) {
-    } else if ((g_vit_gemm_variant == 11 || g_vit_gemm_variant == 12) && nk % 2 == 0) {  // "8b": balanced reads, literal parity
-      if (g_vit_gemm_variant == 11) hipLaunchKernelGGL((gemm_bf16_kernel_8b<EPI, 0>), grid8, dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((gemm_bf16_kernel_8b<EPI, 1>), grid8, dim3(512), 0, s, a);
+    } else if (g_vit_gemm_variant == 13) {  // round 5's walk of the ring (12 / 4 / 8 / 0 reads, run-time parity)
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 0>), grid8, dim3(512), 0, s, a);
       lab_done = true;
     } else if (g_vit_gemm_variant == 10) {
       hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 2>), grid8, dim3(512), 0, s, a);
@@ -1880,7 +1921,7 @@ int dvt_vit_tune(int v) {
     return 0;
   }
 #ifdef DVT_LAB
-  if (v < 0 || v > 12) return DVT_E_BADARG;
+  if (v < 0 || v > 13 || v == 11 || v == 12) return DVT_E_BADARG;
   g_vit_abl4w = g_vit_8p_build = 0;  // an ablation / timing build never survives a change of schedule
 #else
   if (v != 1 && v != 3 && v != 4) return DVT_E_BADARG;

@@ -163,6 +163,16 @@ _SIGNATURES = {
 PROBES = {"adam": 0, "vit_gemm": 1, "vit_attn": 2, "fit_gemm": 3, "grid": 4, "fit_rows": 5}
 
 
+user_tune: dict[int, int] = {}  # dvt_tune_set keys a USER set through tune() (bench.py --tune, developer tools): drivers leave them alone
+
+
+def tune(key: int, value: int) -> None:
+    """dvt_tune_set on behalf of the user: recorded, so that code which flips a knob per mode (Stage1.fit_group: key 6) does
+    not silently override an explicit A/B setting."""
+    check(lib().dvt_tune_set(int(key), int(value)), f"dvt_tune_set({key},{value})")
+    user_tune[int(key)] = int(value)
+
+
 def prof_enable(names=()) -> None:
     mask = 0
     for n in names:

@@ -95,8 +95,9 @@ def get_args(argv=None):
                         "--synthetic).  Without it a missing checkpoint is an error, as in the reference.")
     p.add_argument("--fit_batch", type=int, default=0,
                    help="images fitted concurrently (BASELINE configs[2]): groups of 4 share every launch "
-                        "(dvt_fit_run_batched), further groups run on side streams; 1..16.  0 (default) = auto: 4 when the fit "
-                        "bounds the rate (--num_iters >= 4000: 0.58 instead of 0.46 images/s at 20000 iterations), else 1")
+                        "(dvt_fit_run_batched), further groups run on side streams; 1..16.  0 (default) = auto: 4 (round 6: +0.9 .. "
+                        "1.8 % images/s at 1000 iterations; 0.58 instead of 0.46 images/s at 20000) -- each image in flight "
+                        "holds its views + feature store (5.7 GB at ViT-B/14, 769 views); 1 = the reference's one fit at a time")
     args = p.parse_args(argv)
     if isinstance(args.input_size, int):
         args.input_size = (args.input_size, args.input_size)
@@ -279,7 +280,8 @@ class Stage1:
         order (numpy RNG) -- the draws of the reference's sequential loop."""
         engines = self.engines[:len(group)]
         C = self.feat_dim
-        if engines[0].s.mlp_dtype == "float32" and self.depth > 1:
+        auto_fused = engines[0].s.mlp_dtype == "float32" and self.depth > 1 and 6 not in _lib.user_tune
+        if auto_fused:
             # fp32-operand fit beside a running extractor: the fused row kernel (round 5: 3 launches per step, 157 KB of LDS
             # per workgroup) against the layer-by-layer launches (10 per step, 17 KB each) -- alone they take the same 200 us
             # per step.  Beside the bf16 extractor (one 136-KB GEMM workgroup per CU) either waits for whole CUs and fewer
@@ -293,7 +295,10 @@ class Stage1:
             fit_many(engines, [sl.features.view(-1, C) for sl in group],
                      [sl.coords.view(-1, 2) for sl in group], idxs, log_every=log_every)
         finally:
-            _lib.lib().dvt_tune_set(6, 3)  # (the launches are enqueued: the library's default for whoever comes next)
+            # (the launches are enqueued and the library latches the choice per dvt_fit_run_batched call: back to the library's
+            # default for whoever comes next -- only where THIS method changed it; a user's `--tune 6=.` is never touched)
+            if auto_fused:
+                _lib.lib().dvt_tune_set(6, 3)
         for e, sl in zip(engines, group):
             sl.range_flag = e.range_flag  # travels with the image; the engine moves on to the next one
         return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
@@ -462,8 +467,8 @@ def main(args, rank: int = 0, world: int = 1, stage_factory=None, device=None):
     names = names[lo:hi]
     if stage_factory is None:
         fb = int(getattr(args, "fit_batch", 0) or 0)
-        if fb <= 0:  # auto: concurrent fits pay when the fit, not the extractor, bounds an image (INTEGRATION)
-            fb = 4 if int(args.num_iters) >= 4000 else 1
+        if fb <= 0:  # auto (round 6): shared fit launches pay at every schedule measured, most where the fit bounds an image
+            fb = 4
         st = Stage1(args, device, fit_batch=fb)
     else:
         st = stage_factory(args, device)

@@ -26,13 +26,13 @@ def L():
     return h
 
 
-@pytest.mark.parametrize("variant", [0, 2, 5, 10])
+@pytest.mark.parametrize("variant", [0, 2, 5, 10, 13])
 @pytest.mark.parametrize("m,n,k", V.RESID_SHAPES)
 def test_lab_gemm_residual_vs_torch(L, m, n, k, variant):
     V.check_gemm_residual_vs_torch(L, m, n, k, variant)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 5, 6, 7, 10])
+@pytest.mark.parametrize("variant", [0, 2, 5, 6, 7, 10, 13])
 def test_lab_gemm_bias_variants(L, variant):
     V.check_gemm_bias_variants(L, variant)
 
@@ -68,10 +68,12 @@ def test_lab_ablation_state_is_reset_by_a_schedule_change(L):
         L.dvt_tune_set(1, -300)
 
 
-@pytest.mark.parametrize("variant", [5, 10, 11, 12])
+@pytest.mark.parametrize("variant", [5, 10, 13])
 @pytest.mark.parametrize("n,k,gelu", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 0)])
 def test_gemm_8m_8h_bit_identical_to_8p(L, n, k, gelu, variant):
-    """Two re-schedules of the 8p ring: dvt_tune_set(1, 5) stages every half-tile in the middle of its phase's MFMA segment
+    """The walks of the 8p ring.  Schedule 4 -- the product's -- is since round 6 the "8b" walk (fragment reads balanced
+    8 / 4 / 8 / 4 over the phases, B0 of the next k-tile prefetched in P4, literal ring parity, buffer-descriptor DMA);
+    dvt_tune_set(1, 13) is round 5's walk (12 / 4 / 8 / 0 reads, run-time parity), and two re-schedules of THAT one: dvt_tune_set(1, 5) stages every half-tile in the middle of its phase's MFMA segment
     (after the phase's counted wait instead of before it; waits one stage tighter); dvt_tune_set(1, 10) walks a k-tile in two
     phases of 32 MFMAs instead of four of 16 (half the barriers, its own counted waits).  Same MFMAs in the same k order on
     the same operands, so the output must equal the 8p kernel's BIT FOR BIT -- at a size that keeps every CU busy for many

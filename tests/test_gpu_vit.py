@@ -575,7 +575,7 @@ def test_product_library_rejects_lab_knobs(L):
     rc 0).  What it accepts are the schedules the tests above hold against the references."""
     BADARG = -1
     assert L.dvt_vit_is_lab_build() == 0
-    for v in (0, 2, 5, 6, 7, 8, 9, 10, 11,           # superseded / experimental GEMM schedules
+    for v in (0, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13,   # superseded / experimental GEMM schedules
               -200, -203, -300, -301, -303, -309,     # 4w tiles per workgroup, ablation masks / timing builds
               -364, -399, -400, -410, -499,           # retired 8q values
               -500, -501, -503, -510, -511, -589,     # round-2 attention loop, other schedule masks
