@@ -358,14 +358,19 @@ constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;  // 17408 B x 8 waves = 136 KB <= 
 template <int NI>
 __device__ __forceinline__ void ln_fold(const GemmBArgs& p, f32x4 (&acc)[NI][4], int mrow0, int ncol0, int lane);
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&acc)[4][4], int m0,
+// NI: 16-row blocks per call (4: a wave's 64 x 64 block, 17 KB of LDS; 2: 32 x 64, 8.5 KB -- the persistent kernel's passes,
+// which leave half of the ring to the next tile's operands); `blk0` overrides the wave's LDS block (default: smem + wave *
+// EP_WAVE_BYTES)
+template <int EPI, int NI = 4>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&acc)[NI][4], int m0,
                                                   int n0, int wm, int wn, int wave, int lane,
-                                                  char* smem) {
+                                                  char* smem, char* blk0 = nullptr) {
+  static_assert(NI == 4 || NI == 2, "64- or 32-row passes");
+  constexpr int ROWS = NI * 16;
   const int g = lane >> 4, lc = lane & 15;
   // LayerNorm folded into this GEMM (see ln_fold): the accumulators are x . W'^T of the UN-normalised rows
   const bool ln = (IS_QKV(EPI) || IS_GELU(EPI)) && p.ln_stats != nullptr;
-  float* blk = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
+  float* blk = reinterpret_cast<float*>(blk0 != nullptr ? blk0 : smem + wave * EP_WAVE_BYTES);
   const int nb = n0 + wn * 64;
   if (IS_QKV(EPI) && n0 >= 2 * p.dim) {
     // V tiles: vt[b][h][d][s] wants the TOKENS contiguous.  Round 5: the block goes through LDS transposed -- image
@@ -375,25 +380,27 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     // store instructions per block on 32-B segments) behind 32 scattered (mean, rstd) loads: a V tile's epilogue took ~15 us
     // against 3.6 us for a q / k tile, i.e. the qkv GEMM paid +4 us per tile on average (profiles/r05/README.md).
     const int mbv = m0 + wm * 64;
-    const int tc = lane & 7, dl = lane >> 3;  // 8-token chunk of the block, feature within a pass of 8
+    // NI = 4: 8 chunks of 8 tokens x 8 features per pass, 8 passes; NI = 2: 4 chunks x 16 features, 4 passes
+    constexpr int TCH = ROWS / 8, FPP = 64 / TCH, NPASS = 64 / FPP;
+    const int tc = lane & (TCH - 1), dl = lane / TCH;  // 8-token chunk of the block, feature within a pass
     // folded LayerNorm: (mean, rstd) of this lane's 8 tokens -- 64 B per lane, coalesced, requested before the LDS traffic
     float4 stq[4];
-    float csd[8], bfd[8];  // ... and the column sums / biases of its 8 features (one per pass)
+    float csd[NPASS], bfd[NPASS];  // ... and the column sums / biases of its features (one per pass)
     if (ln) {
       const float4* sp = reinterpret_cast<const float4*>(p.ln_stats + mbv + tc * 8);
 #pragma unroll
       for (int q = 0; q < 4; ++q) stq[q] = sp[q];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        csd[it] = p.ln_cs[nb + it * 8 + dl];
-        bfd[it] = p.bias[nb + it * 8 + dl];
+      for (int it = 0; it < NPASS; ++it) {
+        csd[it] = p.ln_cs[nb + it * FPP + dl];
+        bfd[it] = p.bias[nb + it * FPP + dl];
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float bias = (p.bias != nullptr && !ln) ? p.bias[nb + j * 16 + lc] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const float4 t4 = make_float4(acc[i][j][0] + bias, acc[i][j][1] + bias, acc[i][j][2] + bias, acc[i][j][3] + bias);
         *reinterpret_cast<float4*>(blk + (j * 16 + lc) * EP_LD + i * 16 + 4 * g) = t4;
       }
@@ -403,8 +410,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     const int bimg = mbv / p.s_pad, s0 = mbv - bimg * p.s_pad + tc * 8;
     bf16_t* const vrow = p.vt + ((size_t)(bimg * p.heads + hh) * 64) * p.s_pad + s0;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int d = it * 8 + dl;
+    for (int it = 0; it < NPASS; ++it) {
+      const int d = it * FPP + dl;
       const float4 a = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8);
       const float4 b = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8 + 4);
       float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -433,7 +440,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   // columns of the LDS block with the accumulators (as 32 loads per lane at the top of the epilogue they cost a full
   // memory latency per tile)
   float2 st_row = make_float2(0.f, 0.f);
-  if (ln) st_row = p.ln_stats[m0 + wm * 64 + lane];
+  if (ln && lane < ROWS) st_row = p.ln_stats[m0 + wm * 64 + lane];
   // ... and so are the folded LayerNorm's column sums / biases of the lane's 8 output columns (round 5; before, they were
   // requested after the LDS round trip, right in front of the loop that needs them.  Same-box A/B: no difference -- the other
   // waves of the CU cover that latency -- kept here because it is the natural place)
@@ -449,11 +456,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   for (int j = 0; j < 4; ++j) {
     const float bias = (p.bias != nullptr && !ln) ? p.bias[nb + j * 16 + lc] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) blk[(i * 16 + 4 * g + r) * EP_LD + j * 16 + lc] = acc[i][j][r] + bias;
   }
-  if (ln) *reinterpret_cast<float2*>(blk + lane * EP_LD + 64) = st_row;
+  if (ln && lane < ROWS) *reinterpret_cast<float2*>(blk + lane * EP_LD + 64) = st_row;
   // each wave only re-reads its own block: no workgroup barrier needed, only LDS completion
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int mb = m0 + wm * 64;
@@ -462,7 +469,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
     if (EPI == EPI_RESID) gm = *reinterpret_cast<const float4*>(p.gamma + nb + c4);
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < ROWS / 4; ++it) {
       const int row = it * 4 + g;
       const float4 v = *reinterpret_cast<const float4*>(blk + row * EP_LD + c4);
       const int t = mb + row;
@@ -499,7 +506,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     // (GELU: one row at a time -- four rows of erf polynomials in flight took the fc1 kernel to 254 VGPRs,
     // and at 2 x 256 registers per SIMD no wave of the fit's streaming kernels can share the CU)
 #pragma unroll(IS_GELU(EPI) ? 1 : 4)
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < ROWS / 8; ++it) {
       const int row = it * 8 + (lane >> 3);
       float4 a = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8);
       float4 b = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8 + 4);
@@ -911,13 +918,109 @@ __device__ __forceinline__ void wait_vm() {
 // Measured (profiles/r06/r06b_*, 398 views, random operands, interleaved with round 5's walk): qkv -0.6 %, proj -0.7 %,
 // fc1 -1.7 %, fc2 (48 k-tiles: the k-loop itself) -3.4 %.  Issuing the stage inside the MFMA segment instead ("8m"
 // placement on this walk) LOSES 1-7 %.  K / 64 must be even (launch_gemm).
-template <int MODE>  // 0 steady state, 1 k-tile nk-2 (nothing to issue in P3 / P4), 2 k-tile nk-1 (nothing to issue)
+// MODE of a k-tile: 0 steady state; 1 k-tile nk-2 (nothing to issue in P3 / P4); 2 k-tile nk-1 (nothing to issue).  The
+// persistent kernel (gemm_bf16_kernel_8t) adds 3 = k-tile 0 of a tile whose k-tile 0 was staged under the previous tile
+// (P1 / P2 need no wait) and 4 = k-tile nk-1 staging k-tile 0 of the NEXT tile, one half-tile per phase (rsAn / rsBn).
+template <int MODE>
 struct P8BWait;
 template <> struct P8BWait<0> { static constexpr int w1 = 8, w2 = 8, w3 = 8, w4 = 8; };
 template <> struct P8BWait<1> { static constexpr int w1 = 8, w2 = 8, w3 = 6, w4 = 4; };
 template <> struct P8BWait<2> { static constexpr int w1 = 2, w2 = 0, w3 = -1, w4 = -1; };
+template <> struct P8BWait<3> { static constexpr int w1 = -1, w2 = -1, w3 = 8, w4 = 8; };
+template <> struct P8BWait<4> { static constexpr int w1 = 4, w2 = 4, w3 = -1, w4 = -1; };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Per-lane constants of the 8p / 8t k-loop (declares locals in the caller's scope): the DMA goes through two buffer
+// descriptors (SGPRs) based at the tile's A / W rows -- per lane ONE 32-bit byte offset per pass (512 threads x 16 B = 64
+// rows of a half-tile), the half (h) and the k-tile in the scalar offset: no 64-bit VALU address arithmetic in the load
+// segments, 4 address registers instead of 16.  Fragment read offsets inside a half-tile: row*128 + ((ks*4 + cg) ^ (row & 7))*16;
+// the same four offsets into the ring's second parity are registers of their own (opaque to the compiler): ds_read's
+// instruction offset is 16 bits, the ring 128 KB -- left alone hipcc forms one address register per READ of parity 1 (12).
+#define P8_LANE_SETUP()                                                                                                  \
+  int voA[2], voB[2];                                                                                                    \
+  _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                                     \
+    const int s_ = it * 512 + tid, r = s_ >> 3, c = (s_ & 7) ^ (r & 7);                                                  \
+    voA[it] = (((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2;                                                         \
+    voB[it] = (((r >> 5) * 64 + (r & 31)) * p.ldw + c * 8) * 2;                                                          \
+  }                                                                                                                      \
+  const int hA = 64 * p.lda * 2, hB = 32 * p.ldw * 2; /* second half-tile: +64 A rows / +32 W rows */                    \
+  constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;                                 \
+  char* const ldsw = smem + wave * 1024;                                                                                 \
+  const int cg = lane >> 4;                                                                                              \
+  const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);                                                      \
+  const int oa0 = ra * 128 + (((0 + cg) ^ (ra & 7)) << 4), oa1 = ra * 128 + (((4 + cg) ^ (ra & 7)) << 4);                \
+  const int ob0 = rb * 128 + (((0 + cg) ^ (rb & 7)) << 4), ob1 = rb * 128 + (((4 + cg) ^ (rb & 7)) << 4);                \
+  int oa0q = oa0 + 65536, oa1q = oa1 + 65536, ob0q = ob0 + 65536, ob1q = ob1 + 65536;                                    \
+  asm volatile("" : "+v"(oa0q), "+v"(oa1q), "+v"(ob0q), "+v"(ob1q))
+#define P8_RSRC(ptr, len) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (len), 0x00020000)
+// stage half H (0 / 1) of operand X (A / B) of k-tile kt through descriptor RS into the slot at byte offset off
+#define P8_STAGE_RS(RS, X, H, kt, off)                                                                                   \
+  do {                                                                                                                   \
+    const int so_ = (kt) * (GBK * 2) + (H) * h##X;                                                                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, vo##X[0], so_, 0, 0);                    \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, vo##X[1], so_, 0, 0);             \
+  } while (0)
+#define P8_STAGE(X, H, kt, off) P8_STAGE_RS(rs##X, X, H, kt, off)
+#define P8_RD(base, off) (*reinterpret_cast<const bf16x8*>((base) + (off)))
+// k-tile t of parity PAR (a literal); BC: the B registers that hold B0(t), BX: the other set
+#define P8B_TILE(MODE, PAR, t, BC, BX)                                                            \
+  do {                                                                                            \
+    constexpr int bo_ = (PAR) * BUF, bn_ = bo_ ^ BUF;                                             \
+    constexpr bool st12_ = MODE == 0 || MODE == 1 || MODE == 3, st34_ = MODE == 0 || MODE == 3;   \
+    const int ra0_ = (PAR) ? oa0q : oa0, ra1_ = (PAR) ? oa1q : oa1;  /* this parity's A reads */   \
+    const int rb0_ = (PAR) ? ob0q : ob0, rb1_ = (PAR) ? ob1q : ob1;  /* ... B reads */             \
+    const int rn0_ = (PAR) ? ob0 : ob0q, rn1_ = (PAR) ? ob1 : ob1q;  /* the other parity's B0 */   \
+    /* P1 */                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      a[i][0] = P8_RD(smem + OFF_A0 + i * 2048, ra0_);                                            \
+      a[i][1] = P8_RD(smem + OFF_A0 + i * 2048, ra1_);                                            \
+    }                                                                                             \
+    if (st12_) P8_STAGE(B, 1, (t) + 1, bn_ + OFF_B1);                                             \
+    if (MODE == 4) P8_STAGE_RS(rsBn, B, 0, 0, OFF_B0);                                            \
+    wait_vm<P8BWait<MODE>::w1>();                                                                 \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(0, 0, a, BC);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P2 */                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+      BX[j][0] = P8_RD(smem + OFF_B1 + j * 2048, rb0_);                                           \
+      BX[j][1] = P8_RD(smem + OFF_B1 + j * 2048, rb1_);                                           \
+    }                                                                                             \
+    if (st12_) P8_STAGE(A, 1, (t) + 1, bn_ + OFF_A1);                                             \
+    if (MODE == 4) P8_STAGE_RS(rsAn, A, 0, 0, OFF_A0);                                            \
+    wait_vm<P8BWait<MODE>::w2>();                                                                 \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(0, 2, a, BX);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P3 */                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      a[i][0] = P8_RD(smem + OFF_A1 + i * 2048, ra0_);                                            \
+      a[i][1] = P8_RD(smem + OFF_A1 + i * 2048, ra1_);                                            \
+    }                                                                                             \
+    if (st34_) P8_STAGE(B, 0, (t) + 2, bo_ + OFF_B0);                                             \
+    if (MODE == 4) P8_STAGE_RS(rsBn, B, 1, 0, OFF_B1);                                            \
+    wait_vm<P8BWait<MODE>::w3>();                                                                 \
+    P8_BAR();                                                                                     \
+    P8_LGKM0();                                                                                   \
+    P8_MFMA(4, 2, a, BX);                                                                         \
+    P8_BAR();                                                                                     \
+    /* P4: B0 of the NEXT k-tile -> BX (dead: P3's MFMAs have been issued) */                      \
+    if (MODE != 2 && MODE != 4) {                                                                 \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+        BX[j][0] = P8_RD(smem + OFF_B0 + j * 2048, rn0_);                                         \
+        BX[j][1] = P8_RD(smem + OFF_B0 + j * 2048, rn1_);                                         \
+      }                                                                                           \
+    }                                                                                             \
+    if (st34_) P8_STAGE(A, 0, (t) + 2, bo_ + OFF_A0);                                             \
+    if (MODE == 4) P8_STAGE_RS(rsAn, A, 1, 0, OFF_A1);                                            \
+    wait_vm<P8BWait<MODE>::w4>();                                                                 \
+    P8_BAR();                                                                                     \
+    P8_MFMA(4, 0, a, BC);                                                                         \
+    P8_BAR();                                                                                     \
+  } while (0)
 
 template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
@@ -943,37 +1046,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / GBK;  // even, >= 2 (launch_gemm checks)
-  // DMA sources through two buffer descriptors (SGPRs) based at the tile's A / W rows: per lane ONE 32-bit byte offset per
-  // pass (512 threads x 16 B = 64 rows of a half-tile), the half (h) and the k-tile in the scalar offset -- no 64-bit VALU
-  // address arithmetic in the load segments, 4 address registers instead of 16
-  int voA[2], voB[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int s_ = it * 512 + tid, r = s_ >> 3, c = (s_ & 7) ^ (r & 7);
-    voA[it] = (((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2;
-    voB[it] = (((r >> 5) * 64 + (r & 31)) * p.ldw + c * 8) * 2;
-  }
-  const int hA = 64 * p.lda * 2, hB = 32 * p.ldw * 2;  // second half-tile: +64 A rows / +32 W rows
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
-  constexpr int OFF_A0 = 0, OFF_A1 = 16384, OFF_B0 = 32768, OFF_B1 = 49152, BUF = 65536;
-  char* const ldsw = smem + wave * 1024;
-// stage half H (0 / 1) of operand X (A / B) of k-tile kt into the slot at byte offset off
-#define P8_STAGE(X, H, kt, off)                                                                                          \
-  do {                                                                                                                   \
-    const int so_ = (kt) * (GBK * 2) + (H) * h##X;                                                                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs##X, (lds_ptr_t)(ldsw + (off)), 16, vo##X[0], so_, 0, 0);                 \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs##X, (lds_ptr_t)(ldsw + (off) + 8192), 16, vo##X[1], so_, 0, 0);          \
-  } while (0)
-  const int cg = lane >> 4;
-  const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
-  const int oa0 = ra * 128 + (((0 + cg) ^ (ra & 7)) << 4), oa1 = ra * 128 + (((4 + cg) ^ (ra & 7)) << 4);
-  const int ob0 = rb * 128 + (((0 + cg) ^ (rb & 7)) << 4), ob1 = rb * 128 + (((4 + cg) ^ (rb & 7)) << 4);
-  // the same four offsets into the ring's second parity, as registers of their own (opaque to the compiler): ds_read's
-  // instruction offset is 16 bits, the ring 128 KB -- left alone hipcc forms one address register per READ of parity 1 (12)
-  int oa0q = oa0 + 65536, oa1q = oa1 + 65536, ob0q = ob0 + 65536, ob1q = ob1 + 65536;
-  asm volatile("" : "+v"(oa0q), "+v"(oa1q), "+v"(ob0q), "+v"(ob1q));
-#define P8_RD(base, off) (*reinterpret_cast<const bf16x8*>((base) + (off)))
+  P8_LANE_SETUP();
+  const __amdgpu_buffer_rsrc_t rsA = P8_RSRC(p.A + (size_t)m0 * p.lda, 0x7fffffff);
+  const __amdgpu_buffer_rsrc_t rsB = P8_RSRC(p.W + (size_t)n0 * p.ldw, 0x7fffffff);
+  const __amdgpu_buffer_rsrc_t rsAn = rsA, rsBn = rsB;  // (MODE 4 is the persistent kernel's: not instantiated here)
 
   // prologue: the whole k-tile 0 in the order it is needed, then what P3 / P4 of "k-tile -1" would have issued
   P8_STAGE(B, 0, 0, OFF_B0);
@@ -993,61 +1069,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     be[j][0] = P8_RD(smem + OFF_B0 + j * 2048, ob0);
     be[j][1] = P8_RD(smem + OFF_B0 + j * 2048, ob1);
   }
-
-// k-tile t of parity PAR (a literal); BC: the B registers that hold B0(t), BX: the other set
-#define P8B_TILE(MODE, PAR, t, BC, BX)                                                            \
-  do {                                                                                            \
-    constexpr int bo_ = (PAR) * BUF, bn_ = bo_ ^ BUF;                                             \
-    const int ra0_ = (PAR) ? oa0q : oa0, ra1_ = (PAR) ? oa1q : oa1;  /* this parity's A reads */   \
-    const int rb0_ = (PAR) ? ob0q : ob0, rb1_ = (PAR) ? ob1q : ob1;  /* ... B reads */             \
-    const int rn0_ = (PAR) ? ob0 : ob0q, rn1_ = (PAR) ? ob1 : ob1q;  /* the other parity's B0 */   \
-    /* P1 */                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-      a[i][0] = P8_RD(smem + OFF_A0 + i * 2048, ra0_);                                            \
-      a[i][1] = P8_RD(smem + OFF_A0 + i * 2048, ra1_);                                            \
-    }                                                                                             \
-    if (MODE <= 1) P8_STAGE(B, 1, (t) + 1, bn_ + OFF_B1);                                         \
-    wait_vm<P8BWait<MODE>::w1>();                                                                 \
-    P8_BAR();                                                                                     \
-    P8_LGKM0();                                                                                   \
-    P8_MFMA(0, 0, a, BC);                                                                         \
-    P8_BAR();                                                                                     \
-    /* P2 */                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
-      BX[j][0] = P8_RD(smem + OFF_B1 + j * 2048, rb0_);                                           \
-      BX[j][1] = P8_RD(smem + OFF_B1 + j * 2048, rb1_);                                           \
-    }                                                                                             \
-    if (MODE <= 1) P8_STAGE(A, 1, (t) + 1, bn_ + OFF_A1);                                         \
-    wait_vm<P8BWait<MODE>::w2>();                                                                 \
-    P8_BAR();                                                                                     \
-    P8_LGKM0();                                                                                   \
-    P8_MFMA(0, 2, a, BX);                                                                         \
-    P8_BAR();                                                                                     \
-    /* P3 */                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-      a[i][0] = P8_RD(smem + OFF_A1 + i * 2048, ra0_);                                            \
-      a[i][1] = P8_RD(smem + OFF_A1 + i * 2048, ra1_);                                            \
-    }                                                                                             \
-    if (MODE == 0) P8_STAGE(B, 0, (t) + 2, bo_ + OFF_B0);                                         \
-    wait_vm<P8BWait<MODE>::w3>();                                                                 \
-    P8_BAR();                                                                                     \
-    P8_LGKM0();                                                                                   \
-    P8_MFMA(4, 2, a, BX);                                                                         \
-    P8_BAR();                                                                                     \
-    /* P4: B0 of the NEXT k-tile -> BX (dead: P3's MFMAs have been issued) */                      \
-    if (MODE <= 1) {                                                                              \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
-        BX[j][0] = P8_RD(smem + OFF_B0 + j * 2048, rn0_);                                         \
-        BX[j][1] = P8_RD(smem + OFF_B0 + j * 2048, rn1_);                                         \
-      }                                                                                           \
-    }                                                                                             \
-    if (MODE == 0) P8_STAGE(A, 0, (t) + 2, bo_ + OFF_A0);                                         \
-    wait_vm<P8BWait<MODE>::w4>();                                                                 \
-    P8_BAR();                                                                                     \
-    P8_MFMA(4, 0, a, BC);                                                                         \
-    P8_BAR();                                                                                     \
-  } while (0)
-
   int t = 0;
   for (; t < nk - 2; t += 2) {
     P8B_TILE(0, 0, t, be, bo);
@@ -1055,9 +1076,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   P8B_TILE(1, 0, t, be, bo);
   P8B_TILE(2, 1, t + 1, bo, be);
-#undef P8B_TILE
-#undef P8_STAGE
-#undef P8_RD
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
   __syncthreads();        // operand buffers become epilogue space
   if constexpr (EPI == EPI_RESID) {
@@ -1070,6 +1088,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
 }
+
+#ifdef DVT_LAB
+#include "lab/dvt_vit_gemm8t.inc"  // "8t": this kernel as a persistent workgroup with an overlapped tile boundary (round 6, negative)
+#endif
+#undef P8B_TILE
+#undef P8_STAGE
+#undef P8_STAGE_RS
+#undef P8_RSRC
+#undef P8_RD
+#undef P8_LANE_SETUP
 
 // (Rounds 3 / 4 built two persistent variants of this kernel -- "8q": register epilogue + tile loop, removed; "4w": four
 // waves, deferred epilogue, lab/dvt_vit_gemm4w.inc -- neither beat it: profiles/LOG.md 5 finding 3, profiles/r04/README.md.)
@@ -1212,6 +1240,16 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
           case 8: hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 8>), grid8, dim3(512), 0, s, a); break;
           default: hipLaunchKernelGGL((gemm_bf16_kernel_8p_lab<EPI, 9>), grid8, dim3(512), 0, s, a); break;
         }
+        lab_done = true;
+      }
+    }
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_QKV || EPI == EPI_GELU) {
+      if (!lab_done && g_vit_gemm_variant == 11 && nk >= 4 && grid8.x > 256) {  // "8t": persistent, overlapped tile boundary
+        // workgroups of g_vit_tpw tiles each (0: one workgroup per CU for the whole launch); a multiple of 8 (XCD affinity)
+        int nwg = g_vit_tpw > 0 ? ((int)grid8.x + g_vit_tpw - 1) / g_vit_tpw : 256;
+        nwg = (nwg + 7) / 8 * 8;
+        if (nwg < 256) nwg = 256;
+        hipLaunchKernelGGL((gemm_bf16_kernel_8t<EPI>), dim3(nwg), dim3(512), 0, s, a);
         lab_done = true;
       }
     }
@@ -1902,7 +1940,7 @@ int dvt_vit_tune(int v) {
     return 0;
   }
   if (v <= -200 && v > -300) {  // -200 - n: target tiles per workgroup of the 4w kernel, 0 = auto
-    g_vit_tpw = -200 - v > 16 ? 16 : -200 - v;
+    g_vit_tpw = -200 - v > 64 ? 64 : -200 - v;
     return 0;
   }
 #else
@@ -1921,7 +1959,7 @@ int dvt_vit_tune(int v) {
     return 0;
   }
 #ifdef DVT_LAB
-  if (v < 0 || v > 13 || v == 11 || v == 12) return DVT_E_BADARG;
+  if (v < 0 || v > 13 || v == 12) return DVT_E_BADARG;
   g_vit_abl4w = g_vit_8p_build = 0;  // an ablation / timing build never survives a change of schedule
 #else
   if (v != 1 && v != 3 && v != 4) return DVT_E_BADARG;

@@ -25,13 +25,13 @@ def env_ranks() -> tuple[int, int, int]:
 
 def _first_env(names, default):
     """Value of the first variable of `names` that is set to something int()-able (SLURM writes e.g. "8(x2)": leading digits)."""
-    for n in names:
-        v = os.environ.get(n, "")
-        n = 0
-        while n < len(v) and v[n].isdigit():
-            n += 1
-        if n:
-            return v[:n]
+    for name in names:
+        v = os.environ.get(name, "")
+        digits = 0
+        while digits < len(v) and v[digits].isdigit():
+            digits += 1
+        if digits:
+            return v[:digits]
     return default
 
 
@@ -62,12 +62,21 @@ def pin_host_threads(local_rank: int | None = None, local_world: int | None = No
     # export their own names (with only LOCAL_WORLD_SIZE read, such launches silently lost the pinning and
     # eight ranks fought over the same cores again).  Last resort: WORLD_SIZE when it cannot span more than this host's GPUs.
     if local_world is None:
+        # The scheduler's per-node variables describe the ALLOCATION, not this process: a single `python bench.py` inside an
+        # sbatch allocation made with --ntasks-per-node=8 sees SLURM_NTASKS_PER_NODE=8 / SLURM_LOCALID=0 and must keep the whole
+        # host.  They count only when this process really is one rank of several: a world size > 1 exported by the
+        # LAUNCHER of this process (torch.distributed.run's / a wrapper's WORLD_SIZE -- which dist.init's env:// rendezvous needs
+        # anyway --, mpirun's OMPI_COMM_WORLD_SIZE, PMI_SIZE); SLURM's allocation-level variables alone never suffice.
+        world = int(_first_env(("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE"), 1))
+        is_rank = world > 1
         local_world = int(_first_env(("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE",
-                                      "MPI_LOCALNRANKS"), 0))
-        if local_world <= 0:
-            world = int(os.environ.get("WORLD_SIZE", 1))
+                                      "MPI_LOCALNRANKS"), 0)) if is_rank else 0
+        if local_world <= 0 and is_rank:
             n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-            if 1 < world <= n_dev:
+            # last resort: WORLD_SIZE is this host's rank count only when the launcher ALSO says the ranks are local
+            # (LOCAL_RANK set: torch.distributed.run single-node) -- one rank per node of a multi-node job has WORLD_SIZE > 1
+            # and no local rank, and keeps its host
+            if 1 < world <= n_dev and "LOCAL_RANK" in os.environ:
                 local_world = world
             elif world > 1:
                 _warn_once(f"dvt_amd.dist: WORLD_SIZE={world} but no local world size in the environment (LOCAL_WORLD_SIZE / "

@@ -160,6 +160,15 @@ def random_state_dict(dim: int, depth: int, patch: int, n_tokens: int, seed: int
     return sd
 
 
+_cap_warned: set = set()
+
+
+def _warn_cap(msg: str) -> None:
+    if msg not in _cap_warned:
+        _cap_warned.add(msg)
+        print(msg, flush=True)
+
+
 def balanced_launch_views(n_views: int, max_batch: int) -> int:
     """Views per extractor launch, equal launches: the fewest launches of at most `max_batch` views, equally sized (769
     views at 128 -> 7 x 110 instead of 6 x 128 + 1).  DVT_VIT_BALANCE=0: the reference's plain chunks of max_batch."""
@@ -351,9 +360,30 @@ class HipViT:
             b0 += nb
         return out
 
+    def _memory_cap(self, max_batch: int) -> int:
+        """`max_batch` bounded by what the device can hold NOW (the fp32 extractor's launches grew from 32 to 160
+        views = 8 GB of scratch per engine, zero-filled, with no look at the free memory): the largest launch whose workspace
+        fits into 80 % of the free bytes (+ the workspace this engine already owns), never below 1 view.  DVT_VIT_MAX_VIEWS
+        caps it by hand."""
+        env = os.environ.get("DVT_VIT_MAX_VIEWS", "")
+        if env.isdigit() and int(env) > 0:
+            max_batch = min(max_batch, int(env))
+        if self.device.type != "cuda" or max_batch <= self._ws_batch:
+            return max(1, max_batch)
+        free, _ = torch.cuda.mem_get_info(self.device)
+        budget = int(0.8 * free) + (self._ws.numel() if self._ws is not None else 0)
+        b = max_batch
+        while b > 1 and self.workspace_bytes(b) > budget:
+            b = max(1, min(b - 1, b * 3 // 4))
+        if b < max_batch:
+            _warn_cap(f"dvt_amd.vit: extractor launches capped at {b} views (asked {max_batch}): {self.workspace_bytes(max_batch) / 2**30:.1f} "
+                      f"GiB of scratch do not fit into the {free / 2**30:.1f} GiB free on {self.device}")
+        return b
+
     def launch_plan(self, n_views: int, max_batch: int = 128) -> list[int]:
         """Views of each extractor launch for `n_views` views (what forward_features will do)."""
         cfg = self.cfg
+        max_batch = self._memory_cap(max_batch if not (self.dtype == "float32" and not self.x3) else min(max_batch, 160))
         if self.dtype == "float32" and self.x3:
             max_batch = min(max_batch, 64)  # bf16x3: 64 views, 4.4 GB of scratch
         elif self.dtype == "float32":

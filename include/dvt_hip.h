@@ -264,18 +264,21 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  * (-1 heuristic, 0: 64x64, 1: 32x64, 2: 32x32, 3: 64x32 per workgroup);
  * key 1 = bf16 ViT extractor.  The PRODUCT library accepts only values under which every entry point still computes its
  *         documented result, and returns DVT_E_BADARG for anything else:
- *           4 [default] / 3 / 1: GEMM schedule -- 256x256 8-phase ring (whole 256-tiles, else 3) / 256x128 ping-pong (M a
- *             whole 256-tile, else 1) / 128x128 two-stage;
+ *           4 [default] / 3 / 1: GEMM schedule -- 256x256 8-phase ring (whole 256-tiles and an even number of 64-deep
+ *             k-tiles, else 3) / 256x128 ping-pong (M a whole 256-tile, else 1) / 128x128 two-stage;
  *           values >= 16: KiB of W kept L2-resident per N-tile group of the tile rasterisation; -100 - b: b M panels per
  *             block of the tile order (0 = auto); -50 / -51: non-temporal bf16 output stores off / on;
  *           -60 / -61: LayerNorm as its own kernels / folded into the qkv and fc1 GEMMs [default];
+ *           -700 - pct (pct 0..400, default 0 = off): de-synchronised start of the 256x256 kernel's first round of workgroups,
+ *             spread over pct % of the modelled tile time (round 5: no gain; results do not depend on it);
  *           -520 / -521 and -522 / -523: inside dvt_vit_forward_f32x3, exact-fp32 attention on / off [off] and split kernels
  *             instead of split epilogues on / off [off];
  *           -502 and -525 (= -510 - 15): the one attention kernel / schedule mask the product contains (accepted, no effect).
  *         None of these changes a result beyond summation order (fp32 row statistics of the folded LayerNorm, ~1e-7 relative).
- *         Developer builds (-DDVT_LAB, csrc/lab/, include/dvt_vit.h) add: schedules 0, 2 (superseded), 5, 10 (re-schedules of
- *         4, bit-identical), 6..9 (4-wave persistent kernel; 8 / 9 with an approximate GELU), -200 - n / -600 - n (its tiles
- *         per workgroup / grid), -300 - n (ablation mask of the selected 4-wave schedule, or timing build of schedule 5:
+ *         Developer builds (-DDVT_LAB, csrc/lab/, include/dvt_vit.h) add: schedules 0, 2 (superseded), 13 (round 5's walk of the
+ *         8-phase ring) and 5, 10 (re-schedules of it), 11 (the product's kernel as a persistent workgroup with an overlapped
+ *         tile boundary) -- all bit-identical to 4 --, 6..9 (4-wave persistent kernel; 8 / 9 with an approximate GELU),
+ *         -200 - n / -600 - n (tiles per workgroup of 6..9 and 11 / grid of 6..9), -300 - n (ablation mask of the selected 4-wave schedule, or timing build of schedule 5:
  *         TIMING ONLY, results wrong by construction; reset by every change of schedule), -501 (round-2 attention loop),
  *         -510 - mask (attention schedule masks);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
@@ -283,10 +286,14 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);
  * key 4 = fp32 GEMM: 1 (default) use the 3-stage LDS-DMA kernel when eligible, 0 = register-staged only;
  *         2 / 3 = LDS stages of the stage-2 GEMMs (2, default: two workgroups per CU);
+ *         11 (default) / 10 = the fp32 extractor's linear layers on the 128 x 128 x 32 tile with fused GELU / residual
+ *         epilogues (round 5) / on the 64 x 64 x 64 LDS-DMA kernel + separate row-local passes (results differ in summation
+ *         order only);
  * key 6 = fit step: 1 (default) the fused row kernel (dvt_fit_fused.hip), 0 = one launch per layer (both operand
  *         precisions); 3 (default) / 2 = the same switch for the fp32-operand mode only (round 5: fp32 row kernel on
  *         v_mfma_f32_16x16x4_f32 where its LDS images fit, feat_dim 384 / 768; results agree with the layer-by-layer launches to
- *         1e-7, the same 200 us per step alone; dvt_amd.stage1 selects 2 beside the fp32 extractor, profiles/r05/r05f_*);
+ *         summation order -- tested bound: per-step losses within 5e-5 relative, mean parameter difference 2e-6 after 24 steps
+ *         (tests/test_gpu_fit.py) --, the same 200 us per step alone; the choice is latched once per dvt_fit_run[_batched] call; dvt_amd.stage1 selects 2 beside the fp32 extractor, profiles/r05/r05f_*);
  * key 7 = fit step (both operand precisions since round 4): 1 (default) hash-grid gradient gathered from per-step sorted
  *         corner lists, 0 = scattered with atomics;
  * key 9 = fit step (both precisions): 1 (default) lazy Adam over the fine hash-grid levels -- with fp32 operands always the

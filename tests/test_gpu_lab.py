@@ -68,7 +68,7 @@ def test_lab_ablation_state_is_reset_by_a_schedule_change(L):
         L.dvt_tune_set(1, -300)
 
 
-@pytest.mark.parametrize("variant", [5, 10, 13])
+@pytest.mark.parametrize("variant", [5, 10, 11, 13])
 @pytest.mark.parametrize("n,k,gelu", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 0)])
 def test_gemm_8m_8h_bit_identical_to_8p(L, n, k, gelu, variant):
     """The walks of the 8p ring.  Schedule 4 -- the product's -- is since round 6 the "8b" walk (fragment reads balanced

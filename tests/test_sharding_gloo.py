@@ -127,6 +127,22 @@ def test_ranks_pin_disjoint_host_cpu_slices():
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
         info = json.loads(out.strip().splitlines()[-1])
         assert info["pinned"] and info["local_rank"] == 1 and set(info["affinity"]) == seen[1], (extra, info)
+    # ONE process inside a multi-task allocation (sbatch --ntasks-per-node=8: the batch step exports the
+    # allocation's SLURM_NTASKS_PER_NODE / SLURM_LOCALID=0) is not a rank of anything: it keeps the whole host ...
+    env = dict(os.environ, SLURM_NTASKS_PER_NODE="8", SLURM_LOCALID="0", SLURM_NTASKS="8", SLURM_PROCID="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_WORLD_SIZE", "LOCAL_RANK", "DVT_NO_AFFINITY", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    info = json.loads(out.strip().splitlines()[-1])
+    assert not info["pinned"] and len(info["affinity"]) == n_cpu, info
+    # ... and so does one rank per node of a multi-node job (WORLD_SIZE = 2 <= the GPUs of this host, no local variables)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1")
+    for k in ("LOCAL_WORLD_SIZE", "LOCAL_RANK", "DVT_NO_AFFINITY", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE",
+              "MPI_LOCALNRANKS"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    info = json.loads(out.strip().splitlines()[-1])
+    assert not info["pinned"] and len(info["affinity"]) == n_cpu, info
 
 
 def _bench_env():
