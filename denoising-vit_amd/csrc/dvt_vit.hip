@@ -105,6 +105,7 @@ struct GemmBArgs {
   double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
   unsigned* dbg;      // timing builds of the 8p kernel (dvt_vit_debug_buffer): 24 u32 per wave group and workgroup
   int stagger_ticks;  // 8p: the first round of workgroups (one per CU) starts spread over this many 100-MHz ticks (0: together)
+  int tpw;            // lab 8t: tiles per workgroup (generations of 256 workgroups walk tpw x 256 consecutive tiles)
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -407,7 +408,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // each wave re-reads its own block only
     const int f0 = nb - 2 * p.dim, hh = f0 >> 6;        // (the block is one head's 64 features: dim_ok_sq / 64-aligned)
-    const int bimg = mbv / p.s_pad, s0 = mbv - bimg * p.s_pad + tc * 8;
+    // the image of THIS lane's 8 tokens: a block may straddle two images (s_pad % 64 != 0), an 8-token chunk never (s_pad % 8 == 0)
+    const int trow = mbv + tc * 8, bimg = trow / p.s_pad, s0 = trow - bimg * p.s_pad;
     bf16_t* const vrow = p.vt + ((size_t)(bimg * p.heads + hh) * 64) * p.s_pad + s0;
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
@@ -1246,9 +1248,10 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     if constexpr (EPI == EPI_BIAS || EPI == EPI_QKV || EPI == EPI_GELU) {
       if (!lab_done && g_vit_gemm_variant == 11 && nk >= 4 && grid8.x > 256) {  // "8t": persistent, overlapped tile boundary
         // workgroups of g_vit_tpw tiles each (0: one workgroup per CU for the whole launch); a multiple of 8 (XCD affinity)
-        int nwg = g_vit_tpw > 0 ? ((int)grid8.x + g_vit_tpw - 1) / g_vit_tpw : 256;
-        nwg = (nwg + 7) / 8 * 8;
-        if (nwg < 256) nwg = 256;
+        // generations of 256 workgroups: generation g walks tiles [g, g + 1) x tpw x 256 of the order in tpw lock-step rounds
+        const int tiles = (int)grid8.x;
+        a.tpw = g_vit_tpw > 0 ? g_vit_tpw : (tiles + 255) / 256;
+        const int nwg = (tiles + a.tpw * 256 - 1) / (a.tpw * 256) * 256;
         hipLaunchKernelGGL((gemm_bf16_kernel_8t<EPI>), dim3(nwg), dim3(512), 0, s, a);
         lab_done = true;
       }
@@ -1448,7 +1451,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   char* const Vbl = Kbl + KSET;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lc = lane & 15;
-  const int nqb = s_pad / ATT_Q;
+  const int nqb = (s_pad + ATT_Q - 1) / ATT_Q;  // the last block of an image may hang over its rows (s_pad % 16 == 0: whole waves)
   int id = blockIdx.x;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
@@ -1800,6 +1803,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
 #undef A2_STOREK
 #undef A2_STOREV
 #undef A2_S
+  if (qb * ATT_Q + wave * 16 >= s_pad) return;  // a wave past the image's rows (its 16 "queries" were the next image's): nothing to store
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
@@ -1875,7 +1879,9 @@ int64_t vit_carve(const DvtVitConfig* c, int batch, char* base, VitWork* w) {
   VitWork t;
   t.x = (float*)take(T * c->dim * 4);
   t.xn = (bf16_t*)take(T * c->dim * 2);
-  t.qk = (bf16_t*)take(T * 2 * c->dim * 2);
+  // (+ 128 rows: where s_pad is not a multiple of 128 the attention kernel's last query block / key tile of the LAST image read
+  // up to 127 rows past batch * s_pad -- never used: masked keys, unstored queries -- which T does not always cover)
+  t.qk = (bf16_t*)take((T + 128) * 2 * c->dim * 2);
   t.vt = (bf16_t*)take(((int64_t)batch + 1) * c->s_pad * c->dim * 2);  // the phantom rows' V^T lands in image `batch`
   t.hid = (bf16_t*)take(T * c->mlp_dim * 2);
   t.col = (bf16_t*)take(T * c->k_patch * 2);
@@ -1889,7 +1895,8 @@ int64_t vit_carve(const DvtVitConfig* c, int batch, char* base, VitWork* w) {
 int check_vit_cfg(const DvtVitConfig* c) {
   if (!c || c->dim <= 0 || c->dim % 128 || c->dim > 1024 || c->heads * 64 != c->dim) return DVT_E_BADARG;
   if (c->depth < 1 || c->depth > DVT_VIT_MAX_DEPTH || c->mlp_dim % 128) return DVT_E_BADARG;
-  if (c->s_pad % 128 || c->s_pad < c->n_tokens || c->k_patch % 64) return DVT_E_BADARG;
+  // token rows per image: a multiple of 32 (bf16 path; dvt_vit_config writes the next multiple of 128, the fp32 paths' need)
+  if (c->s_pad % 32 || c->s_pad < c->n_tokens || c->k_patch % 64) return DVT_E_BADARG;
   if (c->n_prefix < 1 || c->n_prefix > 9 || (c->pos_has_cls != 0 && c->pos_has_cls != 1)) return DVT_E_BADARG;
   if (c->n_tokens != c->n_prefix + c->grid_h * c->grid_w) return DVT_E_BADARG;
   return 0;
@@ -2129,13 +2136,14 @@ extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b,
 
 extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads,
                                  int s_pad, int n_valid, void* stream) {
-  if (!qk || !vt || !out || batch <= 0 || heads <= 0 || s_pad % ATT_Q || n_valid <= 0 || n_valid > s_pad)
+  if (!qk || !vt || !out || batch <= 0 || heads <= 0 || s_pad % 16 || n_valid <= 0 || n_valid > s_pad)
     return DVT_E_BADARG;
   DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
                       4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
-  const dim3 grid((s_pad / ATT_Q) * heads * batch);
+  const dim3 grid(((s_pad + ATT_Q - 1) / ATT_Q) * heads * batch);
 #ifdef DVT_LAB
   if (g_vit_attn_variant != 2) {
+    if (s_pad % ATT_Q) return DVT_E_BADARG;  // (the round-2 loop has no query-block tail)
     hipLaunchKernelGGL(attention_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk, (const bf16_t*)vt,
                        (bf16_t*)out, heads, s_pad, n_valid);
     DVT_CHECK_LAUNCH();

@@ -37,7 +37,8 @@ typedef struct DvtVitConfig {
   int32_t img_h, img_w; /* 518 x 518 */
   int32_t grid_h, grid_w; /* (img - patch) / stride + 1 = 37 */
   int32_t n_tokens;  /* n_prefix + grid_h * grid_w = 1370 */
-  int32_t s_pad;     /* tokens per image padded to a multiple of 128 (1408) */
+  int32_t s_pad;     /* token rows per image: >= n_tokens, a multiple of 32 for dvt_vit_forward (dvt_amd uses 1376 for 1370 tokens
+                      * since round 6), of 128 for the fp32 / bf16x3 forwards; dvt_vit_config writes the next multiple of 128 */
   int32_t k_patch;   /* 3 * patch * patch padded to a multiple of 64 (588 -> 640) */
   int32_t n_prefix;  /* prefix tokens: 1 (cls) + register tokens (4 for the *_reg4_* models) */
   float ln_eps;      /* 1e-6 */
@@ -152,8 +153,11 @@ int dvt_vit_gemm_residual(const void* a, const void* w, const float* b, const fl
 /* y (bf16) [rows, dim] = LayerNorm(x fp32 [rows, dim]) * w + b */
 int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, int rows, int dim,
                       float eps, void* stream);
-/* s_pad % 128 == 0.  out[b, s, h*64 + d] (bf16, [batch*s_pad, heads*64]) = softmax(q k^T / 8) v over the first
- * n_valid keys; qk bf16 [batch*s_pad, 2*heads*64] (q then k), vt bf16 [batch, heads, 64, s_pad]. */
+/* s_pad % 16 == 0.  out[b, s, h*64 + d] (bf16, [batch*s_pad, heads*64]) = softmax(q k^T / 8) v over the first
+ * n_valid keys; qk bf16 [batch*s_pad, 2*heads*64] (q then k), vt bf16 [batch, heads, 64, s_pad].  The kernel works in blocks of
+ * 128 queries and tiles of 64 keys: where s_pad is not a multiple of 128 it READS up to 127 rows behind image b's rows of qk /
+ * 63 elements behind a row of vt (the next image's, never used: masked keys, unstored queries) -- the caller keeps 128 rows
+ * of qk and one image of vt allocated behind the last image (dvt_vit_workspace_bytes does). */
 int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
                       int n_valid, void* stream);
 

@@ -193,6 +193,38 @@ def check_attention_vs_torch(L, batch, heads, s_pad, n_valid, attn_variant):
     assert bool(torch.isfinite(got).all())
 
 
+@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(3, 2, 1376, 1370), (2, 1, 160, 150), (1, 2, 1376, 1376), (2, 2, 32, 20)])
+def test_attention_row_pitch_not_a_multiple_of_128(L, batch, heads, s_pad, n_valid):
+    """Round 6: an image owns s_pad rows with s_pad a multiple of 32 only (1370 tokens -> 1376 instead of 1408).  The kernel
+    still walks blocks of 128 queries and tiles of 64 keys: the last block / tile of an image hangs over into the NEXT image's
+    rows (read, masked / not stored) -- every image's valid rows must come out right (nobody else's block stores into them),
+    the pad rows of the output are written by nobody else either, and what lies behind the last image (the slack the caller
+    keeps allocated: 128 rows of qk, one image of vt) may hold anything finite."""
+    torch.manual_seed(s_pad + heads + batch)
+    dim = heads * 64
+    q = torch.randn(batch, s_pad, heads, 64)
+    k = torch.randn(batch, s_pad, heads, 64) + torch.linspace(-1, 1, 64)
+    v = torch.randn(batch, s_pad, heads, 64) * torch.linspace(0.5, 1.5, 64)
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    att = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qb.float() * 0.125, kb.float()[:, :n_valid]), -1)
+    want = torch.einsum("bhqk,bkhd->bqhd", att, vb.float()[:, :n_valid]).reshape(batch, s_pad, dim)
+    rows = batch * s_pad
+    qk = torch.full((rows + 128, 2 * dim), 3.0e4, dtype=torch.bfloat16)  # slack: large, finite
+    qk[:rows] = torch.cat([qb.reshape(rows, dim), kb.reshape(rows, dim)], 1)
+    vt = torch.full((batch + 1, heads, 64, s_pad), -2.0e4, dtype=torch.bfloat16)
+    vt[:batch] = vb.permute(0, 2, 3, 1)
+    qk, vt = qk.to(DEV), vt.to(DEV)
+    out = torch.full((rows + 128, dim), 7.0, device=DEV, dtype=torch.bfloat16)
+    assert L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
+    torch.cuda.synchronize()
+    assert bool((out[rows:].float() == 7.0).all()), "a query block past the last image stored its rows"
+    got = out[:rows].float().reshape(batch, s_pad, dim).cpu()
+    assert bool(torch.isfinite(got).all())
+    for b in range(batch):
+        assert rel(got[b, :n_valid], want[b, :n_valid]) < 2e-2, b
+    assert L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad + 8, n_valid, _s()) == -1
+
+
 SPIKES = [(1, 1.5), (5, 1.5), (20, 1.5), (21, 1.5), (7, 1.0), (13, 1.15)]
 
 
