@@ -1504,10 +1504,15 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
     kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq);                       \
     if constexpr (X3) kr0l = *reinterpret_cast<const uint4*>(kp0 + klo + (size_t)(kt) * KV_TILE * ldq); \
   } while (0)
+// (a lane's 8 keys lie wholly inside or wholly behind the image's s_pad keys (s_pad % 8 == 0).  Behind them -- the last tile
+// where s_pad % 64 != 0 -- the lane re-reads a chunk of real keys instead: those keys' P is 0, but what lies behind a V^T row
+// is the next row / head / image or unwritten workspace, and 0 x NaN would poison the row's output.  "Re-reads": the row's
+// first chunk, which always exists)
 #define A2_LOADV(kt)                                                                   \
   do {                                                                                 \
-    vr0 = *reinterpret_cast<const uint4*>(vp0 + (kt) * KV_TILE);                       \
-    if constexpr (X3) vr0l = *reinterpret_cast<const uint4*>(vp0 + vlo + (kt) * KV_TILE); \
+    const int vk_ = (kt) * KV_TILE + sc * 8 >= s_pad ? -sc * 8 : (kt) * KV_TILE;       \
+    vr0 = *reinterpret_cast<const uint4*>(vp0 + vk_);                                  \
+    if constexpr (X3) vr0l = *reinterpret_cast<const uint4*>(vp0 + vlo + vk_);         \
   } while (0)
 #define A2_STOREK(kt)                                                                                   \
   do {                                                                                                  \

@@ -155,9 +155,9 @@ int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, i
                       float eps, void* stream);
 /* s_pad % 16 == 0.  out[b, s, h*64 + d] (bf16, [batch*s_pad, heads*64]) = softmax(q k^T / 8) v over the first
  * n_valid keys; qk bf16 [batch*s_pad, 2*heads*64] (q then k), vt bf16 [batch, heads, 64, s_pad].  The kernel works in blocks of
- * 128 queries and tiles of 64 keys: where s_pad is not a multiple of 128 it READS up to 127 rows behind image b's rows of qk /
- * 63 elements behind a row of vt (the next image's, never used: masked keys, unstored queries) -- the caller keeps 128 rows
- * of qk and one image of vt allocated behind the last image (dvt_vit_workspace_bytes does). */
+ * 128 queries and tiles of 64 keys: where s_pad is not a multiple of 128 it READS up to 127 rows behind image b's rows of qk
+ * (the next image's, or whatever lies there: masked keys, unstored queries -- any bit pattern is harmless) -- the caller keeps
+ * 128 rows of qk allocated behind the last image (dvt_vit_workspace_bytes does).  vt is never read behind a row's s_pad keys. */
 int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
                       int n_valid, void* stream);
 

@@ -198,8 +198,9 @@ def test_attention_row_pitch_not_a_multiple_of_128(L, batch, heads, s_pad, n_val
     """Round 6: an image owns s_pad rows with s_pad a multiple of 32 only (1370 tokens -> 1376 instead of 1408).  The kernel
     still walks blocks of 128 queries and tiles of 64 keys: the last block / tile of an image hangs over into the NEXT image's
     rows (read, masked / not stored) -- every image's valid rows must come out right (nobody else's block stores into them),
-    the pad rows of the output are written by nobody else either, and what lies behind the last image (the slack the caller
-    keeps allocated: 128 rows of qk, one image of vt) may hold anything finite."""
+    the pad rows of the output are written by nobody else either, and what lies behind the last image (the 128 rows of qk the
+    caller keeps allocated; anything behind vt) may hold ANY bit pattern: NaN here -- a reused workspace re-carved for another
+    batch does hold such patterns, and 0 x NaN once poisoned whole images (round 6, first cut: V^T was read behind its rows)."""
     torch.manual_seed(s_pad + heads + batch)
     dim = heads * 64
     q = torch.randn(batch, s_pad, heads, 64)
@@ -209,9 +210,9 @@ def test_attention_row_pitch_not_a_multiple_of_128(L, batch, heads, s_pad, n_val
     att = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qb.float() * 0.125, kb.float()[:, :n_valid]), -1)
     want = torch.einsum("bhqk,bkhd->bqhd", att, vb.float()[:, :n_valid]).reshape(batch, s_pad, dim)
     rows = batch * s_pad
-    qk = torch.full((rows + 128, 2 * dim), 3.0e4, dtype=torch.bfloat16)  # slack: large, finite
+    qk = torch.full((rows + 128, 2 * dim), float("nan"), dtype=torch.bfloat16)  # slack: NaN
     qk[:rows] = torch.cat([qb.reshape(rows, dim), kb.reshape(rows, dim)], 1)
-    vt = torch.full((batch + 1, heads, 64, s_pad), -2.0e4, dtype=torch.bfloat16)
+    vt = torch.full((batch + 1, heads, 64, s_pad), float("nan"), dtype=torch.bfloat16)
     vt[:batch] = vb.permute(0, 2, 3, 1)
     qk, vt = qk.to(DEV), vt.to(DEV)
     out = torch.full((rows + 128, dim), 7.0, device=DEV, dtype=torch.bfloat16)
