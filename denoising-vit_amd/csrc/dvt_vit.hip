@@ -106,6 +106,9 @@ struct GemmBArgs {
   unsigned* dbg;      // timing builds of the 8p kernel (dvt_vit_debug_buffer): 24 u32 per wave group and workgroup
   int stagger_ticks;  // 8p: the first round of workgroups (one per CU) starts spread over this many 100-MHz ticks (0: together)
   int tpw;            // lab 8t: tiles per workgroup (generations of 256 workgroups walk tpw x 256 consecutive tiles)
+  // map_tile_fast: the tile order's divisors as multiply-shift pairs (fd_make), set by launch_gemm for the 256 x 256 kernels
+  unsigned fd_pg[2], fd_pb[2], fd_w[2], fd_hb[2];  // per_group = group * mt; per_block = mblock * group; width = group; hb = mblock
+  int tiles_full;     // N tiles in whole groups (nt / group * group): ids beyond group `tiles_full / group` take the slow path
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -168,6 +171,47 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int mt, int nt, in
     t.n = g * group + r2 / hb;
     t.m = mb * mblock + r2 % hb;
   }
+  return t;
+}
+
+// Unsigned division by a launch-invariant divisor d (1 <= d < 2^31) as multiply-high + shifts (Granlund-Montgomery, the
+// round-up form): l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1;  x / d = (t + ((x - t) >> 1)) >> (l - 1), t = hi32(m x),
+// exact for every x < 2^32 (l = 0, i.e. d = 1: m = 0, the formula degenerates -- handled).  The tile map of the 256 x 256 GEMM
+// divides wave-UNIFORM values by run-time divisors four to six times per workgroup; the scalar unit has no divide, so hipcc
+// expands each into ~30 VALU instructions with dependent v_rcp chains: 0.6 us from kernel entry to the first LDS-DMA issue,
+// 2.4 % of a K = 768 tile (profiles/r06/r06j_*).  With these it is a handful of s_mul_hi_u32 (tests/test_kernel_math_cpu.py
+// states the arithmetic; every GEMM test exercises it).
+inline void fd_make(unsigned d, unsigned (&fd)[2]) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  fd[0] = d <= 1 ? 0u : (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  fd[1] = l;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned x, const unsigned (&fd)[2]) {
+  if (fd[1] == 0) return x;  // d = 1
+  const unsigned t = __umulhi(x, fd[0]);
+  return (t + ((x - t) >> 1)) >> (fd[1] - 1);
+}
+// map_tile with the regular divisors taken from the launch arguments; ids in the last, narrower N group and tiles of a short
+// last M block (rare) fall back to the generic divisions.  Same result as map_tile for every id.
+__device__ __forceinline__ TileMap map_tile_fast(const GemmBArgs& p, int bid, int nwg, int mt, int nt) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;  // bijective
+  const int group = p.group, mblock = p.mblock, per_group = group * mt;
+  if (id >= p.tiles_full * mt) return map_tile(bid, nwg, mt, nt, group, mblock);  // the narrower last group
+  const int g = (int)fd_div((unsigned)id, p.fd_pg), rem = id - g * per_group;
+  TileMap t;
+  if (mblock <= 1) {
+    t.m = (int)fd_div((unsigned)rem, p.fd_w);
+    t.n = g * group + rem - t.m * group;
+    return t;
+  }
+  const int per_block = mblock * group;
+  const int mb = (int)fd_div((unsigned)rem, p.fd_pb), r2 = rem - mb * per_block;
+  if (mt - mb * mblock < mblock) return map_tile(bid, nwg, mt, nt, group, mblock);  // a short last M block
+  const int nq = (int)fd_div((unsigned)r2, p.fd_hb);
+  t.n = g * group + nq;
+  t.m = mb * mblock + r2 - nq * mblock;
   return t;
 }
 
@@ -1024,9 +1068,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
     P8_BAR();                                                                                     \
   } while (0)
 
-template <int EPI>
+// STAMP (developer library only, schedule 12): the tile's anatomy in WALL time -- s_memrealtime (100 MHz, not the shader clock:
+// independent of DVFS) at kernel entry, at the first MFMA (prologue done), behind the k-loop, behind the last store's issue and
+// behind its retirement, + HW_ID / XCC_ID (which CU): 8 u32 per workgroup at p.dbg (tools/lab_gemm8p_anatomy.py).
+template <int EPI, bool STAMP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
+  unsigned long long ts_[5] = {0, 0, 0, 0, 0};
+  if constexpr (STAMP) ts_[0] = __builtin_amdgcn_s_memrealtime();
   // De-synchronised start (dvt_tune_set(1, -700 - pct); round 5: null except proj, default off): the workgroups of the first
   // round wait a hash-spread fraction of one tile time (s_memrealtime, 100 MHz).  Results do not depend on it.
   if (p.stagger_ticks > 0 && blockIdx.x < 256) {
@@ -1038,7 +1087,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const TileMap tm = map_tile(blockIdx.x, gridDim.x, p.M / 256, p.N / 256, p.group, p.mblock);
+  const TileMap tm = map_tile_fast(p, blockIdx.x, gridDim.x, p.M >> 8, p.N >> 8);
   const int m0 = tm.m * 256, n0 = tm.n * 256;
 
   f32x4 acc[8][4];
@@ -1054,12 +1103,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __amdgpu_buffer_rsrc_t rsAn = rsA, rsBn = rsB;  // (MODE 4 is the persistent kernel's: not instantiated here)
 
   // prologue: the whole k-tile 0 in the order it is needed, then what P3 / P4 of "k-tile -1" would have issued
+  unsigned ts_setup_ = 0, ts_issued_ = 0;
+  if constexpr (STAMP) {
+    asm volatile("" : "+v"(voA[0]), "+v"(voB[0]), "+v"(oa0q));  // (the setup arithmetic is complete here, not sunk below)
+    ts_setup_ = (unsigned)__builtin_amdgcn_s_memrealtime();
+  }
   P8_STAGE(B, 0, 0, OFF_B0);
   P8_STAGE(A, 0, 0, OFF_A0);
   P8_STAGE(B, 1, 0, OFF_B1);
   P8_STAGE(A, 1, 0, OFF_A1);
   P8_STAGE(B, 0, 1, BUF + OFF_B0);
   P8_STAGE(A, 0, 1, BUF + OFF_A0);
+  if constexpr (STAMP) ts_issued_ = (unsigned)__builtin_amdgcn_s_memrealtime();
   wait_vm<8>();  // B0(0), A0(0) have landed
   P8_BAR();
   if (wm == 1) P8_BAR();  // group 1: half a phase behind from here on
@@ -1071,6 +1126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     be[j][0] = P8_RD(smem + OFF_B0 + j * 2048, ob0);
     be[j][1] = P8_RD(smem + OFF_B0 + j * 2048, ob1);
   }
+  if constexpr (STAMP) ts_[1] = __builtin_amdgcn_s_memrealtime();
   int t = 0;
   for (; t < nk - 2; t += 2) {
     P8B_TILE(0, 0, t, be, bo);
@@ -1080,15 +1136,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   P8B_TILE(2, 1, t + 1, bo, be);
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
   __syncthreads();        // operand buffers become epilogue space
+  if constexpr (STAMP) ts_[2] = __builtin_amdgcn_s_memrealtime();
   if constexpr (EPI == EPI_RESID) {
     gemm_epilogue_resid_sq(p, acc, m0 + wm * 128, n0 + wn * 64, wave, lane, smem);
-    return;
+  } else {
+    f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
+    f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
+    gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
   }
-  f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
-  f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
-  gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
+  if constexpr (STAMP) {
+    ts_[3] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts_[4] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg != nullptr && tid == 0) {  // wave 0 (group 0); one record per workgroup
+      unsigned* d_ = p.dbg + (size_t)blockIdx.x * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) d_[i] = (unsigned)ts_[i];
+      d_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: wave / simd / cu / sh / se
+      d_[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+      d_[7] = ((ts_setup_ - (unsigned)ts_[0]) & 0xffffu) | ((ts_issued_ - (unsigned)ts_[0]) << 16);  // setup done / 12 DMAs issued, ticks after entry
+    }
+  }
 }
 
 #ifdef DVT_LAB
@@ -1197,6 +1267,11 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
     a.group = g;
     a.mblock = g_vit_mblock > 0 ? g_vit_mblock : (g >= 6 ? 4 : 1);
     a.nt_store = g_vit_nt_store;
+    fd_make((unsigned)(a.group * (a.M / 256)), a.fd_pg);
+    fd_make((unsigned)(a.mblock * a.group), a.fd_pb);
+    fd_make((unsigned)a.group, a.fd_w);
+    fd_make((unsigned)(a.mblock > 0 ? a.mblock : 1), a.fd_hb);
+    a.tiles_full = nt / a.group * a.group;
     const dim3 grid8((a.M / 256) * nt);
     if (g_vit_stagger_pct > 0 && grid8.x > 512) {  // (a launch of fewer than two rounds has nothing to de-synchronise)
       const double epi_us = EPI == EPI_RESID ? 20.0 : (IS_GELU(EPI) ? 10.5 : 5.6);
@@ -1255,6 +1330,11 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_kernel_8t<EPI>), dim3(nwg), dim3(512), 0, s, a);
         lab_done = true;
       }
+    }
+    if (!lab_done && g_vit_gemm_variant == 12) {  // the product kernel's tile anatomy (wall-clock stamps per workgroup)
+      a.dbg = g_vit_dbg;
+      hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, true>), grid8, dim3(512), 0, s, a);
+      lab_done = true;
     }
     if (lab_done) {
     } else if (g_vit_gemm_variant == 13) {  // round 5's walk of the ring (12 / 4 / 8 / 0 reads, run-time parity)
@@ -1971,7 +2051,7 @@ int dvt_vit_tune(int v) {
     return 0;
   }
 #ifdef DVT_LAB
-  if (v < 0 || v > 13 || v == 12) return DVT_E_BADARG;
+  if (v < 0 || v > 13) return DVT_E_BADARG;
   g_vit_abl4w = g_vit_8p_build = 0;  // an ablation / timing build never survives a change of schedule
 #else
   if (v != 1 && v != 3 && v != 4) return DVT_E_BADARG;

@@ -66,3 +66,36 @@ def test_relu_as_a_half_sum_is_exact_for_every_normal_fp32():
     # fc1 pre-activations of that size do not occur, and the difference (<= 2^-149) is far below the bf16 rounding.
     tiny = np.uint32(1).view(np.float32)
     assert half * tiny + half * np.abs(tiny) != tiny
+
+
+def test_tile_map_multiply_shift_division():
+    """csrc/dvt_vit.hip fd_make / fd_div (round 6): the 256 x 256 GEMM's tile map divides by launch-invariant divisors with a
+    multiply-high and two shifts (Granlund-Montgomery, round-up form) instead of hipcc's ~30-instruction VALU expansion of
+    each run-time division.  The arithmetic, restated: l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, t = hi32(m x),
+    x // d = (t + ((x - t) >> 1)) >> (l - 1) -- exact for every 32-bit x; d = 1 is passed through."""
+    import numpy as np
+
+    def fd_make(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        return (0 if d <= 1 else (((1 << l) - d) << 32) // d + 1), l
+
+    def fd_div(x, fd):
+        m, l = fd
+        if l == 0:
+            return x
+        t = (x.astype(np.uint64) * np.uint64(m)) >> np.uint64(32)
+        return ((t + ((x.astype(np.uint64) - t) >> np.uint64(1))) >> np.uint64(l - 1)).astype(np.uint64)
+
+    rng = np.random.RandomState(0)
+    xs = np.concatenate([np.arange(0, 70000, dtype=np.uint64), rng.randint(0, 2 ** 31 - 1, 200000).astype(np.uint64),
+                         np.array([2 ** 31 - 1, 2 ** 32 - 1], np.uint64)])
+    # the divisors the ViT shapes produce (group * mt, mblock * group, group, mblock) and a sweep
+    ds = [1, 2, 3, 4, 5, 7, 9, 12, 36, 48, 2139, 2140, 9 * 2139, 12 * 2140, 3 * 2087, 64, 65, 1000003, 2 ** 30 + 1, 2 ** 31 - 1]
+    ds += list(rng.randint(1, 2 ** 31 - 1, 50))
+    for d in ds:
+        fd = fd_make(int(d))
+        assert fd[0] < 2 ** 32
+        got = fd_div(xs, fd)
+        assert np.array_equal(got, xs // np.uint64(d)), d
