@@ -45,7 +45,7 @@ PY
     prof)
       cd /tmp
       timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_serial -o serial -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-probes --no-fp32-fit --no-vit-large --no-stage2 --pipeline-depth 1 > $O/prof_serial.log 2>&1
-      timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_pipe -o pipe -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-probes --no-fp32-fit --no-vit-large --no-stage2 > $O/prof_pipe.log 2>&1
+      timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_pipe -o pipe -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-probes --no-fp32-fit --no-vit-large --no-stage2 > $O/prof_pipe.log 2>&1
       cd $R
       for n in serial pipe; do python tools/rocpd_stats.py $(find $O/prof_$n -name '*.db' | head -1) > $O/${n}_kernel_stats.txt; tail -1 $O/prof_$n.log | cut -c1-120; done
       rm -rf $O/prof_serial $O/prof_pipe
