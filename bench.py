@@ -243,8 +243,8 @@ def vit_large_leg(a, device, rank, D, V, Stage1, PretrainedViTWrapper):
         for k in range(n):
             yield k, (lambda slot: None)
 
-    st.run(jobs(4))
-    n, el, _ = D.timed(lambda: st.run(jobs(8)), device)
+    st.run(jobs(4), total=4)
+    n, el, _ = D.timed(lambda: st.run(jobs(8), total=8), device)
     st.process(lambda slot: None)
     t = st.timings[-1]
     out = {"images_per_s": n / el, "images_timed": n, "ms_per_image": 1e3 * el / n, "model": VIT_LARGE, "fit_batch": 4,
@@ -418,7 +418,7 @@ def main():
             e.s.mlp_dtype = mode
             e.cfg.mlp_bf16 = int(mode == "bfloat16")
 
-    st.run(jobs(a.warmup))
+    st.run(jobs(a.warmup), total=a.warmup)
     probes = [] if a.no_probes else ["adam", "vit_gemm", "vit_attn", "fit_gemm", "grid"]
     # un-pipelined passes over one image, outside the timed region.  First with every probe OFF: the reference's two
     # timers (main_img_denoising.py:341, :355) -- round 4 took them with all five probes on and the ~15 k event pairs of a
@@ -435,7 +435,7 @@ def main():
     # distort the metric
     probes = [n for n in probes if n in ("adam", "vit_gemm", "vit_attn")]
     _lib.prof_enable(probes)
-    n_done, elapsed, per_rank = D.timed(lambda: st.run(jobs(a.steps), on_result=write_pair), device)
+    n_done, elapsed, per_rank = D.timed(lambda: st.run(jobs(a.steps), on_result=write_pair, total=a.steps), device)
     npy_bytes = written[0]
     assert n_done == a.steps
     prof = {n: _lib.prof_collect(n) for n in probes}
@@ -445,8 +445,8 @@ def main():
     if not a.no_fp32_fit:  # the other fit precision, same timed bracket, fewer images
         k2 = max(2, a.steps // 3)
         set_fit_dtype(other)
-        st.run(jobs(1))
-        n2, el2, _ = D.timed(lambda: st.run(jobs(k2), on_result=write_pair), device)
+        st.run(jobs(1), total=1)
+        n2, el2, _ = D.timed(lambda: st.run(jobs(k2), on_result=write_pair, total=k2), device)
         st.process(lambda slot: None)
         second = {"images_per_s": world * n2 / el2, "images_timed_per_rank": n2,
                   "t_fit_s_serial": st.timings[-1]["t_fit"]}
@@ -458,8 +458,8 @@ def main():
         # round 4 -- with ~2 s per image the pipeline's fill + drain weighed 4 % of a 3-image bracket)
         set_fit_dtype("float32")
         st.extract_dtype = "float32"
-        st.run(jobs(1))  # builds the fp32 weight copies / workspace, warms the pipeline
-        n3, el3, _ = D.timed(lambda: st.run(jobs(5), on_result=write_pair), device)
+        st.run(jobs(1), total=1)  # builds the fp32 weight copies / workspace, warms the pipeline
+        n3, el3, _ = D.timed(lambda: st.run(jobs(5), on_result=write_pair, total=5), device)
         st.process(lambda slot: None)
         t = st.timings[-1]
         full_fp32 = {"images_per_s": n3 / el3, "images_timed": n3, "flow": f"pipelined (depth {a.pipeline_depth})",
@@ -467,8 +467,8 @@ def main():
         # ... and the same with the extractor's matrix products as bf16x3 (`--fp32_matmul high`: torch's float32 matmul
         # precision "high", an opt-in the reference never sets -- reported beside value_fp32, never in its place)
         st.extract_matmul = "high"
-        st.run(jobs(1))
-        n4, el4, _ = D.timed(lambda: st.run(jobs(3), on_result=write_pair), device)
+        st.run(jobs(1), total=1)
+        n4, el4, _ = D.timed(lambda: st.run(jobs(3), on_result=write_pair, total=3), device)
         st.process(lambda slot: None)
         t = st.timings[-1]
         full_fp32["matmul_high"] = {"images_per_s": n4 / el4, "images_timed": n4, "t_extract_s_serial": t["t_extract"],

@@ -18,6 +18,11 @@
 #include "dvt_grid_dev.h"
 
 extern int g_fit_sorted_grid;
+#ifdef DVT_LAB
+// developer library only, dvt_tune_set(15, mask): TIMING-ONLY ablation of the fused step -- bit 0 skips the row kernel, bit 1 the
+// backward kernel, bit 2 the Adam launch (results are wrong by construction; what each launch costs the PIPELINE: tools/r06)
+int g_fit_skip_mask = 0;
+#endif
 int g_fit_lazy_adam = 1;  // dvt_tune_set(9, 0): dense Adam over the whole arena
 int g_fit_shadow_in_adam = 1;  // dvt_tune_set(12, 0): shadow_build_kernel after every Adam launch
 int g_fit_lazy_merge = 1;  // dvt_tune_set(11, 0): catch-up as its own launch
@@ -307,6 +312,9 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
                           gs ? w.gs_keys + gso : nullptr, gs ? w.gs_pay + gso : nullptr, gs ? w.gs_w + gso : nullptr,
                           lazy_e0};
     }
+#ifdef DVT_LAB
+    if (!(g_fit_skip_mask & 1))
+#endif
     DVT_TRY(dvt_fit_rows_k(c, &shl, k, ff, use_res, s));
   } else {
   // ---- forward ----
@@ -353,6 +361,9 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
   }
   if (fused) {
     // ---- everything that reduces over rows in ONE launch: grid backward || weight gradients (+ dG)
+#ifdef DVT_LAB
+    if (!(g_fit_skip_mask & 2))
+#endif
     DVT_TRY(dvt_fit_backward_k(c, k, ff, use_res, s));
   } else {
   // ---- backward: {field layer 2, h layer 3}, {field layer 1, h layer 2}, hash grid, {h layer 1}
@@ -460,6 +471,9 @@ int fit_step(const DvtFitConfig* c, int k, const DvtFitBuffers* const* bs, const
         uc[f] = ws[f].gs_ucount + (size_t)(gs_local + 1) * c->grid.n_levels;
       }
     const bool shadow_in_adam = fused && lazy_next != nullptr && g_fit_shadow_in_adam;
+#ifdef DVT_LAB
+    if (g_fit_skip_mask & 4) return 0;
+#endif
     DVT_TRY(dvt_adam_step_k(&a, k, P, M, V, Gd, touched, s, &gather, g_adam_pingpong ? (step & 1) : 0, lazy_next,
                             lazy_target, uk, uc, shadow_in_adam ? &shl : nullptr, shadow_in_adam ? shadow : nullptr));
     if (shadow_in_adam) return 0;

@@ -855,6 +855,9 @@ extern int g_fit_shadow_in_adam;
 extern int g_adam_pingpong;
 extern int g_fit_rows32;
 extern int g_fit_small_wg;
+#ifdef DVT_LAB
+extern int g_fit_skip_mask;
+#endif
 
 extern "C" int dvt_tune_set(int key, int value) {
   if (key == 0) {
@@ -911,6 +914,12 @@ extern "C" int dvt_tune_set(int key, int value) {
     g_fit_small_wg = value != 0;
     return 0;
   }
+#ifdef DVT_LAB
+  if (key == 15) {  // timing-only ablation mask of the fused fit step (dvt_fit.hip)
+    g_fit_skip_mask = value & 7;
+    return 0;
+  }
+#endif
   if (key == 9) {
     g_fit_lazy_adam = value != 0;
     if (value >= 2) g_fit_lazy_refresh = value;

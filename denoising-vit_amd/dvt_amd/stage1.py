@@ -304,11 +304,27 @@ class Stage1:
         return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
 
     # -- the pipeline --------------------------------------------------------------------------
-    def run(self, jobs, on_result=None, log_every: int = 1000) -> int:
+    @staticmethod
+    def group_plan(total: int | None, kb: int) -> list | None:
+        """Sizes of the fit groups of a run of `total` images (None: unknown -- greedy groups of `kb`).  Groups of `kb` share
+        every fit launch (68-72 instead of 92 us per fit-step), but a group's fits start only when its LAST image is
+        extracted: the run's last group would fit with nothing left to overlap -- 4 fits = 280 ms of a 20-image run.  So
+        the tail tapers: ..., kb, kb, 2, 1, 1 (kb >= 4; 1, 1 for kb 2-3): the last extractions run beside the fits before
+        them and only ONE fit (92 ms) drains alone.  A partial group, if any, goes first."""
+        if total is None or kb <= 1 or os.environ.get("DVT_FIT_TAPER", "1") == "0":  # (the switch: same-box A/B runs)
+            return None
+        tail = [2, 1, 1] if kb >= 4 else [1, 1]
+        if total <= sum(tail):
+            return [1] * total
+        body = total - sum(tail)
+        return ([body % kb] if body % kb else []) + [kb] * (body // kb) + tail
+
+    def run(self, jobs, on_result=None, log_every: int = 1000, total: int | None = None) -> int:
         """jobs: iterable of (tag, set_views) with set_views(slot) filling slot.views / slot.coords
         (called with `s_vit` current).  on_result(tag, raw_host, den_host) is called (on the
         retiring thread) once an image's outputs have landed in pinned memory.  Returns the number
-        of images.
+        of images.  `total`: the number of jobs when the caller knows it (len(jobs) is tried) -- lets the last fit groups
+        taper (group_plan); the results do not depend on the grouping.
 
         Host threads: the EXTRACTOR walks `jobs` and enqueues view synthesis + ViT on `s_vit`; the
         calling thread enqueues the fits on `s_fit`; the RETIRER waits for finished images, hands
@@ -317,6 +333,9 @@ class Stage1:
         the host for most of the fit's duration (the HIP queue holds ~650 launches) and both
         streams idled 25-85 ms per image waiting for it."""
         kb, dev = self.fit_batch, self.device
+        if total is None and hasattr(jobs, "__len__"):
+            total = len(jobs)
+        plan = self.group_plan(total, kb)
         cur = torch.cuda.current_stream(dev)
         for side in (self.s_vit, self.s_fit):  # work queued by the caller (e.g. resident inputs) comes first
             if side != cur:
@@ -392,9 +411,12 @@ class Stage1:
             th.start()
         try:
             last = False
+            gi = 0
             while not last and not errors:
                 group = []
-                while len(group) < kb:
+                want = plan[gi] if plan is not None and gi < len(plan) else kb
+                gi += 1
+                while len(group) < want:
                     slot = ready.get()
                     if slot is None:
                         last = True
@@ -516,7 +538,7 @@ def main(args, rank: int = 0, world: int = 1, stage_factory=None, device=None):
         with open(os.path.join(args.output_dir, f"timings_rank{rank}.jsonl"), "a") as f:
             f.write(json.dumps({"file": filename, "elapsed_s": el}) + "\n")
 
-    done = st.run(jobs(), on_result)
+    done = st.run(jobs(), on_result, total=len(names))
     seconds = time.time() - start
     print(f"[rank {rank}] {done} images in {seconds:.1f}s")
     # the ONE collective of the sweep: per-rank (images, seconds) -> a summary on rank 0

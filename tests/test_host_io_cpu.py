@@ -231,3 +231,22 @@ def test_launch_views_planning_fp32_tiles():
         assert (tiles % 512 == 0) or (tiles % 512) / 512 >= 0.2, (v, tiles % 512)
     assert plan_launches(64, 160, 1408, 768, 3072, fp32=True) == [64]
     assert plan_launches(769, 400) == [398, 371]  # the bf16 plan is untouched
+
+
+def test_fit_group_plan_tapers_the_tail():
+    """Stage1.group_plan (round 6): groups of `fit_batch` images share every fit launch, but a group's fits start only when its
+    last image is extracted -- so the LAST groups of a run of known length taper (..., 4, 4, 2, 1, 1) and only one fit drains
+    with nothing beside it.  Every image is in exactly one group, order preserved, no group larger than the batch."""
+    from dvt_amd.stage1 import Stage1
+    for total in range(0, 40):
+        for kb in (1, 2, 3, 4, 8):
+            plan = Stage1.group_plan(total, kb)
+            if kb <= 1:
+                assert plan is None
+                continue
+            assert sum(plan) == total and all(1 <= g <= kb for g in plan), (total, kb, plan)
+            if total > 4:
+                assert plan[-1] == 1 and plan[-2] == 1, (total, kb, plan)
+    assert Stage1.group_plan(20, 4) == [4, 4, 4, 4, 2, 1, 1]
+    assert Stage1.group_plan(21, 4) == [1, 4, 4, 4, 4, 2, 1, 1]
+    assert Stage1.group_plan(3, 4) == [1, 1, 1] and Stage1.group_plan(None, 4) is None
