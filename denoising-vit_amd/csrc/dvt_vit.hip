@@ -1001,11 +1001,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
   asm volatile("" : "+v"(oa0q), "+v"(oa1q), "+v"(ob0q), "+v"(ob1q))
 #define P8_RSRC(ptr, len) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (len), 0x00020000)
 // stage half H (0 / 1) of operand X (A / B) of k-tile kt through descriptor RS into the slot at byte offset off
+// (P8_AUX_A / P8_AUX_B: cache-policy bits of the two operand streams -- 0 in the product; the developer library's schedules
+// 14 / 15 / 16 set nt (2) on A / W / both: profiles/r06/r06m_*)
 #define P8_STAGE_RS(RS, X, H, kt, off)                                                                                   \
   do {                                                                                                                   \
     const int so_ = (kt) * (GBK * 2) + (H) * h##X;                                                                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, vo##X[0], so_, 0, 0);                    \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, vo##X[1], so_, 0, 0);             \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off)), 16, vo##X[0], so_, 0, P8_AUX_##X);           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr_t)(ldsw + (off) + 8192), 16, vo##X[1], so_, 0, P8_AUX_##X);    \
   } while (0)
 #define P8_STAGE(X, H, kt, off) P8_STAGE_RS(rs##X, X, H, kt, off)
 #define P8_RD(base, off) (*reinterpret_cast<const bf16x8*>((base) + (off)))
@@ -1071,8 +1073,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // STAMP (developer library only, schedule 12): the tile's anatomy in WALL time -- s_memrealtime (100 MHz, not the shader clock:
 // independent of DVFS) at kernel entry, at the first MFMA (prologue done), behind the k-loop, behind the last store's issue and
 // behind its retirement, + HW_ID / XCC_ID (which CU): 8 u32 per workgroup at p.dbg (tools/lab_gemm8p_anatomy.py).
-template <int EPI, bool STAMP = false>
+template <int EPI, bool STAMP = false, int AUX = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel_8p(GemmBArgs p) {
+  constexpr int P8_AUX_A = (AUX & 1) ? 2 : 0, P8_AUX_B = (AUX & 2) ? 2 : 0;  // nt on the A / W stream (lab schedules 14..16)
   __shared__ __attribute__((aligned(16))) char smem[8 * EP_WAVE_BYTES];  // 136 KB >= 8 half-tiles (128 KB)
   unsigned long long ts_[5] = {0, 0, 0, 0, 0};
   if constexpr (STAMP) ts_[0] = __builtin_amdgcn_s_memrealtime();
@@ -1330,6 +1333,12 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_kernel_8t<EPI>), dim3(nwg), dim3(512), 0, s, a);
         lab_done = true;
       }
+    }
+    if (!lab_done && g_vit_gemm_variant >= 14 && g_vit_gemm_variant <= 16) {  // nt on the A (14) / W (15) / both (16) operand streams
+      if (g_vit_gemm_variant == 14) hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, false, 1>), grid8, dim3(512), 0, s, a);
+      else if (g_vit_gemm_variant == 15) hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, false, 2>), grid8, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gemm_bf16_kernel_8p<EPI, false, 3>), grid8, dim3(512), 0, s, a);
+      lab_done = true;
     }
     if (!lab_done && g_vit_gemm_variant == 12) {  // the product kernel's tile anatomy (wall-clock stamps per workgroup)
       a.dbg = g_vit_dbg;
@@ -2051,7 +2060,7 @@ int dvt_vit_tune(int v) {
     return 0;
   }
 #ifdef DVT_LAB
-  if (v < 0 || v > 13) return DVT_E_BADARG;
+  if (v < 0 || v > 16) return DVT_E_BADARG;
   g_vit_abl4w = g_vit_8p_build = 0;  // an ablation / timing build never survives a change of schedule
 #else
   if (v != 1 && v != 3 && v != 4) return DVT_E_BADARG;
