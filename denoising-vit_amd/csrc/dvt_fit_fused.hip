@@ -37,6 +37,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int g_fit_rows32 = 1;  // dvt_tune_set(13, v), see launch_rows
+int g_fit_xcd_affinity = 1;  // dvt_tune_set(16, v): the row kernel's fit -> XCD map for 2 / 4 fits per launch (fit_rows_kernel) on / off
 int g_fit_small_wg = 0;  // dvt_tune_set(14, v): 1 = 4-wave fit_rows + 8-wave fit_backward workgroups (same arithmetic, same results)
 
 namespace {
@@ -65,6 +66,7 @@ struct FusedArgs {
   DvtShadowLayout S;
   DvtTLayout TL;
   int n, lattice;
+  int xcd_group;  // XCDs per fit of the row kernel's block -> (fit, row block) map: 8 / k for k = 2, 4 fits per launch, else 0 (see fit_rows_kernel)
   float grad_scale;
   long long off_grid, off_b1, off_b2, off_G, off_bh1, off_bh2, off_bh3;
   DvtFusedFit f[DVT_FIT_BATCH_MAX];
@@ -235,10 +237,24 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
   static_assert(L::TOTAL <= 160 * 1024, "LDS images of the row kernel");
   constexpr int H = C / 2, R = C / 4, E = FE, cq = C / 4;
   __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
-  const DvtFusedFit& f = a.f[blockIdx.y];
+  // Block -> (fit, row block).  Workgroups go round-robin to the 8 XCDs (private 4-MB L2s) and every workgroup streams its fit's
+  // whole weight shadow (2.4-4.8 MB) from L2.  With k fits per launch and the plain (x, y) map every XCD hosts row blocks of
+  // ALL k fits: 10-19 MB of weights through each 4-MB L2 -- they come from the memory side instead.  Round 6: fit f owns the
+  // XCDs [f * 8 / k, (f + 1) * 8 / k) (k = 2, 4): an L2 sees ONE fit's weights, 16-32 workgroups re-use every line.  Placement
+  // (workgroup b on XCD b % 8) is an assumption for speed only; the map is a bijection whatever the placement.
+  int fit_, rb_;
+  if (a.xcd_group > 0) {
+    const int lin = (int)blockIdx.x + (int)blockIdx.y * (int)gridDim.x, xcd = lin & 7, j = lin >> 3;
+    fit_ = xcd / a.xcd_group;
+    rb_ = j * a.xcd_group + xcd % a.xcd_group;
+  } else {
+    fit_ = (int)blockIdx.y;
+    rb_ = (int)blockIdx.x;
+  }
+  const DvtFusedFit& f = a.f[fit_];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * FR;
+  const int row0 = rb_ * FR;
   const char* __restrict__ sh = static_cast<const char*>(f.shadow);  // byte pointer: element offsets below are scaled by ES
   const float* __restrict__ P = f.params;
   const float4* __restrict__ feat4 = reinterpret_cast<const float4*>(f.feat);
@@ -264,8 +280,11 @@ __global__ __launch_bounds__(64 * FW) void fit_rows_kernel(FusedArgs a) {
     }
   }
   {
-    const int nslot = (int)gridDim.x >= 128 ? 16 : ((int)gridDim.x + 7) / 8;
-    const int slot = ((int)blockIdx.x >> 3) % nslot;
+    // (the workgroups of one XCD that walk the same fit's weights share the warm-up: 8 per fit and XCD with the plain map at 16
+    // rows, gridDim.x / xcd_group with the fit -> XCD map)
+    const int per_xcd = a.xcd_group > 0 ? (int)gridDim.x / a.xcd_group : ((int)gridDim.x + 7) / 8;
+    const int nslot = per_xcd >= 16 ? 16 : per_xcd;
+    const int slot = (a.xcd_group > 0 ? rb_ / a.xcd_group : (rb_ >> 3)) % nslot;
     const long long lines = ((PH2 ? a.S.total : a.S.direct[2]) * ES + 127) / 128;
     const long long per = (lines + nslot - 1) / nslot;
     const long long l0 = slot * per, l1 = l0 + per < lines ? l0 + per : lines;
@@ -672,19 +691,22 @@ int launch_rows(const FusedArgs& a, int k, bool phase2, hipStream_t s) {
   const bool r32 = fits32 && a.n % 32 == 0 && (g_fit_rows32 == 2 || (g_fit_rows32 == 1 && k >= 4));
   const bool small = g_fit_small_wg && !r32;
   dim3 grid(a.n / (r32 ? 32 : 16), k), block(64 * (small ? 4 : FW8));
+  FusedArgs ax = a;  // (the fit -> XCD map needs whole groups of 8 / k row blocks)
+  ax.xcd_group = (g_fit_xcd_affinity && (k == 2 || k == 4) && grid.x % (8 / k) == 0 && (grid.x * k) % 8 == 0) ? 8 / k : 0;
+  const FusedArgs& a_ = ax;
   if (r32) {
     if (phase2) {
-      if constexpr (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, true, 32, FW8>), grid, block, 0, s, a);
+      if constexpr (FusedLds<C, true, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, true, 32, FW8>), grid, block, 0, s, a_);
     } else {
-      if constexpr (FusedLds<C, false, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, false, 32, FW8>), grid, block, 0, s, a);
+      if constexpr (FusedLds<C, false, 32>::TOTAL <= 160 * 1024) hipLaunchKernelGGL((fit_rows_kernel<C, false, 32, FW8>), grid, block, 0, s, a_);
     }
   } else if (small) {
-    if (phase2) hipLaunchKernelGGL((fit_rows_kernel<C, true, 16, 4>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((fit_rows_kernel<C, false, 16, 4>), grid, block, 0, s, a);
+    if (phase2) hipLaunchKernelGGL((fit_rows_kernel<C, true, 16, 4>), grid, block, 0, s, a_);
+    else hipLaunchKernelGGL((fit_rows_kernel<C, false, 16, 4>), grid, block, 0, s, a_);
   } else if (phase2) {
-    hipLaunchKernelGGL((fit_rows_kernel<C, true, 16, FW8>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((fit_rows_kernel<C, true, 16, FW8>), grid, block, 0, s, a_);
   } else {
-    hipLaunchKernelGGL((fit_rows_kernel<C, false, 16, FW8>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((fit_rows_kernel<C, false, 16, FW8>), grid, block, 0, s, a_);
   }
   DVT_CHECK_LAUNCH();
   return 0;

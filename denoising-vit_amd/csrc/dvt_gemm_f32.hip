@@ -855,6 +855,7 @@ extern int g_fit_shadow_in_adam;
 extern int g_adam_pingpong;
 extern int g_fit_rows32;
 extern int g_fit_small_wg;
+extern int g_fit_xcd_affinity;
 #ifdef DVT_LAB
 extern int g_fit_skip_mask;
 #endif
@@ -912,6 +913,10 @@ extern "C" int dvt_tune_set(int key, int value) {
   }
   if (key == 14) {
     g_fit_small_wg = value != 0;
+    return 0;
+  }
+  if (key == 16) {
+    g_fit_xcd_affinity = value != 0;
     return 0;
   }
 #ifdef DVT_LAB

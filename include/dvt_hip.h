@@ -301,6 +301,8 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         equal bit for bit, tests/test_gpu_fit.py::test_fp32_lazy_adam_vs_dense_sweep); touched entries carry the summation
  *         order of the gathered grid gradient, run-to-run rounding noise in either mode --, 0 = dense Adam over the whole arena,
  *         n >= 2 = lazy with a full refresh every n steps (default 32);
+ * key 16 = fit step with 2 or 4 fits per launch (dvt_fit_run_batched): 1 (default, round 6) the row kernel maps fit f to the XCDs
+ *         [8 f / k, 8 (f + 1) / k) so that an XCD's L2 streams ONE fit's weights, 0 = the plain (row block, fit) grid; same results;
  * key 12 = the merged Adam launch also stores the bf16 weight shadow (1, default) or shadow_build_kernel runs (0);
  * key 11 = the lazy catch-up of the next step shares the Adam launch (1, default) or is its own launch (0);
  * key 10 = lazy Adam replay arithmetic: 0 (default) v_rcp_f32 / v_sqrt_f32 (1 ulp each), an APPROXIMATION of the
