@@ -27,7 +27,7 @@ def _fake_stage(rank):
             self.vit = SimpleNamespace(transformation=SimpleNamespace(transforms=[norm]))
             self.pos_h = self.pos_w = 2
 
-        def run(self, jobs, on_result):
+        def run(self, jobs, on_result, total=None):
             n = 0
             for tag, _set_views in jobs:
                 on_result(tag, np.full((2, 2, 4), rank, np.float32), np.full((1, 2, 2, 4), rank, np.float32))
