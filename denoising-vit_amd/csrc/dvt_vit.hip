@@ -100,6 +100,8 @@ struct GemmBArgs {
   // ... producer side (EPI_RESID): besides x, emit bf16(x) and the per-row partial sums of this 64-column block
   bf16_t* xb;              // [M, N]
   float2* st_part;         // [N / 64][M] (sum, sum of squares)
+  float q_scale;      // EPI_QKV: the q columns (n < dim) leave multiplied by this (log2(e) / 8 for the log2-domain attention
+                      // kernel); 0 = as they are
   int dim_ok_sq;      // 256-wide tiles may be used (no q|k|v boundary inside a tile)
   int lda, ldw;       // leading dimensions (elements) of A and W; 0 = K
   double work;        // profiling probe: ALGORITHMIC flops of this launch (0: 2*M*N*K of the padded shape)
@@ -283,6 +285,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBArgs& p, f32x4 (&acc)[4
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias;
+      if (EPI == EPI_QKV && p.q_scale != 0.f && n < p.dim) {  // q columns for the log2-domain attention kernel (tile-uniform)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.q_scale;
+      }
       if (EPI == EPI_RESID) {
         const float gm = p.gamma[n];
 #pragma unroll
@@ -549,6 +555,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
   } else {
     const int ldo = (IS_QKV(EPI)) ? 2 * p.dim : p.N;
     const int c8 = (lane & 7) * 8;  // 8 lanes x 8 columns = one row; 8 rows per pass
+    const float qsc = (EPI == EPI_QKV && nb < p.dim) ? p.q_scale : 0.f;  // (wave-uniform: a 64-column block is q, k or v)
     // (GELU: one row at a time -- four rows of erf polynomials in flight took the fc1 kernel to 254 VGPRs,
     // and at 2 x 256 registers per SIMD no wave of the fit's streaming kernels can share the CU)
 #pragma unroll(IS_GELU(EPI) ? 1 : 4)
@@ -573,6 +580,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
         gelu_erf_pair(a.z, a.w);
         gelu_erf_pair(b.x, b.y);
         gelu_erf_pair(b.z, b.w);
+      }
+      if (EPI == EPI_QKV && qsc != 0.f) {  // q columns (tile-uniform): * log2(e) / 8 on the fp32 value, ONE rounding to bf16 as before
+        a.x *= qsc; a.y *= qsc; a.z *= qsc; a.w *= qsc;
+        b.x *= qsc; b.y *= qsc; b.z *= qsc; b.w *= qsc;
       }
       uint4 pk;
       pk.x = pack2(a.x, a.y);
@@ -1230,8 +1241,13 @@ int g_vit_attn_mask = 15;
 // dvt_tune_set(1, -700 - pct): the first round of 8p workgroups starts spread over pct % of the modelled tile time (k-loop
 // 1.68 us per k-tile + epilogue); 0 = all together
 int g_vit_stagger_pct = 0;
+// dvt_tune_set(1, -531) (default) / (1, -530): dvt_vit_forward's qkv GEMM writes q * log2(e) / 8 and the attention kernel works
+// in the log2 domain (attention_v2_body, VAR bit 32) / q as it is and the round-3..5 kernel
+int g_vit_attn_log2q = 1;
+constexpr float ATT_Q_PRESCALE = 0.125f * 1.4426950408889634f;
 #ifdef DVT_LAB
 int g_vit_tpw = 0;           // 4w kernel: target tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
+int g_vit_attn_l2_mask = 47;  // dvt_tune_set(1, -540 - extra): ablation builds of the log2-domain attention kernel (47 + 128 / 256 / 384)
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = attention_kernel_v2, 1 = the round-2 kernel
 int g_vit_abl4w = 0;         // dvt_tune_set(1, -300 - mask) while a 4w schedule (6..9) is selected: its ablation mask (EPI_BIAS, timing only)
 int g_vit_8p_build = 0;      // ... while schedule 5 is selected: timing build of the 8p kernel (3 stamps, 6..9 ablations; EPI_BIAS only)
@@ -1523,6 +1539,14 @@ constexpr int ATT2_KBUF = 3;
 //   8  tile loop unrolled by two (S / S-next swap roles instead of being copied)
 //   16 static priority for the second-dispatched half of the workgroup (waves 4-7)
 //   64 two barriers per tile, waves 4-7 one phase behind waves 0-3 (softmax of one group over P.V of the other)
+//   32 (round 6, needs 4) "log2 domain": q arrives PRE-SCALED by log2(e) / 8 (the qkv GEMM's epilogue does it on the fp32
+//      accumulators, one rounding to bf16 as before), so S' = K.Q'^T is the logit in units of log2, and the S MFMA chain starts
+//      from C = -m (the running max, one register quad) instead of 0: the accumulators hold t = s' - m and P = v_exp_f32(t)
+//      with NO scale-and-subtract FMA (8 v_pk_fma_f32 of a tile's ~45 VALU issues; the kernel is VALU-issue bound: 16 quarter-rate
+//      v_exp + ~30 others against 16 MFMAs per wave and tile).  Tile 0's exact max is formed in the prologue; when the running
+//      max grows later (rare: the lane's 16-term row sum left [0, e^8]) this tile's t AND the already issued next tile's are
+//      lowered by the growth.  Waves wholly behind the image's rows (s_pad < the block's 128 queries) stage and synchronise
+//      but neither multiply nor exponentiate, and a last tile with <= 32 valid keys runs its softmax and P.V on half a tile.
 // X3 (the fp32 extractor's opt-in "bf16x3" mode, include/dvt_vit.h): q, k, v arrive as (hi, lo) bf16 pairs of the fp32
 // values (qk / vt = hi, qk_lo / vt_lo = lo), S = K_lo.Q_hi + K_hi.Q_lo + K_hi.Q_hi and O += V_lo.P_hi + V_hi.P_lo + V_hi.P_hi
 // with P split in registers (3 x the MFMAs, fp32 accumulation, fp32 softmax as before) and `out` is fp32 [T, dim].
@@ -1532,6 +1556,9 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
                                                   const bf16_t* __restrict__ qk_lo, const bf16_t* __restrict__ vt_lo,
                                                   int split_out = 0) {
   constexpr int NV = (VAR & 64) ? 3 : 2;  // V^T buffers: the half-tile offset of the two wave groups needs a third
+  constexpr bool L2D = (VAR & 32) != 0;
+  constexpr bool SKIPW = L2D && !(VAR & 128), HALFT = L2D && !(VAR & 256);  // (128 / 256: ablation builds without the idle waves / the half tail tile)
+  static_assert(!L2D || ((VAR & 4) && !X3 && !(VAR & 64)), "log2-domain build: on the no-max-tree structure, bf16 only");
   constexpr int KSET = ATT2_KBUF * KV_TILE * 128, VSET = NV * 64 * VT_LD;  // one precision part: 24 KB + 16 KB
   __shared__ __attribute__((aligned(16))) char smem[(X3 ? 2 : 1) * (KSET + VSET)];
   char* const Kb = smem;
@@ -1557,11 +1584,13 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
     for (int ks = 0; ks < 2; ++ks) {
       union { bf16x8 v; uint32_t u[4]; } raw;
       raw.v = *reinterpret_cast<const bf16x8*>(qrow + ks * 32 + g * 8);
+      if constexpr (!L2D) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float lo = __uint_as_float(raw.u[j] << 16) * 0.125f;
-        const float hi = __uint_as_float(raw.u[j] & 0xffff0000u) * 0.125f;
-        raw.u[j] = pack2(lo, hi);
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __uint_as_float(raw.u[j] << 16) * 0.125f;
+          const float hi = __uint_as_float(raw.u[j] & 0xffff0000u) * 0.125f;
+          raw.u[j] = pack2(lo, hi);
+        }
       }
       dst[ks] = raw.v;
     }
@@ -1574,7 +1603,12 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   f32x4 o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = L2D ? 0.f : -1e30f, l_run = 0.f;  // (L2D: in units of log2; tile 0's exact max is formed in the prologue)
+  f32x4 cinit = (f32x4){0.f, 0.f, 0.f, 0.f};      // L2D: -m_run in every element, the C operand an S chain starts from
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // L2D: a wave whose 16 queries lie wholly behind the image's rows (the last block of an image where s_pad % 128 != 0)
+  // only stages and synchronises (wave-uniform)
+  const bool active = !SKIPW || qb * ATT_Q + __builtin_amdgcn_readfirstlane(wave) * 16 < s_pad;
   const float LOG2E = 1.4426950408889634f;
   const float THR = 8.0f;
 
@@ -1645,13 +1679,13 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                         \
           const int krow = mt * 16 + lc;                                                                           \
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks_ + krow * 128 + (((ks * 4 + g) ^ (krow & 7)) << 4)); \
-          if (ks == 0) dst[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                      \
+          if (ks == 0) dst[mt] = L2D ? cinit : zero4;                                                              \
           dst[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], dst[mt], 0, 0, 0);                         \
         }                                                                                                          \
       }                                                                                                            \
     } else {                                                                                                       \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                             \
-      dst[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                       \
+      dst[mt] = L2D ? cinit : zero4;                                                                               \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
         const int krow = mt * 16 + lc;                                                                             \
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks_ + krow * 128 + (((ks * 4 + g) ^ (krow & 7)) << 4)); \
@@ -1674,7 +1708,42 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   if (ntiles > 1) A2_LOADV(1);
   __syncthreads();
   f32x4 sA[4], sB[4];
-  A2_S(sA, 0);
+  // the exact maximum of a query's logits over its 4 lanes (lc + 16 g): swap rows 0<->1 / 2<->3, then the wave halves (no LDS)
+  auto lane_quad_max = [&](float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+    const unsigned u2 = __float_as_uint(v);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    return fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+  };
+  auto max16 = [&](const f32x4 (&s)[4]) {
+    float tmax = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[0][2]);
+    tmax = max3f(tmax, s[0][3], s[1][0]);
+    tmax = max3f(tmax, s[1][1], s[1][2]);
+    tmax = max3f(tmax, s[1][3], s[2][0]);
+    tmax = max3f(tmax, s[2][1], s[2][2]);
+    tmax = max3f(tmax, s[2][3], s[3][0]);
+    tmax = max3f(tmax, s[3][1], s[3][2]);
+    return fmaxf(tmax, s[3][3]);
+  };
+  if (active) A2_S(sA, 0);
+  if constexpr (L2D) {
+    if (active) {
+      // tile 0: the running max starts at the tile's exact max (every later tile only checks that nothing grew past e^8)
+      if (n_valid < KV_TILE) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (mt * 16 + 4 * g + r >= n_valid) sA[mt][r] = -1e30f;
+      }
+      m_run = lane_quad_max(max16(sA));
+      cinit = (f32x4){-m_run, -m_run, -m_run, -m_run};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) sA[mt] += cinit;
+    }
+  }
   if constexpr (VAR & 16) {
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   }
@@ -1705,6 +1774,25 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
     // exact running max over the query's 4 lanes (lc + 16 g) + rescale of o, l (everything still at the old max is scaled
     // exactly once: P.V of the previous tile is complete)
     auto exact_max = [&]() {
+      if constexpr (L2D) {
+        // s holds t = s' - m_run: the max grows by d = max(t) where that is positive; everything that was formed against
+        // the old max is lowered by d -- o and l (scaled by 2^-d; P.V of the previous tile is complete), this tile's t, and
+        // the NEXT tile's, whose chain already started from the old -m_run
+        const float d = fmaxf(lane_quad_max(max16(s)), 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+        m_run += d;
+        cinit = (f32x4){-m_run, -m_run, -m_run, -m_run};
+        const f32x4 d4 = {d, d, d, d};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          s[mt] -= d4;
+          if constexpr (!LAST) sn[mt] -= d4;
+        }
+        return;
+      }
       float tmax = __builtin_fmaxf(__builtin_fmaxf(s[0][0], s[0][1]), s[0][2]);
       tmax = max3f(tmax, s[0][3], s[1][0]);
       tmax = max3f(tmax, s[1][1], s[1][2]);
@@ -1761,6 +1849,48 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         m_run = m_new;
       }
     }
+    if constexpr (HALFT && LAST) {
+      if (n_valid - kt * KV_TILE <= 32) {
+        // (wave-uniform) keys 32..63 of the last tile are all padding (ViT-B/14 at 518 px: 1370 = 21 x 64 + 26): softmax, pack
+        // and P.V on the tile's first k-half only -- 8 v_exp, one P fragment, 4 V^T fragments, 4 MFMAs
+        float hp[2][4];
+        f32x2 hs2;
+        auto half_softmax = [&]() {
+          hs2 = (f32x2){0.f, 0.f};
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              f32x2 e;
+              e.x = __builtin_amdgcn_exp2f(s[mt][2 * h2]);
+              e.y = __builtin_amdgcn_exp2f(s[mt][2 * h2 + 1]);
+              hs2 += e;
+              hp[mt][2 * h2] = e.x;
+              hp[mt][2 * h2 + 1] = e.y;
+            }
+        };
+        half_softmax();
+        float hsum = hs2.x + hs2.y;
+        if (!__all(hsum <= 2980.0f)) {
+          exact_max();
+          half_softmax();
+          hsum = hs2.x + hs2.y;
+        }
+        l_run += hsum;
+        union { bf16x8 v; uint32_t u[4]; } hf;
+        hf.u[0] = pack2(hp[0][0], hp[0][1]); hf.u[1] = pack2(hp[0][2], hp[0][3]);
+        hf.u[2] = pack2(hp[1][0], hp[1][1]); hf.u[3] = pack2(hp[1][2], hp[1][3]);
+        const char* Vh = Vb + (kt % NV) * (64 * VT_LD);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vh + vr * VT_LD + ((g ^ vs_) << 4));
+          o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, hf.v, o[mt], 0, 0, 0);
+        }
+        __syncthreads();
+        return;
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!LAST) A2_S(sn, kt + 1);  // K(kt+1) became visible at the previous barrier (or in the prologue)
     const f32x2 l2e2 = {LOG2E, LOG2E};
@@ -1775,7 +1905,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const f32x2 sv = {s[mt][2 * h2], s[mt][2 * h2 + 1]};
-          const f32x2 t = __builtin_elementwise_fma(sv, l2e2, nmb2);
+          const f32x2 t = L2D ? sv : __builtin_elementwise_fma(sv, l2e2, nmb2);
           f32x2 e;
           e.x = __builtin_amdgcn_exp2f(t.x);
           e.y = __builtin_amdgcn_exp2f(t.y);
@@ -1808,7 +1938,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
 #pragma unroll
       for (int i = 0; i < (X3 ? 24 : 8); ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, X3 ? 4 : (VAR & 4) ? 5 : 6, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, (X3 || L2D) ? 4 : (VAR & 4) ? 5 : 6, 0);  // VALU
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1868,6 +1998,19 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
     }
     __syncthreads();
   };
+  if constexpr (SKIPW) {
+    if (!active) {
+      // an idle wave's loop: its share of the staging and the tile barriers (s_barrier counts arrivals, whatever the PC)
+      for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt + 2 < ntiles) A2_STOREK(kt + 2);
+        if (kt + 1 < ntiles) A2_STOREV(kt + 1);
+        if (kt + 3 < ntiles) A2_LOADK(kt + 3);
+        if (kt + 2 < ntiles) A2_LOADV(kt + 2);
+        __syncthreads();
+      }
+      return;
+    }
+  }
   if constexpr (VAR & 8) {
     int kt = 0;
     for (; kt + 2 <= ntiles - 1; kt += 2) {
@@ -1941,6 +2084,15 @@ __global__ __launch_bounds__(512) void attention_kernel_v2(const bf16_t* __restr
                                                            bf16_t* __restrict__ out, int heads, int s_pad, int n_valid) {
   attention_v2_body<VAR, false>(qk, vt, out, heads, s_pad, n_valid, nullptr, nullptr);
 }
+// the log2-domain builds (VAR bit 32).  Left alone hipcc takes 134-136 registers for them (the -m quad, twice in the loop
+// unrolled by two) = ONE workgroup per CU; told to fit four waves per SIMD it parks three dwords (the output row pointer, across
+// the loop) and a few more in the last-tile code in scratch and keeps the tile loop free of scratch traffic (ISA checked).
+template <int VAR>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_kernel_l2(
+    const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int heads, int s_pad, int n_valid) {
+  static_assert(VAR & 32, "log2-domain builds only");
+  attention_v2_body<VAR, false>(qk, vt, out, heads, s_pad, n_valid, nullptr, nullptr);
+}
 // the split-operand build: 156 registers, one 80-KB workgroup per CU (capped at 128 registers -- 24 dwords of scratch,
 // two workgroups per CU -- it measured 1.71-1.76 ms per 64 views against 1.30-1.53: dropped)
 __global__ __launch_bounds__(512) void attention_kernel_v2_x3(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
@@ -2010,6 +2162,10 @@ int dvt_vit_tune(int v) {
     g_vit_nt_store = v == -51;
     return 0;
   }
+  if (v == -530 || v == -531) {  // bf16 extractor: attention on q as it is (-530) / on q pre-scaled by log2(e) / 8 (-531, default)
+    g_vit_attn_log2q = v == -531;
+    return 0;
+  }
   if (v == -520 || v == -521) {  // fp32 extractor, bf16x3 mode: exact-fp32 attention (-520) / bf16x3 attention (-521, default)
     g_f32x3_exact_attention = v == -520;
     return 0;
@@ -2023,7 +2179,15 @@ int dvt_vit_tune(int v) {
     g_vit_w4_grid = v > -700 ? -600 - v : -1100 - v;
     return 0;
   }
-  if (v <= -510 && v > -600) {
+  if (v == -540 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384) {
+    g_vit_attn_l2_mask = 47 + (-540 - v);
+    return 0;
+  }
+  if (v <= -510 && v > -530) {
+    g_vit_attn_mask = -510 - v;
+    return 0;
+  }
+  if (v == -510 - 31 || v == -510 - 64 || v == -510 - 79) {
     g_vit_attn_mask = -510 - v;
     return 0;
   }
@@ -2228,6 +2392,35 @@ extern "C" int dvt_vit_layernorm(const float* x, const float* w, const float* b,
   return 0;
 }
 
+// q pre-scaled by log2(e) / 8 (see attention_v2_body, VAR bit 32): the kernel dvt_vit_forward launches since round 6
+extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out, int batch, int heads,
+                                       int s_pad, int n_valid, void* stream) {
+  if (!qk || !vt || !out || batch <= 0 || heads <= 0 || s_pad % 16 || n_valid <= 0 || n_valid > s_pad)
+    return DVT_E_BADARG;
+  DvtProbeScope probe(DVT_PROBE_VIT_ATTN, (hipStream_t)stream,
+                      4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
+  const dim3 grid(((s_pad + ATT_Q - 1) / ATT_Q) * heads * batch);
+#ifdef DVT_LAB
+  if (g_vit_attn_l2_mask == 47 + 128 || g_vit_attn_l2_mask == 47 + 256 || g_vit_attn_l2_mask == 47 + 384) {  // ablation builds
+    if (g_vit_attn_l2_mask == 47 + 128)
+      hipLaunchKernelGGL(attention_kernel_l2<47 + 128>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
+                         (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
+    else if (g_vit_attn_l2_mask == 47 + 256)
+      hipLaunchKernelGGL(attention_kernel_l2<47 + 256>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
+                         (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
+    else
+      hipLaunchKernelGGL(attention_kernel_l2<47 + 384>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
+                         (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
+    DVT_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
+  hipLaunchKernelGGL(attention_kernel_l2<47>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
+                     (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads,
                                  int s_pad, int n_valid, void* stream) {
   if (!qk || !vt || !out || batch <= 0 || heads <= 0 || s_pad % 16 || n_valid <= 0 || n_valid > s_pad)
@@ -2405,6 +2598,10 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
                        c->ln_eps);
     DVT_CHECK_LAUNCH();
   }
+  bool log2q = g_vit_attn_log2q != 0;
+#ifdef DVT_LAB
+  log2q = log2q && g_vit_attn_variant == 2 && g_vit_attn_mask == 15;  // (the superseded kernels and schedule masks take q as it is)
+#endif
   for (int l = 0; l < n_blocks; ++l) {
     const DvtVitBlockWeights& bw = w->blocks[l];
     if (!fuse_ln) DVT_TRY(dvt_vit_layernorm(k.x, bw.norm1_w, bw.norm1_b, k.xn, T, D, c->ln_eps, s));
@@ -2415,9 +2612,11 @@ extern "C" int dvt_vit_forward(const DvtVitConfig* c, const DvtVitWeights* w, co
       if (fuse_ln) { a.ln_stats = k.stats; a.ln_cs = bw.qkv_cs; }
       a.dim = D; a.heads = c->heads; a.s_pad = c->s_pad; a.n_tokens = c->n_tokens;
       a.work = 2.0 * rows * 3.0 * D * D;
+      a.q_scale = log2q ? ATT_Q_PRESCALE : 0.f;
       DVT_TRY(launch_gemm<EPI_QKV>(a, s));
     }
-    DVT_TRY(dvt_vit_attention(k.qk, k.vt, k.xn, batch, c->heads, c->s_pad, c->n_tokens, s));
+    if (log2q) DVT_TRY(dvt_vit_attention_log2q(k.qk, k.vt, k.xn, batch, c->heads, c->s_pad, c->n_tokens, s));
+    else DVT_TRY(dvt_vit_attention(k.qk, k.vt, k.xn, batch, c->heads, c->s_pad, c->n_tokens, s));
     {
       GemmBArgs a{};
       a.A = k.xn; a.W = (const bf16_t*)bw.proj_w; a.M = T; a.N = D; a.K = D;

@@ -49,6 +49,7 @@ _lib.register_signatures({
     "dvt_vit_gemm_lnfold": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "dvt_vit_layernorm": (_I, [_P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "dvt_vit_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dvt_vit_attention_log2q": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dvt_vit_workspace_bytes_f32": (C.c_int64, [C.POINTER(VitConfig), _I]),
     "dvt_vit_forward_f32": (_I, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _P, _I, _I, _P, _P]),
     "dvt_vit_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -273,14 +273,19 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *             spread over pct % of the modelled tile time (round 5: no gain; results do not depend on it);
  *           -520 / -521 and -522 / -523: inside dvt_vit_forward_f32x3, exact-fp32 attention on / off [off] and split kernels
  *             instead of split epilogues on / off [off];
- *           -502 and -525 (= -510 - 15): the one attention kernel / schedule mask the product contains (accepted, no effect).
- *         None of these changes a result beyond summation order (fp32 row statistics of the folded LayerNorm, ~1e-7 relative).
+ *           -502 and -525 (= -510 - 15): the one attention kernel / schedule mask the product contains (accepted, no effect);
+ *           -531 [default] / -530 (round 6): inside dvt_vit_forward the qkv GEMM writes q * log2(e) / 8 and the log2-domain
+ *             attention kernel runs (dvt_vit_attention_log2q, include/dvt_vit.h) / q as it is and dvt_vit_attention.  The two
+ *             differ in WHICH bf16 value q rounds to (q against q * 0.18033688: one rounding each), i.e. by the bf16 rounding
+ *             noise of the logits, not in error class (tests/test_gpu_vit.py holds both against the fp32 oracle).
+ *         None of the others changes a result beyond summation order (fp32 row statistics of the folded LayerNorm, ~1e-7 relative).
  *         Developer builds (-DDVT_LAB, csrc/lab/, include/dvt_vit.h) add: schedules 0, 2 (superseded), 13 (round 5's walk of the
  *         8-phase ring) and 5, 10 (re-schedules of it), 11 (the product's kernel as a persistent workgroup with an overlapped
  *         tile boundary) -- all bit-identical to 4 --, 6..9 (4-wave persistent kernel; 8 / 9 with an approximate GELU),
  *         -200 - n / -600 - n (tiles per workgroup of 6..9 and 11 / grid of 6..9), -300 - n (ablation mask of the selected 4-wave schedule, or timing build of schedule 5:
  *         TIMING ONLY, results wrong by construction; reset by every change of schedule), -501 (round-2 attention loop),
- *         -510 - mask (attention schedule masks);
+ *         -510 - mask (attention schedule masks; any of these also selects q as it is), -540 - 128 / 256 / 384 (ablation builds
+ *         of the log2-domain attention kernel: idle waves not skipped / no half tail tile / neither; -540 = the product's);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);

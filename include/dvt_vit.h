@@ -160,6 +160,14 @@ int dvt_vit_layernorm(const float* x, const float* w, const float* b, void* y, i
  * 128 rows of qk allocated behind the last image (dvt_vit_workspace_bytes does).  vt is never read behind a row's s_pad keys. */
 int dvt_vit_attention(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
                       int n_valid, void* stream);
+/* The same attention on q rows PRE-SCALED by log2(e) / 8 -- qk's q half = bf16(q * 0.18033688...), what dvt_vit_forward's qkv
+ * GEMM writes since round 6 (one rounding to bf16, as for the unscaled q; dvt_tune_set(1, -530) restores q as it is +
+ * dvt_vit_attention inside dvt_vit_forward, -531 = default): the logits come out of the matrix pipe in units of log2 with the
+ * running max already subtracted (the S accumulation starts from -max), so a probability is ONE v_exp_f32 -- the kernel is
+ * VALU-issue bound at head_dim 64.  Waves behind an image's rows only stage, a last key tile with <= 32 valid keys is half a
+ * tile.  Same layouts, same read-behind contract, same argument checks as dvt_vit_attention.                              */
+int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out, int batch, int heads, int s_pad,
+                            int n_valid, void* stream);
 
 /* Developer builds (no reference counterpart).  The product library libdvt_hip.so contains only the kernels the extractor
  * launches; superseded schedules, experiments and timing builds live under csrc/lab/ and are compiled only with -DDVT_LAB
