@@ -1245,9 +1245,11 @@ int g_vit_stagger_pct = 0;
 // in the log2 domain (attention_v2_body, VAR bit 32) / q as it is and the round-3..5 kernel
 int g_vit_attn_log2q = 1;
 constexpr float ATT_Q_PRESCALE = 0.125f * 1.4426950408889634f;
+constexpr int ATT_L2_VAR = 45;  // schedule mask of the log2-domain attention kernel the product launches (attention_v2_body)
 #ifdef DVT_LAB
 int g_vit_tpw = 0;           // 4w kernel: target tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
-int g_vit_attn_l2_mask = 47;  // dvt_tune_set(1, -540 - extra): ablation builds of the log2-domain attention kernel (47 + 128 / 256 / 384)
+int g_vit_attn_l2_mask = ATT_L2_VAR;  // dvt_tune_set(1, -540 - x): builds of the log2-domain attention kernel: x = 0 the product's (mask 45), 2 = with
+                                      // all eight V^T fragments read first (47), 128 / 256 / 384 = ablations (idle waves compute / whole tail tile / both)
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = attention_kernel_v2, 1 = the round-2 kernel
 int g_vit_abl4w = 0;         // dvt_tune_set(1, -300 - mask) while a 4w schedule (6..9) is selected: its ablation mask (EPI_BIAS, timing only)
 int g_vit_8p_build = 0;      // ... while schedule 5 is selected: timing build of the 8p kernel (3 stamps, 6..9 ablations; EPI_BIAS only)
@@ -1559,7 +1561,11 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   constexpr bool L2D = (VAR & 32) != 0;
   constexpr bool SKIPW = L2D && !(VAR & 128), HALFT = L2D && !(VAR & 256);  // (128 / 256: ablation builds without the idle waves / the half tail tile)
   static_assert(!L2D || ((VAR & 4) && !X3 && !(VAR & 64)), "log2-domain build: on the no-max-tree structure, bf16 only");
-  constexpr int KSET = ATT2_KBUF * KV_TILE * 128, VSET = NV * 64 * VT_LD;  // one precision part: 24 KB + 16 KB
+  // K buffers: three suffice (K runs two tiles ahead); the log2-domain build takes FOUR and walks the tiles in an unrolled
+  // loop of four whose counter is a multiple of 4, so that every buffer index ((kt + c) & 3, (kt + c) & 1) is a literal and the
+  // LDS addresses are lane constants + immediates (with three buffers each tile spent ~8 VALU + SALU issues on slot offsets)
+  constexpr int KBUF = L2D ? 4 : ATT2_KBUF;
+  constexpr int KSET = KBUF * KV_TILE * 128, VSET = NV * 64 * VT_LD;  // one precision part: 24 (32) KB + 16 KB
   __shared__ __attribute__((aligned(16))) char smem[(X3 ? 2 : 1) * (KSET + VSET)];
   char* const Kb = smem;
   char* const Vb = smem + KSET;
@@ -1622,25 +1628,40 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   const int vdo1 = sr0 * VT_LD + (((vks * 4 + 2 * (vc & 1) + 1) ^ vsw) << 4) + (vc >> 1) * 8;
   uint4 kr0, vr0, kr0l, vr0l;
   const ptrdiff_t klo = X3 ? (qk_lo - qk) : 0, vlo = X3 ? (vt_lo - vt) : 0;  // element offsets hi -> lo arrays
+  // L2D: staging loads as (wave-uniform base of the tile) + (32-bit lane offset): the base advances on the scalar unit, the
+  // lane part is a loop constant (global_load saddr form; the 64-bit per-lane pointers above cost a v_lshl_add_u64 per load)
+  const unsigned klane = (unsigned)(sr0 * ldq + sc * 8) * 2u;
+  const unsigned vlane = (unsigned)(sr0 * s_pad + sc * 8) * 2u, vlane0 = (unsigned)(sr0 * s_pad) * 2u;
 #define A2_LOADK(kt)                                                                                 \
   do {                                                                                               \
-    kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq);                       \
+    if constexpr (L2D) {                                                                             \
+      kr0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(kbase + (size_t)(kt) * KV_TILE * ldq) + klane); \
+    } else {                                                                                         \
+      kr0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)(kt) * KV_TILE * ldq);                     \
+    }                                                                                                \
     if constexpr (X3) kr0l = *reinterpret_cast<const uint4*>(kp0 + klo + (size_t)(kt) * KV_TILE * ldq); \
   } while (0)
 // (a lane's 8 keys lie wholly inside or wholly behind the image's s_pad keys (s_pad % 8 == 0).  Behind them -- the last tile
 // where s_pad % 64 != 0 -- the lane re-reads a chunk of real keys instead: those keys' P is 0, but what lies behind a V^T row
 // is the next row / head / image or unwritten workspace, and 0 x NaN would poison the row's output.  "Re-reads": the row's
 // first chunk, which always exists)
+// (L2D: the lane re-reads chunk 0 of the SAME tile -- kt * 64 < n_valid <= s_pad, both multiples of 8 -- so that the address
+// stays tile base + a non-negative lane offset)
 #define A2_LOADV(kt)                                                                   \
   do {                                                                                 \
-    const int vk_ = (kt) * KV_TILE + sc * 8 >= s_pad ? -sc * 8 : (kt) * KV_TILE;       \
-    vr0 = *reinterpret_cast<const uint4*>(vp0 + vk_);                                  \
-    if constexpr (X3) vr0l = *reinterpret_cast<const uint4*>(vp0 + vlo + vk_);         \
+    if constexpr (L2D) {                                                               \
+      const unsigned vo_ = (kt) * KV_TILE + sc * 8 >= s_pad ? vlane0 : vlane;          \
+      vr0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vbase + (kt) * KV_TILE) + vo_); \
+    } else {                                                                           \
+      const int vk_ = (kt) * KV_TILE + sc * 8 >= s_pad ? -sc * 8 : (kt) * KV_TILE;     \
+      vr0 = *reinterpret_cast<const uint4*>(vp0 + vk_);                                \
+      if constexpr (X3) vr0l = *reinterpret_cast<const uint4*>(vp0 + vlo + vk_);       \
+    }                                                                                  \
   } while (0)
 #define A2_STOREK(kt)                                                                                   \
   do {                                                                                                  \
-    *reinterpret_cast<uint4*>(Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128) + kdo) = kr0;                   \
-    if constexpr (X3) *reinterpret_cast<uint4*>(Kbl + ((kt) % ATT2_KBUF) * (KV_TILE * 128) + kdo) = kr0l; \
+    *reinterpret_cast<uint4*>(Kb + ((kt) % KBUF) * (KV_TILE * 128) + kdo) = kr0;                   \
+    if constexpr (X3) *reinterpret_cast<uint4*>(Kbl + ((kt) % KBUF) * (KV_TILE * 128) + kdo) = kr0l; \
   } while (0)
 #define A2_STOREV(kt)                                                                     \
   do {                                                                                    \
@@ -1656,9 +1677,9 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   // S^T of tile kt: acc s[mt][r] <-> key = 16*mt + 4*g + r, q = lc
 #define A2_S(dst, kt)                                                                                              \
   do {                                                                                                             \
-    const char* Ks_ = Kb + ((kt) % ATT2_KBUF) * (KV_TILE * 128);                                                   \
+    const char* Ks_ = Kb + ((kt) % KBUF) * (KV_TILE * 128);                                                   \
     if constexpr (X3) {                                                                                            \
-      const char* Kl_ = Kbl + ((kt) % ATT2_KBUF) * (KV_TILE * 128);                                                \
+      const char* Kl_ = Kbl + ((kt) % KBUF) * (KV_TILE * 128);                                                \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
         bf16x8 kh_[4], kl_[4];                                                                                     \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                         \
@@ -1700,12 +1721,20 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   A2_LOADV(0);
   A2_STOREK(0);
   A2_STOREV(0);
-  if (ntiles > 1) {
-    A2_LOADK(1);
+  if constexpr (L2D) {  // (tile indices clamped to the last tile, see the tile body)
+    const int last = ntiles - 1;
+    A2_LOADK(1 < last ? 1 : last);
     A2_STOREK(1);
+    A2_LOADK(2 < last ? 2 : last);
+    A2_LOADV(1 < last ? 1 : last);
+  } else {
+    if (ntiles > 1) {
+      A2_LOADK(1);
+      A2_STOREK(1);
+    }
+    if (ntiles > 2) A2_LOADK(2);
+    if (ntiles > 1) A2_LOADV(1);
   }
-  if (ntiles > 2) A2_LOADK(2);
-  if (ntiles > 1) A2_LOADV(1);
   __syncthreads();
   f32x4 sA[4], sB[4];
   // the exact maximum of a query's logits over its 4 lanes (lc + 16 g): swap rows 0<->1 / 2<->3, then the wave halves (no LDS)
@@ -1759,10 +1788,24 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   // +1 % with hints, -7 % with a hand-placed MFMA / exp interleave whose LDS reads ran only two slots ahead.)
   auto tile = [&](int kt, auto last_tag, f32x4 (&s)[4], f32x4 (&sn)[4]) {
     constexpr bool LAST = decltype(last_tag)::value;
+    if constexpr (L2D) {
+      // unconditional staging (no branches, no phis around the in-flight registers): behind the last tile the LAST tile is
+      // loaded again and lands in buffers nobody reads any more (K: four buffers, the readers are at (kt + 1) & 3 at most; V^T:
+      // the buffer this tile does not read)
+      const int last = ntiles - 1;
+      A2_STOREK(kt + 2);
+      A2_STOREV(kt + 1);
+      if constexpr (!LAST) {
+        const int k3 = kt + 3 < last ? kt + 3 : last, v2 = kt + 2 < last ? kt + 2 : last;
+        A2_LOADK(k3);
+        A2_LOADV(v2);
+      }
+    } else {
     if (kt + 2 < ntiles) A2_STOREK(kt + 2);  // loaded an iteration ago; that buffer was last read two barriers back
     if (kt + 1 < ntiles) A2_STOREV(kt + 1);
     if (kt + 3 < ntiles) A2_LOADK(kt + 3);
     if (kt + 2 < ntiles) A2_LOADV(kt + 2);
+    }
     if constexpr (LAST) {
       const int kbase_idx = kt * KV_TILE;
 #pragma unroll
@@ -1899,7 +1942,9 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
     auto softmax = [&]() {
       const float mb = m_run * LOG2E;
       const f32x2 nmb2 = {-mb, -mb};
-      ps2 = (f32x2){0.f, 0.f};
+      f32x2 psb;  // L2D: two chains of four packed adds (a single chain of eight needs a wait state between any two), started
+                  // from the first pairs instead of 0 + e
+      if constexpr (!L2D) ps2 = (f32x2){0.f, 0.f};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -1909,10 +1954,16 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
           f32x2 e;
           e.x = __builtin_amdgcn_exp2f(t.x);
           e.y = __builtin_amdgcn_exp2f(t.y);
-          ps2 += e;
+          if constexpr (L2D) {
+            if (mt == 0) (h2 == 0 ? ps2 : psb) = e;
+            else (h2 == 0 ? ps2 : psb) += e;
+          } else {
+            ps2 += e;
+          }
           pv[mt][2 * h2] = e.x;
           pv[mt][2 * h2 + 1] = e.y;
         }
+      if constexpr (L2D) ps2 += psb;
     };
     softmax();
     float psum = ps2.x + ps2.y;
@@ -2001,17 +2052,32 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
   if constexpr (SKIPW) {
     if (!active) {
       // an idle wave's loop: its share of the staging and the tile barriers (s_barrier counts arrivals, whatever the PC)
+      const int last = ntiles - 1;
       for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt + 2 < ntiles) A2_STOREK(kt + 2);
-        if (kt + 1 < ntiles) A2_STOREV(kt + 1);
-        if (kt + 3 < ntiles) A2_LOADK(kt + 3);
-        if (kt + 2 < ntiles) A2_LOADV(kt + 2);
+        A2_STOREK(kt + 2);
+        A2_STOREV(kt + 1);
+        A2_LOADK(kt + 3 < last ? kt + 3 : last);
+        A2_LOADV(kt + 2 < last ? kt + 2 : last);
         __syncthreads();
       }
       return;
     }
   }
-  if constexpr (VAR & 8) {
+  if constexpr (L2D) {
+    int kt = 0;
+    for (; kt + 4 <= ntiles - 1; kt += 4) {
+      tile(kt, std::false_type{}, sA, sB);
+      tile(kt + 1, std::false_type{}, sB, sA);
+      tile(kt + 2, std::false_type{}, sA, sB);
+      tile(kt + 3, std::false_type{}, sB, sA);
+    }
+    for (; kt < ntiles - 1; ++kt) {  // 0..3 whole tiles before the last one (buffer indices at run time)
+      tile(kt, std::false_type{}, sA, sB);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) sA[mt] = sB[mt];
+    }
+    tile(ntiles - 1, std::true_type{}, sA, sB);
+  } else if constexpr (VAR & 8) {
     int kt = 0;
     for (; kt + 2 <= ntiles - 1; kt += 2) {
       tile(kt, std::false_type{}, sA, sB);
@@ -2179,8 +2245,8 @@ int dvt_vit_tune(int v) {
     g_vit_w4_grid = v > -700 ? -600 - v : -1100 - v;
     return 0;
   }
-  if (v == -540 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384) {
-    g_vit_attn_l2_mask = 47 + (-540 - v);
+  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384) {
+    g_vit_attn_l2_mask = v == -542 ? (ATT_L2_VAR ^ 2) : ATT_L2_VAR + (-540 - v);
     return 0;
   }
   if (v <= -510 && v > -530) {
@@ -2401,21 +2467,20 @@ extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out
                       4.0 * (double)n_valid * n_valid * 64.0 * heads * batch);
   const dim3 grid(((s_pad + ATT_Q - 1) / ATT_Q) * heads * batch);
 #ifdef DVT_LAB
-  if (g_vit_attn_l2_mask == 47 + 128 || g_vit_attn_l2_mask == 47 + 256 || g_vit_attn_l2_mask == 47 + 384) {  // ablation builds
-    if (g_vit_attn_l2_mask == 47 + 128)
-      hipLaunchKernelGGL(attention_kernel_l2<47 + 128>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
-                         (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
-    else if (g_vit_attn_l2_mask == 47 + 256)
-      hipLaunchKernelGGL(attention_kernel_l2<47 + 256>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
-                         (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
-    else
-      hipLaunchKernelGGL(attention_kernel_l2<47 + 384>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
-                         (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
-    DVT_CHECK_LAUNCH();
-    return 0;
+  if (g_vit_attn_l2_mask != ATT_L2_VAR) {  // ablation builds / the other P.V order
+#define A2L_VAR(n)                                                                                                    \
+  if (g_vit_attn_l2_mask == (n)) {                                                                                    \
+    hipLaunchKernelGGL(attention_kernel_l2<(n)>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,          \
+                       (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);                                       \
+    DVT_CHECK_LAUNCH();                                                                                               \
+    return 0;                                                                                                         \
+  }
+    A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR + 128) A2L_VAR(ATT_L2_VAR + 256) A2L_VAR(ATT_L2_VAR + 384)
+#undef A2L_VAR
+    return DVT_E_BADARG;
   }
 #endif
-  hipLaunchKernelGGL(attention_kernel_l2<47>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
+  hipLaunchKernelGGL(attention_kernel_l2<ATT_L2_VAR>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qk,
                      (const bf16_t*)vt, (bf16_t*)out, heads, s_pad, n_valid);
   DVT_CHECK_LAUNCH();
   return 0;
