@@ -1245,11 +1245,12 @@ int g_vit_stagger_pct = 0;
 // in the log2 domain (attention_v2_body, VAR bit 32) / q as it is and the round-3..5 kernel
 int g_vit_attn_log2q = 1;
 constexpr float ATT_Q_PRESCALE = 0.125f * 1.4426950408889634f;
-constexpr int ATT_L2_VAR = 45;  // schedule mask of the log2-domain attention kernel the product launches (attention_v2_body)
+constexpr int ATT_L2_VAR = 559;  // schedule mask of the log2-domain attention kernel the product launches (attention_v2_body)
 #ifdef DVT_LAB
 int g_vit_tpw = 0;           // 4w kernel: target tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
-int g_vit_attn_l2_mask = ATT_L2_VAR;  // dvt_tune_set(1, -540 - x): builds of the log2-domain attention kernel: x = 0 the product's (mask 45), 2 = with
-                                      // all eight V^T fragments read first (47), 128 / 256 / 384 = ablations (idle waves compute / whole tail tile / both)
+int g_vit_attn_l2_mask = ATT_L2_VAR;  // dvt_tune_set(1, -540 - x): the product's mask (559 = 1 + 2 + 4 + 8 + 32 + 512) with the bits x toggled: 2 = P.V
+                                      // fragment by fragment, 512 = no group pattern for the K reads, 514 = both, 128 / 256 / 384 = ablations (idle
+                                      // waves compute / whole tail tile / both)
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = attention_kernel_v2, 1 = the round-2 kernel
 int g_vit_abl4w = 0;         // dvt_tune_set(1, -300 - mask) while a 4w schedule (6..9) is selected: its ablation mask (EPI_BIAS, timing only)
 int g_vit_8p_build = 0;      // ... while schedule 5 is selected: timing build of the 8p kernel (3 stamps, 6..9 ablations; EPI_BIAS only)
@@ -1549,6 +1550,12 @@ constexpr int ATT2_KBUF = 3;
 //      max grows later (rare: the lane's 16-term row sum left [0, e^8]) this tile's t AND the already issued next tile's are
 //      lowered by the growth.  Waves wholly behind the image's rows (s_pad < the block's 128 queries) stage and synchronise
 //      but neither multiply nor exponentiate, and a last tile with <= 32 valid keys runs its softmax and P.V on half a tile.
+//      Four K buffers and a tile loop unrolled by four (every buffer index a literal), staging unconditional with clamped tile
+//      indices.  128 / 256: ablation builds (idle waves compute / whole tail tile).
+//   512 (with 32) the scheduler's group pattern for the softmax block also places the next tile's K fragment READS: four up
+//      front, then per MFMA slot 4 VALU, the MFMA, one read.  Left alone the reads sink behind the burst of 16 v_exp and every
+//      MFMA waits out its own read (profiles/r06/r06s_*: 2856 -> 2799 us per 396-view launch).  The product launches 559 =
+//      1 + 2 + 4 + 8 + 32 + 512.
 // X3 (the fp32 extractor's opt-in "bf16x3" mode, include/dvt_vit.h): q, k, v arrive as (hi, lo) bf16 pairs of the fp32
 // values (qk / vt = hi, qk_lo / vt_lo = lo), S = K_lo.Q_hi + K_hi.Q_lo + K_hi.Q_hi and O += V_lo.P_hi + V_hi.P_lo + V_hi.P_hi
 // with P split in registers (3 x the MFMAs, fp32 accumulation, fp32 softmax as before) and `out` is fp32 [T, dim].
@@ -1984,7 +1991,17 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
       }
     };
     pack();
-    if constexpr (!LAST) {
+    if constexpr (!LAST && (VAR & 512)) {
+      // (experiment) the K fragment reads placed too: four up front, then per MFMA slot 4 VALU, the MFMA, the read that
+      // re-fills its fragment registers -- left alone the reads sink behind the exps and every MFMA waits for its own read
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    } else if constexpr (!LAST) {
       // scheduler shape for the block above: one S MFMA of the next tile per ~6 VALU of this tile's softmax
 #pragma unroll
       for (int i = 0; i < (X3 ? 24 : 8); ++i) {
@@ -2245,8 +2262,8 @@ int dvt_vit_tune(int v) {
     g_vit_w4_grid = v > -700 ? -600 - v : -1100 - v;
     return 0;
   }
-  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384) {
-    g_vit_attn_l2_mask = v == -542 ? (ATT_L2_VAR ^ 2) : ATT_L2_VAR + (-540 - v);
+  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514) {
+    g_vit_attn_l2_mask = ATT_L2_VAR ^ (-540 - v);
     return 0;
   }
   if (v <= -510 && v > -530) {
@@ -2475,7 +2492,8 @@ extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out
     DVT_CHECK_LAUNCH();                                                                                               \
     return 0;                                                                                                         \
   }
-    A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR + 128) A2L_VAR(ATT_L2_VAR + 256) A2L_VAR(ATT_L2_VAR + 384)
+    A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR ^ 128) A2L_VAR(ATT_L2_VAR ^ 256) A2L_VAR(ATT_L2_VAR ^ 384) A2L_VAR(ATT_L2_VAR ^ 512)
+    A2L_VAR(ATT_L2_VAR ^ 514)
 #undef A2L_VAR
     return DVT_E_BADARG;
   }

@@ -284,8 +284,9 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         tile boundary) -- all bit-identical to 4 --, 6..9 (4-wave persistent kernel; 8 / 9 with an approximate GELU),
  *         -200 - n / -600 - n (tiles per workgroup of 6..9 and 11 / grid of 6..9), -300 - n (ablation mask of the selected 4-wave schedule, or timing build of schedule 5:
  *         TIMING ONLY, results wrong by construction; reset by every change of schedule), -501 (round-2 attention loop),
- *         -510 - mask (attention schedule masks; any of these also selects q as it is), -540 - 128 / 256 / 384 (ablation builds
- *         of the log2-domain attention kernel: idle waves not skipped / no half tail tile / neither; -540 = the product's);
+ *         -510 - mask (attention schedule masks; any of these also selects q as it is), -540 - x (the log2-domain attention kernel with bits x of
+ *         its schedule mask toggled: 2 / 512 / 514 = P.V fragment by fragment / K reads unplaced / both; 128 / 256 / 384 = ablation
+ *         builds: idle waves not skipped / no half tail tile / neither; -540 = the product's);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);

@@ -3,7 +3,7 @@
     python tools/bench_attn_ab.py [--views 396] [--s_pad 1376] [--rounds 6] [--lab]
 
 raw   = dvt_vit_attention       (q as it is, attention_kernel_v2<15>: rounds 3-5)
-log2q = dvt_vit_attention_log2q (q pre-scaled by log2(e) / 8, attention_kernel_l2<45>: round 6)
+log2q = dvt_vit_attention_log2q (q pre-scaled by log2(e) / 8, attention_kernel_l2<559>: round 6)
 --lab adds the ablation builds of the developer library (idle waves not skipped / no half tail tile / neither).
 Variants alternate inside one process, the first round is dropped (the clock ramps over the first launches,
 profiles/r06/README.md); times are hipEvent brackets around `reps` back-to-back launches on one stream.
@@ -61,10 +61,11 @@ def l2(extra=0):
     return f
 
 
-variants = [("raw  v2<15>", raw), ("log2q l2<45>", l2(0))]
+variants = [("raw  v2<15>", raw), ("log2q l2<559>", l2(0))]
 if a.lab:
-    variants += [("log2q, all V^T fragments first (47)", l2(2)), ("log2q, idle waves compute (45+128)", l2(128)),
-                 ("log2q, whole tail tile (45+256)", l2(256)), ("log2q, neither (45+384)", l2(384))]
+    variants += [("log2q, P.V fragment by fragment (557)", l2(2)), ("log2q, K reads unplaced (47)", l2(512)), ("log2q, both (45)", l2(514)),
+                 ("log2q, idle waves compute (559+128)", l2(128)), ("log2q, whole tail tile (559+256)", l2(256)),
+                 ("log2q, neither (559+384)", l2(384))]
 times = {n: [] for n, _ in variants}
 for r in range(a.rounds + 1):
     for name, fn in variants:
