@@ -22,6 +22,7 @@
 // dvt_gemm_f32.hip: the fp32 extractor's 128 x 128 x 32 exact-fp32 MFMA tile (x . w^T + b, shapes per dvt_linear_big_ok)
 int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s);
 bool dvt_linear_big_ok(int m, int n, int k);
+int g_s2_big_bwd = 1;  // DVT_S2_BIG_BWD=0: the data-gradient GEMMs on the 64 x 64 tile (A/B)
 int g_s2_big_fwd = 1;  // DVT_S2_BIG=0 in the environment of the process: the 64 x 64 tile for the forward layers too (A/B)
 
 namespace {
@@ -447,6 +448,7 @@ struct S2Block {  // activations a block keeps for its backward pass
 struct S2Work {
   S2Block blk[DVT_S2_MAX_BLOCKS];
   float *tmp, *d0, *d1, *d2, *dh, *dqkv, *dP, *acc;
+  float* wT;  // training: one transposed weight matrix (max(3 C, F) x C floats), rebuilt in front of each data-gradient GEMM
 };
 
 int64_t carve(const DvtS2Config* c, int batch, int training, char* base, S2Work* w) {
@@ -487,6 +489,7 @@ int64_t carve(const DvtS2Config* c, int batch, int training, char* base, S2Work*
     t.dqkv = take(R * 3 * C);
     t.dP = take(PP);
     t.acc = take(64);
+    t.wT = take((3 * C > F ? 3 * C : F) * C);
   }
   if (w) *w = t;
   return o;
@@ -533,9 +536,23 @@ int lin_fwd(const float* x, const float* w, const float* b, float* y, int R, int
   g.bias = b;
   return dvt_gemm_f32_ex(&g, s);
 }
+// out[k][n] = in[n][k] (n, k multiples of 32): 32 x 32 tiles through LDS, both sides in whole 128-B row pieces
+__global__ __launch_bounds__(256) void s2_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int k) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = in[(size_t)(n0 + ty + 8 * i) * k + k0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[(size_t)(k0 + ty + 8 * i) * n + n0 + tx] = tile[tx][ty + 8 * i];
+}
+
 // dx[R][k] = dy[R][n] . w[n][k];  dw[n][k] += dy^T . x;  db[n] += colsum(dy)
+// wT (round 6): scratch for w^T [k][n].  With it the data gradient is a FORWARD linear layer of the transposed weight --
+// dx = dy . (w^T)^T -- and takes the 128 x 128 x 32 tile (dvt_linear_fwd_big: both operands k-contiguous); the transposition is
+// 2 x 9 MB of traffic at most per layer, the GEMM 0.07-0.2 TFLOP.  Summation order differs from the 64 x 64 kernel only.
 int lin_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int R, int n, int k,
-            hipStream_t s) {
+            hipStream_t s, float* wT = nullptr) {
   DvtGemmEx g{};
   g.layout = 2;
   g.A = dy; g.B = x; g.C = dw;
@@ -545,6 +562,11 @@ int lin_bwd(const float* dy, const float* x, const float* w, float* dx, float* d
   g.accumulate = 1;
   S2_TRY(dvt_gemm_f32_ex(&g, s));
   if (!dx) return 0;
+  if (wT && g_s2_big_bwd && n % 32 == 0 && k % 32 == 0 && dvt_linear_big_ok(R, k, n)) {
+    hipLaunchKernelGGL(s2_transpose_kernel, dim3(k / 32, n / 32), dim3(256), 0, s, w, wT, n, k);
+    DVT_CHECK_LAUNCH();
+    return dvt_linear_fwd_big(dy, wT, nullptr, dx, R, k, n, s);
+  }
   DvtGemmEx d{};
   d.layout = 1;
   d.A = dy; d.B = w; d.C = dx;
@@ -649,16 +671,16 @@ int run(const DvtS2Config* c, const float* params, float* grads, const float* x,
   for (int b = NB - 1; b >= 0; --b) {
     const S2Block& k = w.blk[b];
     // mlp: out = x1 + fc2(gelu(fc1(norm2(x1))))
-    S2_TRY(lin_bwd(w.d0, k.a, P(b, FC2W), w.dh, G(b, FC2W), G(b, FC2B), R, C, F, s));
+    S2_TRY(lin_bwd(w.d0, k.a, P(b, FC2W), w.dh, G(b, FC2W), G(b, FC2B), R, C, F, s, w.wT));
     {
       const int64_t n4 = (int64_t)R * F / 4;
       hipLaunchKernelGGL(s2_gelu_bwd_kernel, dim3(dvt_cdiv(n4, 256)), dim3(256), 0, s, (const float4*)k.h, (float4*)w.dh, n4);
       DVT_CHECK_LAUNCH();
     }
-    S2_TRY(lin_bwd(w.dh, k.xn2, P(b, FC1W), w.d2, G(b, FC1W), G(b, FC1B), R, F, C, s));
+    S2_TRY(lin_bwd(w.dh, k.xn2, P(b, FC1W), w.d2, G(b, FC1W), G(b, FC1B), R, F, C, s, w.wT));
     S2_TRY(ln_bwd(C, w.d2, k.x1, k.mean2, k.rstd2, P(b, N2W), w.d0, w.d1, G(b, N2W), G(b, N2B), R, s));  // d1 = d x1
     // attention: x1 = xin + proj(attn(norm1(xin)))
-    S2_TRY(lin_bwd(w.d1, k.ao, P(b, PROJW), w.d2, G(b, PROJW), G(b, PROJB), R, C, C, s));  // d2 = d ao
+    S2_TRY(lin_bwd(w.d1, k.ao, P(b, PROJW), w.d2, G(b, PROJW), G(b, PROJB), R, C, C, s, w.wT));  // d2 = d ao
     {
       // dV = P^T dao
       DvtGemmEx g = attn_gemm(ad, 2, k.P, Tp, ps0, ps1, w.d2, C, os0, os1, w.dqkv + 2 * C, 3 * C, qs0, qs1, Tp, 64, Tp);
@@ -674,7 +696,7 @@ int run(const DvtS2Config* c, const float* params, float* grads, const float* x,
       g = attn_gemm(ad, 2, w.dP, Tp, ps0, ps1, k.qkv, 3 * C, qs0, qs1, w.dqkv + C, 3 * C, qs0, qs1, Tp, 64, Tp);
       S2_TRY(dvt_gemm_f32_ex(&g, s));
     }
-    S2_TRY(lin_bwd(w.dqkv, k.xn1, P(b, QKVW), w.d2, G(b, QKVW), G(b, QKVB), R, 3 * C, C, s));
+    S2_TRY(lin_bwd(w.dqkv, k.xn1, P(b, QKVW), w.d2, G(b, QKVW), G(b, QKVB), R, 3 * C, C, s, w.wT));
     S2_TRY(ln_bwd(C, w.d2, k.xin, k.mean1, k.rstd1, P(b, N1W), w.d1, w.d0, G(b, N1W), G(b, N1B), R, s));  // d0 = d xin
   }
   if (c->enable_pe) {
@@ -711,6 +733,8 @@ static void s2_read_env() {
   done = true;
   const char* e = getenv("DVT_S2_BIG");
   if (e && e[0] == '0') g_s2_big_fwd = 0;
+  e = getenv("DVT_S2_BIG_BWD");
+  if (e && e[0] == '0') g_s2_big_bwd = 0;
 }
 
 extern "C" int dvt_s2_forward(const DvtS2Config* cfg, const float* params, const float* x, float* pred, int batch,

@@ -111,6 +111,8 @@ struct GemmBArgs {
   // map_tile_fast: the tile order's divisors as multiply-shift pairs (fd_make), set by launch_gemm for the 256 x 256 kernels
   unsigned fd_pg[2], fd_pb[2], fd_w[2], fd_hb[2];  // per_group = group * mt; per_block = mblock * group; width = group; hb = mblock
   int tiles_full;     // N tiles in whole groups (nt / group * group): ids beyond group `tiles_full / group` take the slow path
+  int abl;            // developer library, TIMING ONLY (dvt_tune_set(1, -560 - mask)): bit 0 = the epilogues do not park their
+                      // accumulators in LDS (outputs are garbage): what the parking writes cost a tile
 };
 
 // async global -> LDS copy of 16 B per lane; the LDS address is wave-uniform base + lane*16
@@ -504,6 +506,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     bf0 = *reinterpret_cast<const float4*>(p.bias + nb + c8_ln);
     bf1 = *reinterpret_cast<const float4*>(p.bias + nb + c8_ln + 4);
   }
+#ifdef DVT_LAB
+  if (!(p.abl & 1))
+#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float bias = (p.bias != nullptr && !ln) ? p.bias[nb + j * 16 + lc] : 0.f;
@@ -745,6 +750,9 @@ __device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias[j] = p.bias != nullptr ? p.bias[nb + j * 16 + lc] : 0.f;
   const float4 gm = *reinterpret_cast<const float4*>(p.gamma + nb + c4);
+#ifdef DVT_LAB
+  if (!(p.abl & 1))
+#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -766,6 +774,9 @@ __device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4
     if (p.xb != nullptr) RS_LN(it, o);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own reads of the block are complete
+#ifdef DVT_LAB
+  if (!(p.abl & 1))
+#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1251,6 +1262,7 @@ int g_vit_tpw = 0;           // 4w kernel: target tiles per workgroup, 0 = auto 
 int g_vit_attn_l2_mask = ATT_L2_VAR;  // dvt_tune_set(1, -540 - x): the product's mask (559 = 1 + 2 + 4 + 8 + 32 + 512) with the bits x toggled: 2 = P.V
                                       // fragment by fragment, 512 = no group pattern for the K reads, 514 = both, 128 / 256 / 384 = ablations (idle
                                       // waves compute / whole tail tile / both)
+int g_vit_epi_abl = 0;       // dvt_tune_set(1, -560 - mask): GemmBArgs::abl
 int g_vit_attn_variant = 2;  // dvt_tune_set(1, -500 - v): 2 (default) = attention_kernel_v2, 1 = the round-2 kernel
 int g_vit_abl4w = 0;         // dvt_tune_set(1, -300 - mask) while a 4w schedule (6..9) is selected: its ablation mask (EPI_BIAS, timing only)
 int g_vit_8p_build = 0;      // ... while schedule 5 is selected: timing build of the 8p kernel (3 stamps, 6..9 ablations; EPI_BIAS only)
@@ -1301,6 +1313,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       a.stagger_ticks = (int)(tile_us * 100.0 * g_vit_stagger_pct / 100.0);
     }
 #ifdef DVT_LAB
+    a.abl = g_vit_epi_abl;
     const int nk = a.K / GBK;
     if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU) {
       if (g_vit_gemm_variant >= 6 && g_vit_gemm_variant <= 9 && a.K >= W4_MIN_K) {
@@ -1990,7 +2003,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         pl1.u[2] = lo2(pf1.u[2], pv[3][0], pv[3][1]); pl1.u[3] = lo2(pf1.u[3], pv[3][2], pv[3][3]);
       }
     };
-    pack();
+    if constexpr (!(VAR & 1024)) pack();
     if constexpr (!LAST && (VAR & 512)) {
       // (experiment) the K fragment reads placed too: four up front, then per MFMA slot 4 VALU, the MFMA, the read that
       // re-fills its fragment registers -- left alone the reads sink behind the exps and every MFMA waits for its own read
@@ -2016,7 +2029,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         exact_max();
         softmax();
         psum = ps2.x + ps2.y;
-        pack();
+        if constexpr (!(VAR & 1024)) pack();
       }
     }
     l_run += psum;
@@ -2047,11 +2060,13 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         vf[mt] = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
         vf[4 + mt] = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
       }
+      if constexpr (VAR & 1024) pack();  // (experiment) P is packed BEHIND the V^T fragment reads: the eight v_cvt_pk cover their latency
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[mt], pf0.v, o[mt], 0, 0, 0);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[4 + mt], pf1.v, o[mt], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the eight LDS reads
+      if constexpr (VAR & 1024) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // the eight v_cvt_pk
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // then the MFMAs in source order
     } else {
 #pragma unroll
@@ -2262,7 +2277,11 @@ int dvt_vit_tune(int v) {
     g_vit_w4_grid = v > -700 ? -600 - v : -1100 - v;
     return 0;
   }
-  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514) {
+  if (v <= -560 && v >= -563) {  // timing-only ablation of the GEMM epilogues (GemmBArgs::abl)
+    g_vit_epi_abl = -560 - v;
+    return 0;
+  }
+  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024) {
     g_vit_attn_l2_mask = ATT_L2_VAR ^ (-540 - v);
     return 0;
   }
@@ -2493,7 +2512,7 @@ extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out
     return 0;                                                                                                         \
   }
     A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR ^ 128) A2L_VAR(ATT_L2_VAR ^ 256) A2L_VAR(ATT_L2_VAR ^ 384) A2L_VAR(ATT_L2_VAR ^ 512)
-    A2L_VAR(ATT_L2_VAR ^ 514)
+    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024)
 #undef A2L_VAR
     return DVT_E_BADARG;
   }

@@ -20,6 +20,10 @@ L = use_lab_library()
 L.dvt_vit_debug_buffer.argtypes = [C.c_void_p]
 L.dvt_vit_debug_buffer.restype = C.c_int
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 398 * 1376 // 256 * 256
+ABL = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # timing-only ablation mask of the epilogues (dvt_tune_set(1, -560 - mask)): 1 = no parking writes
+assert L.dvt_tune_set(1, -560 - ABL) == 0
+if ABL:
+    print(f"TIMING ONLY: epilogue ablation mask {ABL} (outputs are garbage)")
 cases = [("qkv  bias", "bias", 2304, 768), ("fc1  ln+gelu", "gelu", 3072, 768), ("proj resid", "resid", 768, 768),
          ("fc2  resid", "resid", 768, 3072), ("fc2  bias", "bias", 768, 3072)]
 torch.manual_seed(0)
