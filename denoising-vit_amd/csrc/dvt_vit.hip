@@ -1955,6 +1955,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (VAR & 4096) __builtin_amdgcn_s_setprio(1);  // (experiment) ... or the S / softmax block does
     if constexpr (!LAST) A2_S(sn, kt + 1);  // K(kt+1) became visible at the previous barrier (or in the prologue)
     const f32x2 l2e2 = {LOG2E, LOG2E};
     float pv[4][4];
@@ -2023,6 +2024,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (VAR & 4096) __builtin_amdgcn_s_setprio(0);
     if constexpr (VAR & 4) {
       // every P of this lane is within [0, e^8] iff its 16-term sum is (terms are >= 0; inf / NaN fail the compare)
       if (!__all(psum <= 2980.0f)) {
@@ -2052,6 +2054,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh1, pf1.v, o[mt], 0, 0, 0);
       }
     } else if constexpr (VAR & 2) {
+      if constexpr (VAR & 2048) __builtin_amdgcn_s_setprio(1);  // (experiment) the P.V block wins the issue arbitration
       bf16x8 vf[8];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -2068,6 +2071,7 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the eight LDS reads
       if constexpr (VAR & 1024) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // the eight v_cvt_pk
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // then the MFMAs in source order
+      if constexpr (VAR & 2048) __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -2281,7 +2285,7 @@ int dvt_vit_tune(int v) {
     g_vit_epi_abl = -560 - v;
     return 0;
   }
-  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024) {
+  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024 || v == -540 - 2048 || v == -540 - 4096) {
     g_vit_attn_l2_mask = ATT_L2_VAR ^ (-540 - v);
     return 0;
   }
@@ -2512,7 +2516,7 @@ extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out
     return 0;                                                                                                         \
   }
     A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR ^ 128) A2L_VAR(ATT_L2_VAR ^ 256) A2L_VAR(ATT_L2_VAR ^ 384) A2L_VAR(ATT_L2_VAR ^ 512)
-    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024)
+    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024) A2L_VAR(ATT_L2_VAR ^ 2048) A2L_VAR(ATT_L2_VAR ^ 4096)
 #undef A2L_VAR
     return DVT_E_BADARG;
   }

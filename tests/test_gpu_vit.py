@@ -22,13 +22,15 @@ ATTN_MASK_DEFAULT = 15  # dvt_tune_set(1, -510 - mask): schedule mask of the rou
 # "log2q" (round 6): the kernel dvt_vit_forward launches -- dvt_vit_attention_log2q, q PRE-SCALED by log2(e) / 8 (the qkv GEMM's
 # epilogue does that on its fp32 accumulators), logits in units of log2, the S chain started from -max; the same checks
 ATTN_CASES = [(2, 15), "log2q"]
-LAB_ATTN_CASES = [(1, 0), (2, 0), (2, 79)]
+# ("log2q", x): developer builds of the log2-domain kernel, schedule-mask bits x toggled (dvt_tune_set(1, -540 - x)): the other P.V
+# order, no group pattern for the K reads, the ablation builds (idle waves compute / whole tail tile), P packed behind the V^T reads
+LAB_ATTN_CASES = [(1, 0), (2, 0), (2, 79), ("log2q", 2), ("log2q", 514), ("log2q", 384), ("log2q", 1024)]
 Q_PRESCALE = 0.125 * 1.4426950408889634
 
 
 def attn_q(q, attn_variant):
     """(the bf16 q the kernel is handed, the q of the reference's logits q . k) for one attention entry point."""
-    if attn_variant == "log2q":
+    if attn_variant == "log2q" or attn_variant[0] == "log2q":
         qp = (q.float() * Q_PRESCALE).bfloat16()
         return qp, qp.double() * 0.6931471805599453  # 2^(q' . k) = e^(ln 2 q' . k)
     qb = q.bfloat16()
@@ -38,6 +40,12 @@ def attn_q(q, attn_variant):
 def run_attention(L, attn_variant, qk, vt, out, batch, heads, s_pad, n_valid):
     if attn_variant == "log2q":
         return L.dvt_vit_attention_log2q(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s())
+    if attn_variant[0] == "log2q":
+        assert L.dvt_tune_set(1, -540 - attn_variant[1]) == 0
+        try:
+            return L.dvt_vit_attention_log2q(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s())
+        finally:
+            assert L.dvt_tune_set(1, -540) == 0
     set_attn(L, *attn_variant)
     try:
         return L.dvt_vit_attention(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s())
