@@ -111,6 +111,8 @@ struct GemmBArgs {
   // map_tile_fast: the tile order's divisors as multiply-shift pairs (fd_make), set by launch_gemm for the 256 x 256 kernels
   unsigned fd_pg[2], fd_pb[2], fd_w[2], fd_hb[2];  // per_group = group * mt; per_block = mblock * group; width = group; hb = mblock
   int tiles_full;     // N tiles in whole groups (nt / group * group): ids beyond group `tiles_full / group` take the slow path
+  int pf_next;        // 8p: late in its epilogue a workgroup touches the first pf_next (0..2) k-tiles' operand lines of tile
+                      // blockIdx + 256, the tile the next workgroup of its XCD walks (NextTilePf; dvt_tune_set(1, -570 - n))
   int abl;            // developer library, TIMING ONLY (dvt_tune_set(1, -560 - mask)): bit 0 = the epilogues do not park their
                       // accumulators in LDS (outputs are garbage): what the parking writes cost a tile
 };
@@ -411,13 +413,42 @@ constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;  // 17408 B x 8 waves = 136 KB <= 
 template <int NI>
 __device__ __forceinline__ void ln_fold(const GemmBArgs& p, f32x4 (&acc)[NI][4], int mrow0, int ncol0, int lane);
 
+// L2 prefetch for the NEXT workgroup of this XCD (round 6).  A 256 x 256 tile starts cold: its first LDS-DMAs miss the L2 and a
+// K = 768 tile waits ~2.3 us for them while every CU loads at once (profiles/r06/r06j_*: prologue 3.0 us of 25.2).  Workgroups go
+// round-robin to the XCDs, so tile blockIdx + 256 is walked by a workgroup of THIS XCD (this L2) about when this one exits: late in
+// its epilogue a workgroup touches the first one or two k-tiles' operand lines of that tile -- one dword per 128-B line and thread,
+// 256 A rows + 256 W rows.  Placement: program order behind the last load whose result the epilogue still waits for (gfx9 retires
+// vector-memory operations of a wave in issue order, and hipcc's counted s_waitcnt does not know these loads: older ones would be
+// waited for).  The destination registers stay reserved to the kernel's end (pf_retire): the data lands long after the asm
+// statement, and a "dead" destination would be handed out again -- as an address register, the first cut of this faulted.
+// MEASURED NULL (profiles/r06/r07a_*, r06z_*): the prologue shrinks as predicted (qkv 3.1 -> 1.1 us, proj 2.5 -> 1.4, fc2 2.4 -> 1.6) and
+// the first k-tiles run faster, but the launch does not get shorter (qkv 1793 -> 1812 us, fc1 2786 -> 2769, proj 946 -> 981):
+// s_endpgm waits for a wave's outstanding loads, so the fetch latency moves from the next workgroup's prologue into this one's
+// exit, and the K = 768 launches are bound by the THROUGHPUT of the shared L2 -> LDS / memory-side path, which a prefetch does
+// not add to (the same reason the persistent and staggered variants gave nothing).  Off by default; kept as a knob.
+struct NextTilePf {
+  const bf16_t* src;  // this thread's operand row of the next tile (nullptr: nothing to touch)
+  int n;              // k-tiles to touch (1..2)
+  unsigned d0, d1;
+};
+__device__ __forceinline__ void pf_issue(NextTilePf& f) {
+  if (f.src == nullptr) return;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(f.d0) : "v"(f.src) : "memory");
+  if (f.n > 1) asm volatile("global_load_dword %0, %1, off offset:128" : "=v"(f.d1) : "v"(f.src) : "memory");
+}
+__device__ __forceinline__ void pf_retire(NextTilePf& f) {
+  if (f.src == nullptr) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::"v"(f.d0), "v"(f.d1));
+}
+
 // NI: 16-row blocks per call (4: a wave's 64 x 64 block, 17 KB of LDS; 2: 32 x 64, 8.5 KB -- the persistent kernel's passes,
 // which leave half of the ring to the next tile's operands); `blk0` overrides the wave's LDS block (default: smem + wave *
 // EP_WAVE_BYTES)
 template <int EPI, int NI = 4>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&acc)[NI][4], int m0,
                                                   int n0, int wm, int wn, int wave, int lane,
-                                                  char* smem, char* blk0 = nullptr) {
+                                                  char* smem, char* blk0 = nullptr, NextTilePf* pf = nullptr) {
   static_assert(NI == 4 || NI == 2, "64- or 32-row passes");
   constexpr int ROWS = NI * 16;
   const int g = lane >> 4, lc = lane & 15;
@@ -465,6 +496,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     bf16_t* const vrow = p.vt + ((size_t)(bimg * p.heads + hh) * 64) * p.s_pad + s0;
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
+      if (pf != nullptr && it == 1) pf_issue(*pf);  // (behind the pass that consumed the last loaded parameters)
       const int d = it * FPP + dl;
       const float4 a = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8);
       const float4 b = *reinterpret_cast<const float4*>(blk + d * EP_LD + tc * 8 + 4);
@@ -528,6 +560,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
 #pragma unroll 4
     for (int it = 0; it < ROWS / 4; ++it) {
       const int row = it * 4 + g;
+      if (pf != nullptr && it == ROWS / 8 && EPI == EPI_F32) pf_issue(*pf);  // (EPI_F32 loads nothing per row; the others do)
       const float4 v = *reinterpret_cast<const float4*>(blk + row * EP_LD + c4);
       const int t = mb + row;
       float4* px = reinterpret_cast<float4*>(p.x + (size_t)t * p.N + nb + c4);
@@ -565,6 +598,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmBArgs& p, f32x4 (&ac
     // and at 2 x 256 registers per SIMD no wave of the fit's streaming kernels can share the CU)
 #pragma unroll(IS_GELU(EPI) ? 1 : 4)
     for (int it = 0; it < ROWS / 8; ++it) {
+      if (pf != nullptr && it == 1) pf_issue(*pf);  // (pass 0 consumed the last loaded parameters)
       const int row = it * 8 + (lane >> 3);
       float4 a = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8);
       float4 b = *reinterpret_cast<const float4*>(blk + row * EP_LD + c8 + 4);
@@ -713,7 +747,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // 64-row half are requested up front (64 VGPRs; the k-loop's fragment registers are dead), and the
 // second half's requests go out as soon as the first half's accumulators are parked in LDS.
 __device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4 (&acc)[8][4], int mb,
-                                                       int nb, int wave, int lane, char* smem) {
+                                                       int nb, int wave, int lane, char* smem, NextTilePf* pf = nullptr) {
   const int g = lane >> 4, lc = lane & 15, c4 = lc * 4;
   float* blk = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
   // buffer addressing: one resource (SGPRs) based at the block, ONE 32-bit lane offset and a
@@ -774,6 +808,7 @@ __device__ __forceinline__ void gemm_epilogue_resid_sq(const GemmBArgs& p, f32x4
     if (p.xb != nullptr) RS_LN(it, o);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own reads of the block are complete
+  if (pf != nullptr) pf_issue(*pf);  // younger than every row load, older than the second half's stores only
 #ifdef DVT_LAB
   if (!(p.abl & 1))
 #endif
@@ -1162,15 +1197,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (wm == 0) P8_BAR();  // balance group 1's extra barrier
   __syncthreads();        // operand buffers become epilogue space
   if constexpr (STAMP) ts_[2] = __builtin_amdgcn_s_memrealtime();
+  NextTilePf pf_{nullptr, p.pf_next, 0u, 0u};
+  if (p.pf_next > 0 && (int)blockIdx.x + 256 < (int)gridDim.x) {
+    const TileMap tn = map_tile_fast(p, blockIdx.x + 256, gridDim.x, p.M >> 8, p.N >> 8);
+    pf_.src = tid < 256 ? p.A + (size_t)(tn.m * 256 + tid) * p.lda : p.W + (size_t)(tn.n * 256 + tid - 256) * p.ldw;
+  }
   if constexpr (EPI == EPI_RESID) {
-    gemm_epilogue_resid_sq(p, acc, m0 + wm * 128, n0 + wn * 64, wave, lane, smem);
+    gemm_epilogue_resid_sq(p, acc, m0 + wm * 128, n0 + wn * 64, wave, lane, smem, &pf_);
   } else {
     f32x4(&lo)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]);
     f32x4(&hi)[4][4] = *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]);
     gemm_epilogue_lds<EPI>(p, lo, m0 + wm * 128, n0 + wn * 64, 0, 0, wave, lane, smem);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem);
+    gemm_epilogue_lds<EPI>(p, hi, m0 + wm * 128 + 64, n0 + wn * 64, 0, 0, wave, lane, smem, nullptr, &pf_);
   }
+  pf_retire(pf_);
   if constexpr (STAMP) {
     ts_[3] = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1256,6 +1297,7 @@ int g_vit_stagger_pct = 0;
 // in the log2 domain (attention_v2_body, VAR bit 32) / q as it is and the round-3..5 kernel
 int g_vit_attn_log2q = 1;
 constexpr float ATT_Q_PRESCALE = 0.125f * 1.4426950408889634f;
+int g_vit_pf_next = 0;  // dvt_tune_set(1, -570 - n): GemmBArgs::pf_next (0 = off, the default: measured null, profiles/r06/r07a_*)
 constexpr int ATT_L2_VAR = 559;  // schedule mask of the log2-domain attention kernel the product launches (attention_v2_body)
 #ifdef DVT_LAB
 int g_vit_tpw = 0;           // 4w kernel: target tiles per workgroup, 0 = auto (dvt_tune_set(1, -200 - n))
@@ -1312,6 +1354,7 @@ int launch_gemm(const GemmBArgs& a0, hipStream_t s) {
       const double tile_us = 1.68 * (a.K / GBK) + epi_us;
       a.stagger_ticks = (int)(tile_us * 100.0 * g_vit_stagger_pct / 100.0);
     }
+    a.pf_next = g_vit_pf_next;
 #ifdef DVT_LAB
     a.abl = g_vit_epi_abl;
     const int nk = a.K / GBK;
@@ -2262,6 +2305,10 @@ int dvt_vit_tune(int v) {
   }
   if (v == -50 || v == -51) {  // non-temporal bf16 output stores off / on
     g_vit_nt_store = v == -51;
+    return 0;
+  }
+  if (v <= -570 && v >= -572) {  // 8p GEMM: L2 prefetch of the next workgroup's first 0 / 1 / 2 k-tiles (NextTilePf; results do not depend on it)
+    g_vit_pf_next = -570 - v;
     return 0;
   }
   if (v == -530 || v == -531) {  // bf16 extractor: attention on q as it is (-530) / on q pre-scaled by log2(e) / 8 (-531, default)

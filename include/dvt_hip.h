@@ -274,6 +274,8 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *           -520 / -521 and -522 / -523: inside dvt_vit_forward_f32x3, exact-fp32 attention on / off [off] and split kernels
  *             instead of split epilogues on / off [off];
  *           -502 and -525 (= -510 - 15): the one attention kernel / schedule mask the product contains (accepted, no effect);
+ *           -570 [default] / -571 / -572 (round 6): the 256x256 kernel's workgroups touch the first 0 / 1 / 2 k-tiles' operand lines of
+ *             the tile the next workgroup of their XCD walks (an L2 prefetch late in the epilogue; measured null, results unaffected);
  *           -531 [default] / -530 (round 6): inside dvt_vit_forward the qkv GEMM writes q * log2(e) / 8 and the log2-domain
  *             attention kernel runs (dvt_vit_attention_log2q, include/dvt_vit.h) / q as it is and dvt_vit_attention.  The two
  *             differ in WHICH bf16 value q rounds to (q against q * 0.18033688: one rounding each), i.e. by the bf16 rounding

@@ -22,6 +22,9 @@ L.dvt_vit_debug_buffer.restype = C.c_int
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 398 * 1376 // 256 * 256
 ABL = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # timing-only ablation mask of the epilogues (dvt_tune_set(1, -560 - mask)): 1 = no parking writes
 assert L.dvt_tune_set(1, -560 - ABL) == 0
+PF = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # experiment: L2 prefetch of the next workgroup's first PF k-tiles (dvt_tune_set(1, -570 - n))
+assert L.dvt_tune_set(1, -570 - PF) == 0
+print(f"L2 prefetch of the next workgroup's first {PF} k-tile(s) late in the epilogue (0 = off)")
 if ABL:
     print(f"TIMING ONLY: epilogue ablation mask {ABL} (outputs are garbage)")
 cases = [("qkv  bias", "bias", 2304, 768), ("fc1  ln+gelu", "gelu", 3072, 768), ("proj resid", "resid", 768, 768),
