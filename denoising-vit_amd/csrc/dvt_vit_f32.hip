@@ -45,8 +45,13 @@ struct VitWorkF {
   float *x, *xn, *qkv, *ao, *hid, *tmp, *col;
 };
 
+// rows of the linear layers' launches: batch * s_pad rounded up to whole 128-row tiles of the 128 x 128 x 32 GEMM (round 6: s_pad
+// is any multiple of 32 -- 1370 tokens -> 1376 rows instead of 1408 --, so batch * s_pad need not be one); the rows behind
+// batch * s_pad are computed on whatever they hold and never read
+inline int64_t rows128(const DvtVitConfig* c, int batch) { return ((int64_t)batch * c->s_pad + 127) / 128 * 128; }
+
 int64_t carve_f32(const DvtVitConfig* c, int batch, char* base, VitWorkF* w) {
-  const int64_t T = (int64_t)batch * c->s_pad;
+  const int64_t T = rows128(c, batch);
   int64_t o = 0;
   auto take = [&](int64_t floats) {
     char* p = base ? base + o : nullptr;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   __shared__ float Vs[2][FA_K * FA_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h2 = lane >> 5;
-  const int nqb = s_pad / FA_Q;
+  const int nqb = (s_pad + FA_Q - 1) / FA_Q;  // the last block of an image may hang over its rows (s_pad % 32 == 0: whole waves)
   const int id = blockIdx.x;
   const int qb = id % nqb, hd = (id / nqb) % heads, b = id / (nqb * heads);
   const int dim = heads * 64, ld = 3 * dim;
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     if (more) park(cur ^ 1);  // that buffer was last read in iteration kt - 1, a barrier ago
     __syncthreads();
   }
+  if (qb * FA_Q + wave * 32 >= s_pad) return;  // a wave behind the image's rows (its "queries" were the next image's): nothing to store
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
   // o0[r] = O^T[d = kappa(r) + 4 h2][query j], o1: d + 32
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 }  // namespace
 
 extern "C" int64_t dvt_vit_workspace_bytes_f32(const DvtVitConfig* c, int batch) {
-  if (!c || batch <= 0 || c->s_pad % 128 || c->dim % 64 || c->heads * 64 != c->dim) return -1;
+  if (!c || batch <= 0 || c->s_pad % 32 || c->dim % 64 || c->heads * 64 != c->dim) return -1;
   return carve_f32(c, batch, nullptr, nullptr);
 }
 
@@ -503,9 +509,9 @@ extern "C" int dvt_vit_forward_f32x3(const DvtVitConfig* c, const DvtVitWeights*
 
 extern "C" int dvt_vit_attention_f32(const float* qkv, float* out, int batch, int heads, int s_pad, int n_valid,
                                      void* stream) {
-  if (!qkv || !out || batch <= 0 || heads <= 0 || s_pad % FA_Q || n_valid <= 0 || n_valid > s_pad)
+  if (!qkv || !out || batch <= 0 || heads <= 0 || s_pad % 32 || n_valid <= 0 || n_valid > s_pad)
     return DVT_E_BADARG;
-  hipLaunchKernelGGL(attention_f32_kernel, dim3((s_pad / FA_Q) * heads * batch), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(attention_f32_kernel, dim3(((s_pad + FA_Q - 1) / FA_Q) * heads * batch), dim3(256), 0, (hipStream_t)stream,
                      qkv, out, heads, s_pad, n_valid);
   DVT_CHECK_LAUNCH();
   return 0;
@@ -515,11 +521,12 @@ extern "C" int dvt_vit_forward_f32(const DvtVitConfig* c, const DvtVitWeights* w
                                    int batch, int n_blocks, void* workspace, void* stream) {
   if (!c || !w || !img || !feat || !workspace || batch <= 0 || n_blocks < 0 || n_blocks > c->depth)
     return DVT_E_BADARG;
-  if (c->s_pad % 128 || c->dim % 64 || c->heads * 64 != c->dim || c->k_patch % 4) return DVT_E_BADARG;
+  if (c->s_pad % 32 || c->dim % 64 || c->heads * 64 != c->dim || c->k_patch % 4) return DVT_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   VitWorkF k;
   carve_f32(c, batch, (char*)workspace, &k);
   const int T = batch * c->s_pad, D = c->dim;
+  const int Tg = (int)rows128(c, batch);  // the linear layers' M (whole 128-row tiles; rows [T, Tg) are never read)
   const long long nqD = (long long)T * D / 4;
   const int ew_blocks = 256 * 8;
 #define DVT_TRY(x)         \
@@ -529,7 +536,7 @@ extern "C" int dvt_vit_forward_f32(const DvtVitConfig* c, const DvtVitWeights* w
   } while (0)
   hipLaunchKernelGGL(im2col_f32_kernel, dim3(T), dim3(256), 0, s, img, k.col, *c);
   DVT_CHECK_LAUNCH();
-  DVT_TRY(dvt_linear_fwd_big(k.col, (const float*)w->patch_w, w->patch_b, k.tmp, T, D, c->k_patch, s));
+  DVT_TRY(dvt_linear_fwd_big(k.col, (const float*)w->patch_w, w->patch_b, k.tmp, Tg, D, c->k_patch, s));
   hipLaunchKernelGGL(embed_f32_kernel, dim3(T), dim3(256), 0, s, (const float4*)k.tmp, (float4*)k.x,
                      (const float4*)w->cls_token, (const float4*)w->pos_embed, *c);
   DVT_CHECK_LAUNCH();
@@ -538,15 +545,15 @@ extern "C" int dvt_vit_forward_f32(const DvtVitConfig* c, const DvtVitWeights* w
     hipLaunchKernelGGL(layernorm_f32_kernel<false>, dim3(dvt_cdiv(T, 4)), dim3(256), 0, s, k.x, bw.norm1_w,
                        bw.norm1_b, k.xn, T, D, c->ln_eps, 0, 0, 0);
     DVT_CHECK_LAUNCH();
-    DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.qkv_w, bw.qkv_b, k.qkv, T, 3 * D, D, s));
+    DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.qkv_w, bw.qkv_b, k.qkv, Tg, 3 * D, D, s));
     DVT_TRY(dvt_vit_attention_f32(k.qkv, k.ao, batch, c->heads, c->s_pad, c->n_tokens, s));
     // round 5: where the 128 x 128 GEMM kernel takes the shapes, LayerScale + residual and the exact-erf GELU are its epilogues
     // (three passes over fp32 [T, dim] / [T, mlp_dim] tensors per block less); otherwise the separate kernels as before
-    const bool fuse = dvt_linear_big_ok(T, D, D) && dvt_linear_big_ok(T, c->mlp_dim, D) && dvt_linear_big_ok(T, D, c->mlp_dim);
+    const bool fuse = dvt_linear_big_ok(Tg, D, D) && dvt_linear_big_ok(Tg, c->mlp_dim, D) && dvt_linear_big_ok(Tg, D, c->mlp_dim);
     if (fuse) {
-      DVT_TRY(dvt_linear_fwd_big_epi(k.ao, (const float*)bw.proj_w, bw.proj_b, k.x, T, D, D, 2, bw.ls1, s));
+      DVT_TRY(dvt_linear_fwd_big_epi(k.ao, (const float*)bw.proj_w, bw.proj_b, k.x, Tg, D, D, 2, bw.ls1, s));
     } else {
-      DVT_TRY(dvt_linear_fwd_big(k.ao, (const float*)bw.proj_w, bw.proj_b, k.tmp, T, D, D, s));
+      DVT_TRY(dvt_linear_fwd_big(k.ao, (const float*)bw.proj_w, bw.proj_b, k.tmp, Tg, D, D, s));
       hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
                          (const float4*)bw.ls1, nqD, D / 4);
       DVT_CHECK_LAUNCH();
@@ -555,14 +562,14 @@ extern "C" int dvt_vit_forward_f32(const DvtVitConfig* c, const DvtVitWeights* w
                        bw.norm2_b, k.xn, T, D, c->ln_eps, 0, 0, 0);
     DVT_CHECK_LAUNCH();
     if (fuse) {
-      DVT_TRY(dvt_linear_fwd_big_epi(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, T, c->mlp_dim, D, 1, nullptr, s));
-      DVT_TRY(dvt_linear_fwd_big_epi(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.x, T, D, c->mlp_dim, 2, bw.ls2, s));
+      DVT_TRY(dvt_linear_fwd_big_epi(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, Tg, c->mlp_dim, D, 1, nullptr, s));
+      DVT_TRY(dvt_linear_fwd_big_epi(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.x, Tg, D, c->mlp_dim, 2, bw.ls2, s));
     } else {
-      DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, T, c->mlp_dim, D, s));
+      DVT_TRY(dvt_linear_fwd_big(k.xn, (const float*)bw.fc1_w, bw.fc1_b, k.hid, Tg, c->mlp_dim, D, s));
       hipLaunchKernelGGL(gelu_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.hid,
                          (long long)T * c->mlp_dim / 4);
       DVT_CHECK_LAUNCH();
-      DVT_TRY(dvt_linear_fwd_big(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.tmp, T, D, c->mlp_dim, s));
+      DVT_TRY(dvt_linear_fwd_big(k.hid, (const float*)bw.fc2_w, bw.fc2_b, k.tmp, Tg, D, c->mlp_dim, s));
       hipLaunchKernelGGL(resid_f32_kernel, dim3(ew_blocks), dim3(256), 0, s, (float4*)k.x, (const float4*)k.tmp,
                          (const float4*)bw.ls2, nqD, D / 4);
       DVT_CHECK_LAUNCH();

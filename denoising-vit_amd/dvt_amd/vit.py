@@ -265,8 +265,8 @@ class HipViT:
         dim = sd["pos_embed"].shape[-1]
         depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
         n_reg = int(sd["reg_token"].shape[1]) if "reg_token" in sd else 0
-        row_pad = 128
-        if dtype == "bfloat16":
+        row_pad = 128  # (the bf16x3 forward: its split kernels walk 64-token blocks of whole 128-row images)
+        if not self.x3:  # bf16 (round 6) and exact fp32 (round 6, second session): any multiple of 32 -- 1370 tokens -> 1376 rows
             env = os.environ.get("DVT_VIT_ROW_PAD", "")
             row_pad = int(env) if env.isdigit() and int(env) > 0 else 32
         self.cfg = vit_config(dim, depth, patch, stride, img_size[0], img_size[1], n_reg, row_pad=row_pad)

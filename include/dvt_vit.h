@@ -37,8 +37,9 @@ typedef struct DvtVitConfig {
   int32_t img_h, img_w; /* 518 x 518 */
   int32_t grid_h, grid_w; /* (img - patch) / stride + 1 = 37 */
   int32_t n_tokens;  /* n_prefix + grid_h * grid_w = 1370 */
-  int32_t s_pad;     /* token rows per image: >= n_tokens, a multiple of 32 for dvt_vit_forward (dvt_amd uses 1376 for 1370 tokens
-                      * since round 6), of 128 for the fp32 / bf16x3 forwards; dvt_vit_config writes the next multiple of 128 */
+  int32_t s_pad;     /* token rows per image: >= n_tokens, a multiple of 32 for dvt_vit_forward and dvt_vit_forward_f32 (dvt_amd
+                      * uses 1376 for 1370 tokens since round 6), of 128 for the bf16x3 forward; dvt_vit_config writes the next
+                      * multiple of 128 */
   int32_t k_patch;   /* 3 * patch * patch padded to a multiple of 64 (588 -> 640) */
   int32_t n_prefix;  /* prefix tokens: 1 (cls) + register tokens (4 for the *_reg4_* models) */
   float ln_eps;      /* 1e-6 */
@@ -134,7 +135,10 @@ int dvt_vit_attention_x3_presplit(const void* scratch, void* out, int batch, int
 int64_t dvt_vit_workspace_bytes_f32x3(const DvtVitConfig* h_cfg, int batch);
 int dvt_vit_forward_f32x3(const DvtVitConfig* h_cfg, const DvtVitWeights* h_w, const float* img, float* feat,
                           int batch, int n_blocks, void* workspace, void* stream);
-/* fp32 attention on qkv [batch*s_pad, 3*heads*64] (q | k | v, head-major inside): out [batch*s_pad, heads*64] */
+/* fp32 attention on qkv [batch*s_pad, 3*heads*64] (q | k | v, head-major inside): out [batch*s_pad, heads*64].  s_pad % 32 == 0
+ * (round 6); blocks of 128 queries: where s_pad is not a multiple of 128 the kernel READS up to 96 rows behind an image's rows of
+ * qkv as queries (the next image's, or whatever lies behind the last one: nothing of them is stored -- the caller keeps those
+ * rows allocated, dvt_vit_workspace_bytes_f32 does); keys are never read behind n_valid's 32-key tile, i.e. inside the image. */
 int dvt_vit_attention_f32(const float* qkv, float* out, int batch, int heads, int s_pad, int n_valid, void* stream);
 
 /* ---- building blocks, exported for parity tests ---- */

@@ -355,7 +355,8 @@ def test_wrapper_api_full_depth(L):
         PretrainedViTWrapper("vit_base_patch16_224.mae", stride=16)
 
 
-@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370)])
+@pytest.mark.parametrize("batch,heads,s_pad,n_valid", [(2, 2, 128, 100), (1, 3, 256, 256), (1, 2, 1408, 1370), (3, 2, 1376, 1370),
+                                                        (2, 1, 160, 150), (2, 2, 32, 20)])
 def test_attention_f32_vs_torch(L, batch, heads, s_pad, n_valid):
     """fp32 attention of the `--dtype float32` extractor (exact-fp32 MFMA, P kept in the accumulator registers)"""
     torch.manual_seed(s_pad + heads)
@@ -365,13 +366,18 @@ def test_attention_f32_vs_torch(L, batch, heads, s_pad, n_valid):
     v = torch.randn(batch, s_pad, heads, 64) * torch.linspace(0.5, 1.5, 64)
     att = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double() * 0.125, k.double()[:, :n_valid]), -1)
     want = torch.einsum("bhqk,bkhd->bqhd", att, v.double()[:, :n_valid]).reshape(batch, s_pad, dim)
-    qkv = torch.cat([q.reshape(batch * s_pad, dim), k.reshape(batch * s_pad, dim), v.reshape(batch * s_pad, dim)],
-                    1).contiguous().to(DEV)
-    out = torch.empty((batch * s_pad, dim), device=DEV, dtype=torch.float32)
+    rows = batch * s_pad
+    qkv = torch.full((rows + 128, 3 * dim), float("nan"))  # what the last block reads behind the last image: NaN, never stored
+    qkv[:rows] = torch.cat([q.reshape(rows, dim), k.reshape(rows, dim), v.reshape(rows, dim)], 1)
+    qkv = qkv.to(DEV)
+    out = torch.full((rows + 128, dim), 7.0, device=DEV, dtype=torch.float32)
     assert L.dvt_vit_attention_f32(qkv.data_ptr(), out.data_ptr(), batch, heads, s_pad, n_valid, _s()) == 0
-    got = out.reshape(batch, s_pad, dim).cpu()
+    torch.cuda.synchronize()
+    assert bool((out[rows:] == 7.0).all()), "a query block behind the last image stored its rows"
+    got = out[:rows].reshape(batch, s_pad, dim).cpu()
     assert rel(got[:, :n_valid], want[:, :n_valid]) < 2e-5
     assert bool(torch.isfinite(got).all())
+    assert L.dvt_vit_attention_f32(qkv.data_ptr(), out.data_ptr(), batch, heads, s_pad + 8, n_valid, _s()) == -1
 
 
 @pytest.mark.parametrize("dim,depth,img,stride,n_reg", [(128, 2, 56, 14, 0), (256, 2, 98, 7, 4), (768, 2, 518, 14, 0)])
