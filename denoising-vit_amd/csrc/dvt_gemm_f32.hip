@@ -680,6 +680,93 @@ __global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmArgs p) {
   }
 }
 
+// ---- the same 128 x 128 tile for the WEIGHT-GRADIENT product of the stage-2 trainer (round 6): C[M][N] (+)= sum_k A(m, k) B(k, n) with
+// BOTH operands stored reduction-index-major -- A_mem[k][m] = dy[row][out feature], B_mem[k][n] = x[row][in feature]; the
+// reduction runs over the 45 056 token rows of a batch, split over blockIdx.z with one atomic add per split and element.
+// A stage is 32 rows of each operand, [row][128] floats as they lie in memory (whole 512-B row pieces per LDS-DMA
+// instruction, lane-linear: no swizzle needed -- an MFMA 32x32x2 operand is ONE float per lane, lane i of a half-wave reads
+// column i of row 2 s + (lane >> 5): 32 consecutive dwords, conflict-free ds_read_b32).  Per stage and wave 64 reads feed 64
+// MFMAs (2 x 2 accumulator blocks, four independent chains).  colsum[m] += sum_k A(m, k) (the bias gradient) by the n-tile-0
+// blocks from the fragments they read anyway.  Two 32-KB stages = two workgroups per CU, as the forward kernel.
+__device__ __forceinline__ void stage_rows_big(const float* __restrict__ X, int ld, int k0, int c0, float* lds, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = it * 256 + wave * 64 + lane;  // 16-B slot: row s >> 5, columns 4 (s & 31) ..
+    glds16f(X + (size_t)(k0 + (s >> 5)) * ld + c0 + (s & 31) * 4, lds + (it * 256 + wave * 64) * 4);
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_big_tn_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * GB_STAGE_FLOATS];  // 64 KB, one LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+  const int kbeg = blockIdx.z * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
+  const int nk = (kend - kbeg) / GB_BK;
+  const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0 && wn == 0;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float csum[2] = {0.f, 0.f};
+#define GT_ISSUE(kt)                                                                       \
+  do {                                                                                     \
+    float* st_ = smem + ((kt) & 1) * GB_STAGE_FLOATS;                                      \
+    stage_rows_big(p.A, p.lda, kbeg + (kt) * GB_BK, m0, st_, wave, lane);                  \
+    stage_rows_big(p.B, p.ldb, kbeg + (kt) * GB_BK, n0, st_ + GB_TILE_FLOATS, wave, lane); \
+  } while (0)
+  if (nk > 0) GT_ISSUE(0);
+  const int l31 = lane & 31, kh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) GT_ISSUE(kt + 1);
+    const float* As = smem + (kt & 1) * GB_STAGE_FLOATS + kh * 128 + wm * 64 + l31;
+    const float* Bs = smem + (kt & 1) * GB_STAGE_FLOATS + GB_TILE_FLOATS + kh * 128 + wn * 64 + l31;
+#pragma unroll
+    for (int s = 0; s < GB_BK / 2; ++s) {  // rows 2 s + kh of the stage
+      const float a0 = As[s * 256], a1 = As[s * 256 + 32], b0 = Bs[s * 256], b1 = Bs[s * 256 + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (do_colsum) {
+        csum[0] += a0;
+        csum[1] += a1;
+      }
+    }
+  }
+#undef GT_ISSUE
+  // C/D layout of the 32x32 MFMA: col = lane & 31 (n), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (m)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gn = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float* c = p.C + (size_t)gm * p.ldc + gn;
+        if (p.atomic)
+          atomic_add_f32(c, acc[i][j][r]);
+        else
+          *c = acc[i][j][r];
+      }
+  }
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+      if (kh == 0) atomic_add_f32(p.colsum + m0 + wm * 64 + i * 32 + l31, v);
+    }
+  }
+}
+
 int g_f32_big = 1;  // dvt_tune_set(4, 10 / 11): the 128 x 128 kernel of dvt_linear_fwd_big off / on (A/B; results differ in summation order only)
 int g_f32_glds = 1;  // 0: always the register-staged kernel
 int g_f32_ex_stages = 2;  // LDS stages of the stage-2 GEMMs (dvt_gemm_f32_ex): 2 or 3
@@ -998,6 +1085,33 @@ int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s) {
 
 // the 128 x 128 x 32 kernel takes this shape (and with it the fused GELU / residual epilogues below)
 bool dvt_linear_big_ok(int m, int n, int k) { return g_f32_big && m > 0 && m % 128 == 0 && n % 128 == 0 && k % GB_BK == 0; }
+
+// dw[n][k] (+)= sum_r dy[r][n] x[r][k], db[n] += sum_r dy[r][n] on the 128 x 128 tile (gemm_f32_big_tn_kernel); n, k multiples of
+// 128, rows of 32; `accumulate`: atomic adds into dw (the reduction is split so that ~1024 workgroups exist), else ONE split
+bool dvt_linear_wgrad_big_ok(int rows, int n, int k) { return g_f32_big && rows > 0 && rows % GB_BK == 0 && n % 128 == 0 && k % 128 == 0; }
+int dvt_linear_wgrad_big(const float* dy, const float* x, float* dw, float* db, int rows, int n, int k, int accumulate,
+                         hipStream_t s) {
+  if (!dy || !x || !dw || !dvt_linear_wgrad_big_ok(rows, n, k)) return DVT_E_BADARG;
+  GemmArgs a{};
+  a.A = dy; a.B = x; a.C = dw;
+  a.M = n; a.N = k; a.K = rows;
+  a.lda = n; a.ldb = k; a.ldc = k;
+  a.colsum = db;
+  a.atomic = accumulate;
+  const int tiles = (n / 128) * (k / 128), ktiles = rows / GB_BK;
+  int splits = 1;
+  if (accumulate) {
+    splits = dvt_cdiv(1024, tiles);
+    if (splits > ktiles / 8) splits = ktiles / 8;
+    if (splits < 1) splits = 1;
+  }
+  a.kchunk = dvt_cdiv(ktiles, splits) * GB_BK;
+  splits = dvt_cdiv(rows, a.kchunk);
+  DvtProbeScope probe(DVT_PROBE_FIT_GEMM, s, 2.0 * a.M * a.N * a.K);
+  hipLaunchKernelGGL(gemm_f32_big_tn_kernel, dim3(k / 128, n / 128, splits), dim3(256), 0, s, a);
+  DVT_CHECK_LAUNCH();
+  return 0;
+}
 
 // y = epi(x . w^T + b) on the 128 x 128 x 32 kernel ONLY (dvt_linear_big_ok): epi 1 = exact-erf GELU, epi 2 = y += gamma (.) (.)
 int dvt_linear_fwd_big_epi(const float* x, const float* w, const float* b, float* y, int m, int n, int k, int epi,

@@ -22,6 +22,10 @@
 // dvt_gemm_f32.hip: the fp32 extractor's 128 x 128 x 32 exact-fp32 MFMA tile (x . w^T + b, shapes per dvt_linear_big_ok)
 int dvt_linear_fwd_big(const float* x, const float* w, const float* b, float* y, int m, int n, int k, hipStream_t s);
 bool dvt_linear_big_ok(int m, int n, int k);
+bool dvt_linear_wgrad_big_ok(int rows, int n, int k);
+int dvt_linear_wgrad_big(const float* dy, const float* x, float* dw, float* db, int rows, int n, int k, int accumulate,
+                         hipStream_t s);
+int g_s2_big_wgrad = 1;  // DVT_S2_BIG_WGRAD=0: the weight-gradient GEMMs on the 64 x 64 tile (A/B)
 int g_s2_big_bwd = 1;  // DVT_S2_BIG_BWD=0: the data-gradient GEMMs on the 64 x 64 tile (A/B)
 int g_s2_big_fwd = 1;  // DVT_S2_BIG=0 in the environment of the process: the 64 x 64 tile for the forward layers too (A/B)
 
@@ -553,14 +557,18 @@ __global__ __launch_bounds__(256) void s2_transpose_kernel(const float* __restri
 // 2 x 9 MB of traffic at most per layer, the GEMM 0.07-0.2 TFLOP.  Summation order differs from the 64 x 64 kernel only.
 int lin_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int R, int n, int k,
             hipStream_t s, float* wT = nullptr) {
-  DvtGemmEx g{};
-  g.layout = 2;
-  g.A = dy; g.B = x; g.C = dw;
-  g.M = n; g.N = k; g.K = R;
-  g.lda = n; g.ldb = k; g.ldc = k;
-  g.colsum = db;
-  g.accumulate = 1;
-  S2_TRY(dvt_gemm_f32_ex(&g, s));
+  if (g_s2_big_wgrad && dvt_linear_wgrad_big_ok(R, n, k)) {  // round 6: the weight gradient on the 128 x 128 tile too
+    S2_TRY(dvt_linear_wgrad_big(dy, x, dw, db, R, n, k, 1, s));
+  } else {
+    DvtGemmEx g{};
+    g.layout = 2;
+    g.A = dy; g.B = x; g.C = dw;
+    g.M = n; g.N = k; g.K = R;
+    g.lda = n; g.ldb = k; g.ldc = k;
+    g.colsum = db;
+    g.accumulate = 1;
+    S2_TRY(dvt_gemm_f32_ex(&g, s));
+  }
   if (!dx) return 0;
   if (wT && g_s2_big_bwd && n % 32 == 0 && k % 32 == 0 && dvt_linear_big_ok(R, k, n)) {
     hipLaunchKernelGGL(s2_transpose_kernel, dim3(k / 32, n / 32), dim3(256), 0, s, w, wT, n, k);
@@ -735,6 +743,8 @@ static void s2_read_env() {
   if (e && e[0] == '0') g_s2_big_fwd = 0;
   e = getenv("DVT_S2_BIG_BWD");
   if (e && e[0] == '0') g_s2_big_bwd = 0;
+  e = getenv("DVT_S2_BIG_WGRAD");
+  if (e && e[0] == '0') g_s2_big_wgrad = 0;
 }
 
 extern "C" int dvt_s2_forward(const DvtS2Config* cfg, const float* params, const float* x, float* pred, int batch,
