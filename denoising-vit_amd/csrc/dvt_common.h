@@ -276,6 +276,11 @@ struct DvtGemmEx {
   int accumulate;
   int nb0, nb1;
   long long sA0, sA1, sB0, sB1, sC0, sC1;
+  // softmax-backward epilogue (batched layout 0 with K <= 64 only; round 6): C = oscale * smul (.) (A B^T - rowsub), smul
+  // indexed like C (batch strides sC0 / sC1, leading dimension ldc), rowsub[(b0 * nb1 + b1) * M + m]
+  const float* smul;
+  const float* rowsub;
+  float oscale;
 };
 int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s);
 // bf16_operands: round operands to bf16 while staging (autocast semantics), fp32 otherwise

@@ -47,6 +47,11 @@ struct GemmArgs {
   // C[m][n] += gamma[n] * (acc + bias[n]) (timm Block: x = x + ls(f(norm(x))))
   int epi;
   const float* gamma;
+  // gemm_f32_body, set by the batched small-k kernel only: C = oscale * smul[m][n] * (acc - rowsub[m]) -- the softmax backward
+  // dS = scale P (.) (dP - rowsum(dP (.) P)) as the epilogue of dP = dO V^T, with rowsum(dP (.) P) = dO . O handed in
+  const float* smul;
+  const float* rowsub;
+  float oscale;
 };
 
 // Operand tile of R rows x BK: R*BK/4 float4, spread over NT threads.  BK is a template
@@ -181,6 +186,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& p, int bx, int by,
       float v = acc[r] + bias;
       if (p.relu) v = fmaxf(v, 0.f);
       if (p.mask != nullptr) v = p.mask[(size_t)gm * p.ldmask + gn] > 0.f ? v : 0.f;
+      if (p.smul != nullptr) v = p.oscale * p.smul[(size_t)gm * p.ldc + gn] * (v - p.rowsub[gm]);
       float* c = p.C + (size_t)gm * p.ldc + gn;
       if (p.atomic)
         atomic_add_f32(c, v);
@@ -569,6 +575,10 @@ __global__ __launch_bounds__(256) void gemm_f32_batched_small_k_kernel(GemmArgs 
   q.A = p.A + b0 * d.sA0 + b1 * d.sA1;
   q.B = p.B + b0 * d.sB0 + b1 * d.sB1;
   q.C = p.C + b0 * d.sC0 + b1 * d.sC1;
+  if (p.smul != nullptr) {
+    q.smul = p.smul + b0 * d.sC0 + b1 * d.sC1;
+    q.rowsub = p.rowsub + (size_t)blockIdx.z * p.M;
+  }
   gemm_f32_body<A_KC, B_KC, 2, 2, 64>(q, blockIdx.x, blockIdx.y, 0, As, Bs);
 }
 
@@ -1036,6 +1046,13 @@ int dvt_gemm_f32_ex(const DvtGemmEx* g, hipStream_t s) {
   a.bias = g->bias;
   a.colsum = g->layout == 2 ? g->colsum : nullptr;
   a.atomic = g->accumulate;
+  if (g->smul != nullptr) {  // softmax-backward epilogue: the batched small-k kernel only
+    const int nb_ = (g->nb0 > 0 ? g->nb0 : 1) * (g->nb1 > 0 ? g->nb1 : 1);
+    if (!g->rowsub || g->layout != 0 || nb_ <= 1 || g->K > BK || g->accumulate) return DVT_E_BADARG;
+    a.smul = g->smul;
+    a.rowsub = g->rowsub;
+    a.oscale = g->oscale;
+  }
   if (a.K % BK) return DVT_E_BADARG;
   const bool a_kc = g->layout != 2, b_kc = g->layout == 0;
   if ((!a_kc && (a.M % 64)) || (!b_kc && (a.N % 64)) || (a.lda & 3) || (a.ldb & 3)) return DVT_E_BADARG;

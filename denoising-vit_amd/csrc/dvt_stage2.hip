@@ -25,6 +25,8 @@ bool dvt_linear_big_ok(int m, int n, int k);
 bool dvt_linear_wgrad_big_ok(int rows, int n, int k);
 int dvt_linear_wgrad_big(const float* dy, const float* x, float* dw, float* db, int rows, int n, int k, int accumulate,
                          hipStream_t s);
+int g_s2_attn_rows = 1;  // DVT_S2_ATTN_ROWS=0: the [Tp][Tp] products on the 64 x 64 GEMM tile + separate softmax passes (A/B)
+int g_s2_fuse_softmax_bwd = 1;  // DVT_S2_FUSE_SOFTMAX_BWD=0: dP written, s2_softmax_bwd_kernel over it (A/B)
 int g_s2_big_wgrad = 1;  // DVT_S2_BIG_WGRAD=0: the weight-gradient GEMMs on the 64 x 64 tile (A/B)
 int g_s2_big_bwd = 1;  // DVT_S2_BIG_BWD=0: the data-gradient GEMMs on the 64 x 64 tile (A/B)
 int g_s2_big_fwd = 1;  // DVT_S2_BIG=0 in the environment of the process: the 64 x 64 tile for the forward layers too (A/B)
@@ -298,6 +300,186 @@ __global__ __launch_bounds__(256) void s2_softmax_bwd_kernel(const float* __rest
   }
 }
 
+
+// ==========================================================================================================
+// Round 6: the two [Tp][Tp]-sized products of a head WITH the softmax arithmetic that used to run over their output.
+// One workgroup = 128 query rows of one (image, head): 4 waves x 32 rows, the row operand (q, or d ao) lives in registers
+// -- 32 fragment values per lane, as in the fp32 extractor's attention kernel --, the key-side operand (k, or v) streams
+// through LDS in 32-key tiles (two buffers, one barrier per tile).  v_mfma_f32_32x32x2_f32 in BOTH operand orders off the
+// SAME registers and the same LDS reads:
+//   T-order  D = K_tile . A^T   lane holds query (lane & 31), keys kappa(r) + 4 (lane >> 5): row statistics are lane-local
+//   N-order  D = A . K_tile^T   lane holds key (lane & 31), queries kappa(r) + 4 (lane >> 5): a half-wave stores 32
+//                               consecutive keys of one query row = one whole 128-B line per instruction
+// MODE 0, forward (main_denoiser.py:138-140 -> timm Attention.forward: softmax(q k^T / 8)): sweep 1 in T-order forms every
+//   query's running max and sum (base 2, the scale folded into q), sweep 2 recomputes the logits in N-order and writes
+//   P = 2^(s - m) / l ONCE.  Before: S written by a 64 x 64-tile GEMM (186 k workgroups of 32 MFMAs per wave), read and
+//   rewritten by s2_softmax_kernel: 9 GB of traffic, 1.76 + 1.22 ms per step at batch 32.  Padded query rows and key columns
+//   (>= T) get P = 0, as s2_softmax_kernel wrote them.
+// MODE 1, backward: dS = scale P (.) (dao v^T - D) in N-order, D = rowsum(dP (.) P) = dao . ao from s2_rowdot_kernel; P is
+//   read once (requested a tile ahead), dP never exists.
+// ==========================================================================================================
+constexpr int AR_Q = 128, AR_K = 32, AR_LD = 65;  // odd pitch: the 32 rows of a key-tile fragment read hit 32 banks
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void s2_attn_rows_kernel(const float* __restrict__ rowop, int ld_row, const float* __restrict__ keyop,
+                                                           int ld_key, const float* __restrict__ Pin, const float* __restrict__ D,
+                                                           float* __restrict__ out, int heads, int T, int Tp, float scale) {
+  __shared__ float Ks[2][AR_K * AR_LD];
+  __shared__ float stat[2][AR_Q];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h2 = lane >> 5;
+  const int nqb = Tp / AR_Q;
+  const int id = blockIdx.x;
+  const int qb = id % nqb, hd = (id / nqb) % heads, b = id / (nqb * heads);
+  const size_t row0 = (size_t)b * Tp;
+  const int q0w = qb * AR_Q + wave * 32;  // first query row of this wave inside the image
+  const float LOG2E = 1.4426950408889634f;
+  // row-operand fragments of this lane: A[query q0w + j][d = 2 s + h2] (forward: q * scale * log2(e): softmax in base 2)
+  float af[32];
+  {
+    const float* ap = rowop + (row0 + q0w + j) * ld_row + hd * 64 + h2;
+    const float f = MODE == 0 ? scale * LOG2E : 1.0f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) af[s] = ap[2 * s] * f;
+  }
+  const float* kbase = keyop + row0 * ld_key + hd * 64;
+  float* obase = out + ((size_t)(b * heads + hd) * Tp) * Tp;
+  const float* pbase = MODE == 1 ? Pin + ((size_t)(b * heads + hd) * Tp) * Tp : nullptr;
+  const int ntiles = Tp / AR_K;
+  const int key0 = tid >> 4, dq0 = tid & 15;  // staging: 32 keys x 64 d = 512 float4, two per thread (second: key0 + 16)
+  float4 kr[2];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      kr[it] = *reinterpret_cast<const float4*>(kbase + (size_t)(kt * AR_K + key0 + 16 * it) * ld_key + dq0 * 4);
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float* kd = Ks[buf] + (key0 + 16 * it) * AR_LD + dq0 * 4;
+      kd[0] = kr[it].x; kd[1] = kr[it].y; kd[2] = kr[it].z; kd[3] = kr[it].w;
+    }
+  };
+  if constexpr (MODE == 0) {
+    // ---- sweep 1 (T-order): running max / sum per query, lane-local over its 16 keys of a tile
+    float m_run = -1e30f, l_run = 0.f;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < ntiles;
+      if (more) fetch(kt + 1);
+      const float* K = Ks[cur];
+      floatx16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(K[j * AR_LD + 2 * t + h2], af[t], s, 0, 0, 0);
+      float tmax = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * AR_K + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (key >= T) s[r] = -1e30f;
+        tmax = fmaxf(tmax, s[r]);
+      }
+      const float m_new = fmaxf(m_run, tmax);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) psum += __builtin_amdgcn_exp2f(s[r] - m_new);
+      l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + psum;
+      m_run = m_new;
+      if (more) park(cur ^ 1);
+      __syncthreads();
+    }
+    {  // the two lanes of a query (h2 = 0 / 1) hold disjoint keys: merge, then (m, 1 / l) of the wave's 32 queries -> LDS
+      const float m2 = __shfl_xor(m_run, 32, 64), l2 = __shfl_xor(l_run, 32, 64);
+      const float mt = fmaxf(m_run, m2);
+      const float lt = l_run * __builtin_amdgcn_exp2f(m_run - mt) + l2 * __builtin_amdgcn_exp2f(m2 - mt);
+      if (h2 == 0) {
+        stat[0][wave * 32 + j] = mt;
+        stat[1][wave * 32 + j] = 1.0f / lt;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the N-order sweep: lane = key column (lane & 31), rows kappa(r) + 4 h2 of the wave's 32 queries
+  float rs0[16], rs1[16];  // per row: forward (m, 1 / l); backward (D, -)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qi = (r & 3) + 8 * (r >> 2) + 4 * h2;
+    if constexpr (MODE == 0) {
+      rs0[r] = stat[0][wave * 32 + qi];
+      rs1[r] = q0w + qi < T ? stat[1][wave * 32 + qi] : 0.f;  // padded query rows: P = 0
+    } else {
+      rs0[r] = D[(size_t)(b * heads + hd) * Tp + q0w + qi];
+      rs1[r] = scale;
+    }
+  }
+  float pr[16];
+  auto fetch_p = [&](int kt) {
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h2;
+        pr[r] = pbase[(size_t)(q0w + qi) * Tp + kt * AR_K + j];
+      }
+    }
+  };
+  fetch(0);
+  park(0);
+  fetch_p(0);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) fetch(kt + 1);
+    const float* K = Ks[cur];
+    floatx16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], K[j * AR_LD + 2 * t + h2], s, 0, 0, 0);
+    const int key = kt * AR_K + j;
+    float o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (MODE == 0) o[r] = key < T ? __builtin_amdgcn_exp2f(s[r] - rs0[r]) * rs1[r] : 0.f;
+      else o[r] = rs1[r] * pr[r] * (s[r] - rs0[r]);
+    }
+    if (more) fetch_p(kt + 1);  // (behind the uses of this tile's P)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * h2;
+      obase[(size_t)(q0w + qi) * Tp + key] = o[r];
+    }
+    if (more) park(cur ^ 1);
+    __syncthreads();
+  }
+}
+
+// D[(b * heads + h) * Tp + t] = sum_d dO[b * Tp + t][64 h + d] * O[b * Tp + t][64 h + d] = rowsum(dP (.) P) of that (image, head, query)
+// (O = P V, dP = dO V^T): what the softmax backward subtracts, from two [R][C] tensors instead of two [.., Tp][Tp] ones.  One
+// wave per token row, 16 lanes per head pass (C / 64 heads, 4 per pass).
+__global__ __launch_bounds__(256) void s2_rowdot_kernel(const float* __restrict__ dO, const float* __restrict__ O,
+                                                        float* __restrict__ D, int R, int Tp, int C) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int b = r / Tp, t = r - b * Tp, heads = C >> 6;
+  const float4* a = reinterpret_cast<const float4*>(dO + (size_t)r * C);
+  const float4* o = reinterpret_cast<const float4*>(O + (size_t)r * C);
+  for (int h0 = 0; h0 < heads; h0 += 4) {  // 64 lanes x float4 = 4 heads of 64 columns
+    const int h = h0 + (lane >> 4);
+    float v = h < heads ? f4_dot(a[h0 * 16 + lane], o[h0 * 16 + lane]) : 0.f;
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    if ((lane & 15) == 0 && h < heads) D[((size_t)b * heads + h) * Tp + t] = v;
+  }
+}
+
 // ==========================================================================================================
 // Loss and its gradient, one wave per row (main_denoiser.py:213-217):
 //   o = a + b (the last residual add);  l2 = mean((o - t)^2) over batch*T*C;
@@ -452,6 +634,7 @@ struct S2Block {  // activations a block keeps for its backward pass
 struct S2Work {
   S2Block blk[DVT_S2_MAX_BLOCKS];
   float *tmp, *d0, *d1, *d2, *dh, *dqkv, *dP, *acc;
+  float* rowdot;  // training: [batch * heads * Tp] rowsum(dP (.) P) of the softmax backward (s2_rowdot_kernel)
   float* wT;  // training: one transposed weight matrix (max(3 C, F) x C floats), rebuilt in front of each data-gradient GEMM
 };
 
@@ -494,6 +677,7 @@ int64_t carve(const DvtS2Config* c, int batch, int training, char* base, S2Work*
     t.dP = take(PP);
     t.acc = take(64);
     t.wT = take((3 * C > F ? 3 * C : F) * C);
+    t.rowdot = take((int64_t)batch * c->heads * c->tokens_pad);
   }
   if (w) *w = t;
   return o;
@@ -614,6 +798,7 @@ int run(const DvtS2Config* c, const float* params, float* grads, const float* x,
   const int R = batch * Tp;
   const int64_t rowsP = (int64_t)batch * H * Tp;
   const float scale = 0.125f;  // head_dim^-0.5
+  const bool attn_rows = g_s2_attn_rows && Tp % AR_Q == 0;  // s2_attn_rows_kernel walks whole blocks of 128 query rows
   const AttnDims ad{batch, H, Tp, C};
   const long long qs0 = (long long)Tp * 3 * C, qs1 = 64, ps0 = (long long)H * Tp * Tp, ps1 = (long long)Tp * Tp,
                   os0 = (long long)Tp * C, os1 = 64;
@@ -628,10 +813,17 @@ int run(const DvtS2Config* c, const float* params, float* grads, const float* x,
     if (!training && (b & 1)) k.xin = w.d0;  // inference with several blocks: block inputs ping-pong
     S2_TRY(lin_fwd(k.xn1, P(b, QKVW), P(b, QKVB), k.qkv, R, 3 * C, C, s));
     {  // S = q k^T  ->  P = softmax(scale S)  ->  ao = P v
-      DvtGemmEx g = attn_gemm(ad, 0, k.qkv, 3 * C, qs0, qs1, k.qkv + C, 3 * C, qs0, qs1, k.P, Tp, ps0, ps1, Tp, Tp, 64);
-      S2_TRY(dvt_gemm_f32_ex(&g, s));
-      hipLaunchKernelGGL(s2_softmax_kernel, dim3(dvt_cdiv(rowsP, 4)), dim3(256), 0, s, k.P, T, Tp, rowsP, scale);
-      DVT_CHECK_LAUNCH();
+      DvtGemmEx g{};
+      if (attn_rows) {  // round 6: q k^T and the softmax in one kernel, P written once
+        hipLaunchKernelGGL(s2_attn_rows_kernel<0>, dim3((Tp / AR_Q) * H * batch), dim3(256), 0, s, (const float*)k.qkv, 3 * C,
+                           (const float*)(k.qkv + C), 3 * C, (const float*)nullptr, (const float*)nullptr, k.P, H, T, Tp, scale);
+        DVT_CHECK_LAUNCH();
+      } else {
+        g = attn_gemm(ad, 0, k.qkv, 3 * C, qs0, qs1, k.qkv + C, 3 * C, qs0, qs1, k.P, Tp, ps0, ps1, Tp, Tp, 64);
+        S2_TRY(dvt_gemm_f32_ex(&g, s));
+        hipLaunchKernelGGL(s2_softmax_kernel, dim3(dvt_cdiv(rowsP, 4)), dim3(256), 0, s, k.P, T, Tp, rowsP, scale);
+        DVT_CHECK_LAUNCH();
+      }
       g = attn_gemm(ad, 1, k.P, Tp, ps0, ps1, k.qkv + 2 * C, 3 * C, qs0, qs1, k.ao, C, os0, os1, Tp, 64, Tp);
       S2_TRY(dvt_gemm_f32_ex(&g, s));
     }
@@ -693,11 +885,28 @@ int run(const DvtS2Config* c, const float* params, float* grads, const float* x,
       // dV = P^T dao
       DvtGemmEx g = attn_gemm(ad, 2, k.P, Tp, ps0, ps1, w.d2, C, os0, os1, w.dqkv + 2 * C, 3 * C, qs0, qs1, Tp, 64, Tp);
       S2_TRY(dvt_gemm_f32_ex(&g, s));
-      // dP = dao v^T
+      // dP = dao v^T, and the softmax backward dS = scale P (.) (dP - rowsum(dP (.) P)).  Round 6: rowsum(dP (.) P) = dao . ao per
+      // (image, head, query) comes from the two [R][C] tensors (s2_rowdot_kernel) and the backward is the EPILOGUE of the dP
+      // product -- dP is never written, P read once (before: 3 GB written + 9 GB read + 3 GB written by s2_softmax_bwd_kernel)
       g = attn_gemm(ad, 0, w.d2, C, os0, os1, k.qkv + 2 * C, 3 * C, qs0, qs1, w.dP, Tp, ps0, ps1, Tp, Tp, 64);
-      S2_TRY(dvt_gemm_f32_ex(&g, s));
-      hipLaunchKernelGGL(s2_softmax_bwd_kernel, dim3(dvt_cdiv(rowsP, 4)), dim3(256), 0, s, (const float*)k.P, w.dP, Tp, rowsP, scale);
-      DVT_CHECK_LAUNCH();
+      if (g_s2_fuse_softmax_bwd && attn_rows) {
+        hipLaunchKernelGGL(s2_rowdot_kernel, dim3(dvt_cdiv(R, 4)), dim3(256), 0, s, (const float*)w.d2, (const float*)k.ao, w.rowdot, R, Tp, C);
+        DVT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(s2_attn_rows_kernel<1>, dim3((Tp / AR_Q) * H * batch), dim3(256), 0, s, (const float*)w.d2, C,
+                           (const float*)(k.qkv + 2 * C), 3 * C, (const float*)k.P, (const float*)w.rowdot, w.dP, H, T, Tp, scale);
+        DVT_CHECK_LAUNCH();
+      } else if (g_s2_fuse_softmax_bwd) {
+        hipLaunchKernelGGL(s2_rowdot_kernel, dim3(dvt_cdiv(R, 4)), dim3(256), 0, s, (const float*)w.d2, (const float*)k.ao, w.rowdot, R, Tp, C);
+        DVT_CHECK_LAUNCH();
+        g.smul = k.P;
+        g.rowsub = w.rowdot;
+        g.oscale = scale;
+        S2_TRY(dvt_gemm_f32_ex(&g, s));
+      } else {
+        S2_TRY(dvt_gemm_f32_ex(&g, s));
+        hipLaunchKernelGGL(s2_softmax_bwd_kernel, dim3(dvt_cdiv(rowsP, 4)), dim3(256), 0, s, (const float*)k.P, w.dP, Tp, rowsP, scale);
+        DVT_CHECK_LAUNCH();
+      }
       // dq = dS k,  dk = dS^T q
       g = attn_gemm(ad, 1, w.dP, Tp, ps0, ps1, k.qkv + C, 3 * C, qs0, qs1, w.dqkv, 3 * C, qs0, qs1, Tp, 64, Tp);
       S2_TRY(dvt_gemm_f32_ex(&g, s));
@@ -743,6 +952,10 @@ static void s2_read_env() {
   if (e && e[0] == '0') g_s2_big_fwd = 0;
   e = getenv("DVT_S2_BIG_BWD");
   if (e && e[0] == '0') g_s2_big_bwd = 0;
+  e = getenv("DVT_S2_ATTN_ROWS");
+  if (e && e[0] == '0') g_s2_attn_rows = 0;
+  e = getenv("DVT_S2_FUSE_SOFTMAX_BWD");
+  if (e && e[0] == '0') g_s2_fuse_softmax_bwd = 0;
   e = getenv("DVT_S2_BIG_WGRAD");
   if (e && e[0] == '0') g_s2_big_wgrad = 0;
 }
