@@ -2126,7 +2126,11 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pf1.v, o[mt], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if constexpr (VAR & 8192) {  // TIMING ONLY (developer library): no tile barrier -- what the lock step of a workgroup's 8 waves costs
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      __syncthreads();
+    }
   };
   if constexpr (SKIPW) {
     if (!active) {
@@ -2332,7 +2336,7 @@ int dvt_vit_tune(int v) {
     g_vit_epi_abl = -560 - v;
     return 0;
   }
-  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024 || v == -540 - 2048 || v == -540 - 4096) {
+  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024 || v == -540 - 2048 || v == -540 - 4096 || v == -540 - 8192) {
     g_vit_attn_l2_mask = ATT_L2_VAR ^ (-540 - v);
     return 0;
   }
@@ -2563,7 +2567,7 @@ extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out
     return 0;                                                                                                         \
   }
     A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR ^ 128) A2L_VAR(ATT_L2_VAR ^ 256) A2L_VAR(ATT_L2_VAR ^ 384) A2L_VAR(ATT_L2_VAR ^ 512)
-    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024) A2L_VAR(ATT_L2_VAR ^ 2048) A2L_VAR(ATT_L2_VAR ^ 4096)
+    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024) A2L_VAR(ATT_L2_VAR ^ 2048) A2L_VAR(ATT_L2_VAR ^ 4096) A2L_VAR(ATT_L2_VAR ^ 8192)
 #undef A2L_VAR
     return DVT_E_BADARG;
   }

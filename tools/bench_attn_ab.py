@@ -66,7 +66,8 @@ if a.lab:
     variants += [("log2q, P.V fragment by fragment (557)", l2(2)), ("log2q, K reads unplaced (47)", l2(512)), ("log2q, both (45)", l2(514)),
                  ("log2q, idle waves compute (559+128)", l2(128)), ("log2q, whole tail tile (559+256)", l2(256)),
                  ("log2q, neither (559+384)", l2(384)), ("log2q, P packed behind the V^T reads (559+1024)", l2(1024)),
-                 ("log2q, s_setprio 1 around P.V (559+2048)", l2(2048)), ("log2q, s_setprio 1 around S + softmax (559+4096)", l2(4096))]
+                 ("log2q, s_setprio 1 around P.V (559+2048)", l2(2048)), ("log2q, s_setprio 1 around S + softmax (559+4096)", l2(4096)),
+                 ("TIMING ONLY: log2q without the tile barrier (559+8192)", l2(8192))]
 times = {n: [] for n, _ in variants}
 for r in range(a.rounds + 1):
     for name, fn in variants:
