@@ -243,6 +243,7 @@ struct DvtProbeScope {
 int dvt_vit_tune(int gemm_variant);
 int dvt_grid_tune(int lds_level_max);
 int dvt_adam_tune(int zero_all);
+int dvt_s2_tune(int mask);
 
 // One linear-layer contraction for the grouped launch (dvt_gemm_f32.hip).
 struct DvtLinearOp {

@@ -1027,6 +1027,7 @@ extern "C" int dvt_tune_set(int key, int value) {
     if (value >= 2) g_fit_lazy_refresh = value;
     return 0;
   }
+  if (key == 18) return dvt_s2_tune(value);
   if (key == 1) return dvt_vit_tune(value);
   if (key == 2) return dvt_grid_tune(value);
   if (key == 3) return dvt_adam_tune(value);

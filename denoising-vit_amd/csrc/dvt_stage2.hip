@@ -944,6 +944,21 @@ extern "C" int64_t dvt_s2_workspace_bytes(const DvtS2Config* cfg, int batch, int
   return carve(cfg, batch, training, nullptr, nullptr);
 }
 
+// dvt_tune_set(18, mask): the same switches from inside a process (tests / A/B tools): bit 0 forward layers, 1 data gradients,
+// 2 weight gradients on the 128 x 128 tile, 3 softmax fused into the attention products, 4 softmax backward without a dP pass;
+// 31 = default.  Results differ in summation order only.
+static void s2_read_env();
+int dvt_s2_tune(int mask) {
+  if (mask < 0 || mask > 31) return DVT_E_BADARG;
+  s2_read_env();  // (so that a later first call does not overwrite this)
+  g_s2_big_fwd = mask & 1;
+  g_s2_big_bwd = (mask >> 1) & 1;
+  g_s2_big_wgrad = (mask >> 2) & 1;
+  g_s2_attn_rows = (mask >> 3) & 1;
+  g_s2_fuse_softmax_bwd = (mask >> 4) & 1;
+  return 0;
+}
+
 static void s2_read_env() {
   static bool done = false;
   if (done) return;

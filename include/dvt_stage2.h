@@ -19,6 +19,13 @@
  * layout reported by dvt_s2_param_offsets; the gradient arena is what a data-parallel trainer all-reduces
  * (ONE flat RCCL all-reduce per step; main_denoiser.py:138-140 uses DistributedDataParallel for this).
  *
+ * Kernels (round 6; every choice changes summation order only, results are held against autograd by tests/test_gpu_stage2.py):
+ * the linear layers' forward, data-gradient (as a forward layer of a transposed weight copy) and weight-gradient GEMMs run the
+ * 128 x 128 x 32 exact-fp32 tile; the softmax is fused into the two [tokens_pad][tokens_pad]-sized attention products around it
+ * (tokens_pad a multiple of 128, else the GEMM + softmax passes).  Environment switches of the process, read once, for A/B runs
+ * only: DVT_S2_BIG=0 / DVT_S2_BIG_BWD=0 / DVT_S2_BIG_WGRAD=0 (64 x 64 tile for forward / data gradient / weight gradient),
+ * DVT_S2_ATTN_ROWS=0 (GEMM + softmax passes), DVT_S2_FUSE_SOFTMAX_BWD=0 (with it: round 5's flow).
+ *
  * Conventions as in dvt_hip.h: int return codes (0 = ok, DVT_E_* / hipError_t otherwise), device pointers
  * owned by the caller, `stream` is a hipStream_t, nothing synchronises.
  */
