@@ -47,7 +47,10 @@ def test_forward_vs_oracle(h, w, c, blocks, batch):
     assert torch.equal(d["original_feats"].cpu(), x)
 
 
-@pytest.mark.parametrize("h,w,c,blocks,batch", [(7, 7, 384, 1, 3), (6, 6, 384, 2, 2), (37, 37, 768, 1, 2)])
+# (11 x 11 = 121 tokens -> 128 padded rows: the fused attention-rows kernel and the 128-row GEMM tiles at other widths / depths;
+# 7 x 7, 6 x 6: 64 padded rows, the 64 x 64-tile fallbacks)
+@pytest.mark.parametrize("h,w,c,blocks,batch", [(7, 7, 384, 1, 3), (6, 6, 384, 2, 2), (37, 37, 768, 1, 2), (11, 11, 384, 2, 3),
+                                                (11, 11, 1024, 1, 2)])
 def test_step_gradients_vs_autograd(h, w, c, blocks, batch):
     ref, mine = make_pair(h, w, c, blocks, seed=1)
     torch.manual_seed(2)
