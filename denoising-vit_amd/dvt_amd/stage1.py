@@ -304,14 +304,35 @@ class Stage1:
         return [e.infer(sl.coords[-1]).unsqueeze(0) for e, sl in zip(engines, group)]
 
     # -- the pipeline --------------------------------------------------------------------------
+    def taper_pays(self) -> bool:
+        """Does a tapered tail (group_plan) pay?  Only where the EXTRACTOR sets the pace: a group's fits must be done before
+        the next group is extracted.  With long fits (the reference's default 25 000 iterations: 5 s of fp32 fit per image
+        against 1.9 s of extraction) the run is fit-bound, sharing every launch between 4 fits is what counts, and a tail of
+        2 + 1 + 1 fits costs 5 s of a 22-s run (measured, profiles/r06/literal_defaults/).  A model, not a measurement: fit
+        ~ 70 (bf16 operands) / 200 (fp32) us per step and fit at 4 fits per launch; extraction ~ 0.35 / 2.5 / 1.2 ms per view of a
+        ViT-B/14 at 518 x 518 (bf16 / fp32 / fp32 "high"), scaled by depth x dim^2 x tokens.  DVT_FIT_TAPER=1 / 0 forces it."""
+        env = os.environ.get("DVT_FIT_TAPER", "")
+        if env in ("0", "1"):
+            return env == "1"
+        return self.taper_model(self.args.num_iters, self.args.num_views + 1, self.extract_dtype, self.extract_matmul,
+                                int(self.layer_index) + 1, self.feat_dim, self.pos_h * self.pos_w + 1)
+
     @staticmethod
-    def group_plan(total: int | None, kb: int) -> list | None:
+    def taper_model(num_iters: int, n_views: int, dtype: str, matmul: str, blocks: int, feat_dim: int, tokens: int) -> bool:
+        fit_s = float(num_iters) * (70e-6 if dtype == "bfloat16" else 200e-6)
+        per_view = 0.35e-3 if dtype == "bfloat16" else (1.2e-3 if matmul == "high" else 2.5e-3)
+        scale = (max(1, blocks) / 12.0) * (feat_dim / 768.0) ** 2 * (tokens / 1370.0)
+        return fit_s < n_views * per_view * scale
+
+    @staticmethod
+    def group_plan(total: int | None, kb: int, taper: bool = True) -> list | None:
         """Sizes of the fit groups of a run of `total` images (None: unknown -- greedy groups of `kb`).  Groups of `kb` share
         every fit launch (68-72 instead of 92 us per fit-step), but a group's fits start only when its LAST image is
         extracted: the run's last group would fit with nothing left to overlap -- 4 fits = 280 ms of a 20-image run.  So
         the tail tapers: ..., kb, kb, 2, 1, 1 (kb >= 4; 1, 1 for kb 2-3): the last extractions run beside the fits before
-        them and only ONE fit (92 ms) drains alone.  A partial group, if any, goes first."""
-        if total is None or kb <= 1 or os.environ.get("DVT_FIT_TAPER", "1") == "0":  # (the switch: same-box A/B runs)
+        them and only ONE fit (92 ms) drains alone.  A partial group, if any, goes first.  `taper` False (fit-bound runs,
+        taper_pays): greedy groups."""
+        if total is None or kb <= 1 or not taper:
             return None
         tail = [2, 1, 1] if kb >= 4 else [1, 1]
         if total <= sum(tail):
@@ -335,7 +356,7 @@ class Stage1:
         kb, dev = self.fit_batch, self.device
         if total is None and hasattr(jobs, "__len__"):
             total = len(jobs)
-        plan = self.group_plan(total, kb)
+        plan = self.group_plan(total, kb, self.taper_pays())
         cur = torch.cuda.current_stream(dev)
         for side in (self.s_vit, self.s_fit):  # work queued by the caller (e.g. resident inputs) comes first
             if side != cur:

@@ -250,3 +250,12 @@ def test_fit_group_plan_tapers_the_tail():
     assert Stage1.group_plan(20, 4) == [4, 4, 4, 4, 2, 1, 1]
     assert Stage1.group_plan(21, 4) == [1, 4, 4, 4, 4, 2, 1, 1]
     assert Stage1.group_plan(3, 4) == [1, 1, 1] and Stage1.group_plan(None, 4) is None
+    # ... and only where the extractor sets the pace (Stage1.taper_pays / taper_model): the metric's configuration yes; the
+    # reference's literal defaults (25 000 iterations: 5 s of fp32 fit against 1.9 s of extraction per image) no -- there a
+    # 2 + 1 + 1 tail cost 5 s of a 22-s run of four images (profiles/r06/literal_defaults/)
+    assert Stage1.group_plan(20, 4, taper=False) is None
+    assert Stage1.taper_model(1000, 769, "bfloat16", "highest", 12, 768, 1370)
+    assert Stage1.taper_model(1000, 769, "float32", "highest", 12, 768, 1370)
+    assert not Stage1.taper_model(25000, 769, "float32", "highest", 12, 768, 1370)
+    assert not Stage1.taper_model(25000, 769, "bfloat16", "highest", 12, 768, 1370)
+    assert Stage1.taper_model(1000, 769, "bfloat16", "highest", 24, 1024, 1370)
