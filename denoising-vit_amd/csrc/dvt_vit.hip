@@ -1997,6 +1997,90 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
         return;
       }
     }
+    if constexpr (L2D && !LAST && (VAR & 16384)) {
+      // (experiment, 16384) the softmax SPLIT over the tile's two blocks, so that both carry matrix work AND exps: block 1 = the
+      // next tile's 8 S MFMAs beside the exps of keys 0..31 (P fragment 0); block 2 = the first four P.V MFMAs (fragment 0)
+      // beside the exps of keys 32..63 (fragment 1), then the other four.  Each half has its own lane-sum vote.  A growth of
+      // the max found by the SECOND vote rescales o and l -- which then already hold the first half's contribution, formed
+      // against the same old max and finite (its vote passed): scaled by the same 2^-d it is what the new max asks for.
+      union PH { bf16x8 v; uint32_t u[4]; };
+      float hp[4][4];
+      auto soft_half = [&](int h) {
+        f32x2 a2, b2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int mt = 2 * h + q;
+          f32x2 e0, e1;
+          e0.x = __builtin_amdgcn_exp2f(s[mt][0]);
+          e0.y = __builtin_amdgcn_exp2f(s[mt][1]);
+          e1.x = __builtin_amdgcn_exp2f(s[mt][2]);
+          e1.y = __builtin_amdgcn_exp2f(s[mt][3]);
+          if (q == 0) {
+            a2 = e0;
+            b2 = e1;
+          } else {
+            a2 += e0;
+            b2 += e1;
+          }
+          hp[mt][0] = e0.x; hp[mt][1] = e0.y; hp[mt][2] = e1.x; hp[mt][3] = e1.y;
+        }
+        a2 += b2;
+        return a2.x + a2.y;
+      };
+      auto pack_half = [&](int h, PH& f) {
+        f.u[0] = pack2(hp[2 * h][0], hp[2 * h][1]); f.u[1] = pack2(hp[2 * h][2], hp[2 * h][3]);
+        f.u[2] = pack2(hp[2 * h + 1][0], hp[2 * h + 1][1]); f.u[3] = pack2(hp[2 * h + 1][2], hp[2 * h + 1][3]);
+      };
+      PH f0, f1;
+      __builtin_amdgcn_sched_barrier(0);
+      A2_S(sn, kt + 1);
+      float ps = soft_half(0);
+      pack_half(0, f0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!__all(ps <= 2980.0f)) {
+        exact_max();
+        ps = soft_half(0);
+        pack_half(0, f0);
+      }
+      l_run += ps;
+      const char* Vs2 = Vb + (kt % NV) * (64 * VT_LD);
+      bf16x8 vf[8];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int vr = mt * 16 + lc, vs_ = (vr >> 1) & 7;
+        const char* vrow = Vs2 + vr * VT_LD;
+        vf[mt] = *reinterpret_cast<const bf16x8*>(vrow + ((g ^ vs_) << 4));
+        vf[4 + mt] = *reinterpret_cast<const bf16x8*>(vrow + (((4 + g) ^ vs_) << 4));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[mt], f0.v, o[mt], 0, 0, 0);
+      float ps1 = soft_half(1);
+      pack_half(1, f1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!__all(ps1 <= 2980.0f)) {
+        exact_max();  // (o and l: the first half's share included, see above)
+        ps1 = soft_half(1);
+        pack_half(1, f1);
+      }
+      l_run += ps1;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[4 + mt], f1.v, o[mt], 0, 0, 0);
+      __syncthreads();
+      return;
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (VAR & 4096) __builtin_amdgcn_s_setprio(1);  // (experiment) ... or the S / softmax block does
     if constexpr (!LAST) A2_S(sn, kt + 1);  // K(kt+1) became visible at the previous barrier (or in the prologue)
@@ -2336,7 +2420,7 @@ int dvt_vit_tune(int v) {
     g_vit_epi_abl = -560 - v;
     return 0;
   }
-  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024 || v == -540 - 2048 || v == -540 - 4096 || v == -540 - 8192) {
+  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024 || v == -540 - 2048 || v == -540 - 4096 || v == -540 - 8192 || v == -540 - 16384) {
     g_vit_attn_l2_mask = ATT_L2_VAR ^ (-540 - v);
     return 0;
   }
@@ -2567,7 +2651,7 @@ extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out
     return 0;                                                                                                         \
   }
     A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR ^ 128) A2L_VAR(ATT_L2_VAR ^ 256) A2L_VAR(ATT_L2_VAR ^ 384) A2L_VAR(ATT_L2_VAR ^ 512)
-    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024) A2L_VAR(ATT_L2_VAR ^ 2048) A2L_VAR(ATT_L2_VAR ^ 4096) A2L_VAR(ATT_L2_VAR ^ 8192)
+    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024) A2L_VAR(ATT_L2_VAR ^ 2048) A2L_VAR(ATT_L2_VAR ^ 4096) A2L_VAR(ATT_L2_VAR ^ 8192) A2L_VAR(ATT_L2_VAR ^ 16384)
 #undef A2L_VAR
     return DVT_E_BADARG;
   }
