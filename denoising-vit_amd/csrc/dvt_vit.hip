@@ -2132,7 +2132,11 @@ __device__ __forceinline__ void attention_v2_body(const bf16_t* __restrict__ qk,
       }
     };
     if constexpr (!(VAR & 1024)) pack();
-    if constexpr (!LAST && (VAR & 512)) {
+    if constexpr (!LAST && (VAR & 32768)) {
+      // (experiment) LLVM's own interleaving strategies for this block instead of the group pattern: 2 = MFMAExpInterleave,
+      // written for exp-heavy attention loops (VAR & 65536: 3 = its simple form)
+      __builtin_amdgcn_iglp_opt((VAR & 65536) ? 3 : 2);
+    } else if constexpr (!LAST && (VAR & 512)) {
       // (experiment) the K fragment reads placed too: four up front, then per MFMA slot 4 VALU, the MFMA, the read that
       // re-fills its fragment registers -- left alone the reads sink behind the exps and every MFMA waits for its own read
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -2420,7 +2424,7 @@ int dvt_vit_tune(int v) {
     g_vit_epi_abl = -560 - v;
     return 0;
   }
-  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024 || v == -540 - 2048 || v == -540 - 4096 || v == -540 - 8192 || v == -540 - 16384) {
+  if (v == -540 || v == -540 - 2 || v == -540 - 128 || v == -540 - 256 || v == -540 - 384 || v == -540 - 512 || v == -540 - 514 || v == -540 - 1024 || v == -540 - 2048 || v == -540 - 4096 || v == -540 - 8192 || v == -540 - 16384 || v == -540 - 32768 || v == -540 - 32768 - 65536) {
     g_vit_attn_l2_mask = ATT_L2_VAR ^ (-540 - v);
     return 0;
   }
@@ -2651,7 +2655,7 @@ extern "C" int dvt_vit_attention_log2q(const void* qk, const void* vt, void* out
     return 0;                                                                                                         \
   }
     A2L_VAR(ATT_L2_VAR ^ 2) A2L_VAR(ATT_L2_VAR ^ 128) A2L_VAR(ATT_L2_VAR ^ 256) A2L_VAR(ATT_L2_VAR ^ 384) A2L_VAR(ATT_L2_VAR ^ 512)
-    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024) A2L_VAR(ATT_L2_VAR ^ 2048) A2L_VAR(ATT_L2_VAR ^ 4096) A2L_VAR(ATT_L2_VAR ^ 8192) A2L_VAR(ATT_L2_VAR ^ 16384)
+    A2L_VAR(ATT_L2_VAR ^ 514) A2L_VAR(ATT_L2_VAR ^ 1024) A2L_VAR(ATT_L2_VAR ^ 2048) A2L_VAR(ATT_L2_VAR ^ 4096) A2L_VAR(ATT_L2_VAR ^ 8192) A2L_VAR(ATT_L2_VAR ^ 16384) A2L_VAR(ATT_L2_VAR ^ 32768) A2L_VAR(ATT_L2_VAR ^ (32768 + 65536))
 #undef A2L_VAR
     return DVT_E_BADARG;
   }

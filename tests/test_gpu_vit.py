@@ -24,7 +24,7 @@ ATTN_MASK_DEFAULT = 15  # dvt_tune_set(1, -510 - mask): schedule mask of the rou
 ATTN_CASES = [(2, 15), "log2q"]
 # ("log2q", x): developer builds of the log2-domain kernel, schedule-mask bits x toggled (dvt_tune_set(1, -540 - x)): the other P.V
 # order, no group pattern for the K reads, the ablation builds (idle waves compute / whole tail tile), P packed behind the V^T reads
-LAB_ATTN_CASES = [(1, 0), (2, 0), (2, 79), ("log2q", 2), ("log2q", 514), ("log2q", 384), ("log2q", 1024), ("log2q", 16384)]
+LAB_ATTN_CASES = [(1, 0), (2, 0), (2, 79), ("log2q", 2), ("log2q", 514), ("log2q", 384), ("log2q", 1024), ("log2q", 16384), ("log2q", 32768), ("log2q", 32768 + 65536)]
 Q_PRESCALE = 0.125 * 1.4426950408889634
 
 

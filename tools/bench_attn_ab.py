@@ -68,7 +68,9 @@ if a.lab:
                  ("log2q, neither (559+384)", l2(384)), ("log2q, P packed behind the V^T reads (559+1024)", l2(1024)),
                  ("log2q, s_setprio 1 around P.V (559+2048)", l2(2048)), ("log2q, s_setprio 1 around S + softmax (559+4096)", l2(4096)),
                  ("TIMING ONLY: log2q without the tile barrier (559+8192)", l2(8192)),
-                 ("log2q, softmax split over the two blocks (559+16384)", l2(16384))]
+                 ("log2q, softmax split over the two blocks (559+16384)", l2(16384)),
+                 ("log2q, iglp_opt(2) MFMAExpInterleave for the softmax block", l2(32768)),
+                 ("log2q, iglp_opt(3) for the softmax block", l2(32768 + 65536))]
 times = {n: [] for n, _ in variants}
 for r in range(a.rounds + 1):
     for name, fn in variants:
