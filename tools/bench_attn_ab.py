@@ -26,6 +26,7 @@ ap.add_argument("--n_valid", type=int, default=1370)
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--lab", action="store_true")
+ap.add_argument("--only", default="", help="with --lab: comma-separated toggles x of dvt_tune_set(1, -540 - x) to compare (0 = the product's mask)")
 a = ap.parse_args()
 
 if a.lab:
@@ -71,6 +72,8 @@ if a.lab:
                  ("log2q, softmax split over the two blocks (559+16384)", l2(16384)),
                  ("log2q, iglp_opt(2) MFMAExpInterleave for the softmax block", l2(32768)),
                  ("log2q, iglp_opt(3) for the softmax block", l2(32768 + 65536))]
+if a.lab and a.only:
+    variants = [(f"log2q, mask 559 ^ {int(x)}", l2(int(x))) for x in a.only.split(",")]
 times = {n: [] for n, _ in variants}
 for r in range(a.rounds + 1):
     for name, fn in variants:
