@@ -25,6 +25,7 @@ bool dvt_linear_big_ok(int m, int n, int k);
 bool dvt_linear_wgrad_big_ok(int rows, int n, int k);
 int dvt_linear_wgrad_big(const float* dy, const float* x, float* dw, float* db, int rows, int n, int k, int accumulate,
                          hipStream_t s);
+int g_s2_fork_wgrad = 1;  // DVT_S2_FORK_WGRAD=0 / dvt_tune_set(18, mask) bit 5: weight gradients on the caller's stream (A/B)
 int g_s2_attn_rows = 1;  // DVT_S2_ATTN_ROWS=0: the [Tp][Tp] products on the 64 x 64 GEMM tile + separate softmax passes (A/B)
 int g_s2_fuse_softmax_bwd = 1;  // DVT_S2_FUSE_SOFTMAX_BWD=0: dP written, s2_softmax_bwd_kernel over it (A/B)
 int g_s2_big_wgrad = 1;  // DVT_S2_BIG_WGRAD=0: the weight-gradient GEMMs on the 64 x 64 tile (A/B)
@@ -724,6 +725,20 @@ int lin_fwd(const float* x, const float* w, const float* b, float* y, int R, int
   g.bias = b;
   return dvt_gemm_f32_ex(&g, s);
 }
+// side stream + fork / join events of lin_bwd (created once per process, never destroyed; one trainer per process and device)
+hipStream_t g_s2_side = nullptr;
+hipEvent_t g_s2_ev_fork = nullptr, g_s2_ev_join = nullptr;
+bool s2_side_stream(hipStream_t* out) {
+  if (g_s2_side == nullptr) {
+    if (hipStreamCreateWithFlags(&g_s2_side, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&g_s2_ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_s2_ev_join, hipEventDisableTiming) != hipSuccess)
+      return false;
+  }
+  *out = g_s2_side;
+  return true;
+}
+
 // out[k][n] = in[n][k] (n, k multiples of 32): 32 x 32 tiles through LDS, both sides in whole 128-B row pieces
 __global__ __launch_bounds__(256) void s2_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int k) {
   __shared__ float tile[32][33];
@@ -741,8 +756,19 @@ __global__ __launch_bounds__(256) void s2_transpose_kernel(const float* __restri
 // 2 x 9 MB of traffic at most per layer, the GEMM 0.07-0.2 TFLOP.  Summation order differs from the 64 x 64 kernel only.
 int lin_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int R, int n, int k,
             hipStream_t s, float* wT = nullptr) {
+  // Round 6: the weight gradient and the data gradient of a layer are independent products of the same dy.  Their grids are a few
+  // rounds of the chip's 512 workgroup slots each (2112 tiles = 4.1 rounds for the 768-wide outputs: the last round is 1/8
+  // full), so the weight gradient goes to a side stream and the two fill each other's tails; joined before this returns (the
+  // caller's next kernels overwrite dy / x).
+  hipStream_t sw = s;
+  const bool fork = g_s2_fork_wgrad && dx != nullptr && s2_side_stream(&sw);
+  if (fork) {
+    if (hipEventRecord(g_s2_ev_fork, s) != hipSuccess || hipStreamWaitEvent(sw, g_s2_ev_fork, 0) != hipSuccess) return DVT_E_BADARG;
+  } else {
+    sw = s;
+  }
   if (g_s2_big_wgrad && dvt_linear_wgrad_big_ok(R, n, k)) {  // round 6: the weight gradient on the 128 x 128 tile too
-    S2_TRY(dvt_linear_wgrad_big(dy, x, dw, db, R, n, k, 1, s));
+    S2_TRY(dvt_linear_wgrad_big(dy, x, dw, db, R, n, k, 1, sw));
   } else {
     DvtGemmEx g{};
     g.layout = 2;
@@ -751,20 +777,25 @@ int lin_bwd(const float* dy, const float* x, const float* w, float* dx, float* d
     g.lda = n; g.ldb = k; g.ldc = k;
     g.colsum = db;
     g.accumulate = 1;
-    S2_TRY(dvt_gemm_f32_ex(&g, s));
+    S2_TRY(dvt_gemm_f32_ex(&g, sw));
   }
   if (!dx) return 0;
+  int rc = 0;
   if (wT && g_s2_big_bwd && n % 32 == 0 && k % 32 == 0 && dvt_linear_big_ok(R, k, n)) {
     hipLaunchKernelGGL(s2_transpose_kernel, dim3(k / 32, n / 32), dim3(256), 0, s, w, wT, n, k);
     DVT_CHECK_LAUNCH();
-    return dvt_linear_fwd_big(dy, wT, nullptr, dx, R, k, n, s);
+    rc = dvt_linear_fwd_big(dy, wT, nullptr, dx, R, k, n, s);
+  } else {
+    DvtGemmEx d{};
+    d.layout = 1;
+    d.A = dy; d.B = w; d.C = dx;
+    d.M = R; d.N = k; d.K = n;
+    d.lda = n; d.ldb = k; d.ldc = k;
+    rc = dvt_gemm_f32_ex(&d, s);
   }
-  DvtGemmEx d{};
-  d.layout = 1;
-  d.A = dy; d.B = w; d.C = dx;
-  d.M = R; d.N = k; d.K = n;
-  d.lda = n; d.ldb = k; d.ldc = k;
-  return dvt_gemm_f32_ex(&d, s);
+  if (fork && (hipEventRecord(g_s2_ev_join, sw) != hipSuccess || hipStreamWaitEvent(s, g_s2_ev_join, 0) != hipSuccess))
+    return DVT_E_BADARG;
+  return rc;
 }
 
 // The six (image, head)-batched attention products.  q/k/v live in qkv [R][3C] at column offsets 0 / C / 2C
@@ -945,17 +976,18 @@ extern "C" int64_t dvt_s2_workspace_bytes(const DvtS2Config* cfg, int batch, int
 }
 
 // dvt_tune_set(18, mask): the same switches from inside a process (tests / A/B tools): bit 0 forward layers, 1 data gradients,
-// 2 weight gradients on the 128 x 128 tile, 3 softmax fused into the attention products, 4 softmax backward without a dP pass;
-// 31 = default.  Results differ in summation order only.
+// 2 weight gradients on the 128 x 128 tile, 3 softmax fused into the attention products, 4 softmax backward without a dP pass,
+// 5 weight gradients on a side stream beside the data gradients; 63 = default.  Results differ in summation order only.
 static void s2_read_env();
 int dvt_s2_tune(int mask) {
-  if (mask < 0 || mask > 31) return DVT_E_BADARG;
+  if (mask < 0 || mask > 63) return DVT_E_BADARG;
   s2_read_env();  // (so that a later first call does not overwrite this)
   g_s2_big_fwd = mask & 1;
   g_s2_big_bwd = (mask >> 1) & 1;
   g_s2_big_wgrad = (mask >> 2) & 1;
   g_s2_attn_rows = (mask >> 3) & 1;
   g_s2_fuse_softmax_bwd = (mask >> 4) & 1;
+  g_s2_fork_wgrad = (mask >> 5) & 1;
   return 0;
 }
 
@@ -967,6 +999,8 @@ static void s2_read_env() {
   if (e && e[0] == '0') g_s2_big_fwd = 0;
   e = getenv("DVT_S2_BIG_BWD");
   if (e && e[0] == '0') g_s2_big_bwd = 0;
+  e = getenv("DVT_S2_FORK_WGRAD");
+  if (e && e[0] == '0') g_s2_fork_wgrad = 0;
   e = getenv("DVT_S2_ATTN_ROWS");
   if (e && e[0] == '0') g_s2_attn_rows = 0;
   e = getenv("DVT_S2_FUSE_SOFTMAX_BWD");

@@ -289,9 +289,10 @@ int dvt_render_views(const float* img, int H, int W, const int32_t* boxes, float
  *         -510 - mask (attention schedule masks; any of these also selects q as it is), -540 - x (the log2-domain attention kernel with bits x of
  *         its schedule mask toggled: 2 / 512 / 514 = P.V fragment by fragment / K reads unplaced / both; 128 / 256 / 384 = ablation
  *         builds: idle waves not skipped / no half tail tile / neither; -540 = the product's);
- * key 18 = stage-2 trainer (include/dvt_stage2.h), mask 0..31, 31 = default: bit 0 / 1 / 2 = forward / data-gradient / weight-gradient
+ * key 18 = stage-2 trainer (include/dvt_stage2.h), mask 0..63, 63 = default: bit 0 / 1 / 2 = forward / data-gradient / weight-gradient
  *         GEMMs of the linear layers on the 128 x 128 x 32 tile, bit 3 = softmax fused into the attention products, bit 4 = softmax
- *         backward without a dP pass (0 = round 5's flow); results differ in summation order only (tests/test_gpu_stage2.py);
+ *         backward without a dP pass, bit 5 = a layer's weight gradient on a side stream beside its data gradient (0 = round 5's
+ *         flow); results differ in summation order only (tests/test_gpu_stage2.py);
  * key 2 = grid backward: levels with more entries than `value` use global atomics (default 0 = all);
  * key 5 = fp32 GEMM k-depth of the register-staged kernel: 64 (default), 32, or 16 (10 KB LDS per
  *         workgroup, lets fit kernels co-reside with the ViT extractor's 136-144 KB workgroups);

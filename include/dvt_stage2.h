@@ -24,7 +24,9 @@
  * 128 x 128 x 32 exact-fp32 tile; the softmax is fused into the two [tokens_pad][tokens_pad]-sized attention products around it
  * (tokens_pad a multiple of 128, else the GEMM + softmax passes).  Environment switches of the process, read once, for A/B runs
  * only: DVT_S2_BIG=0 / DVT_S2_BIG_BWD=0 / DVT_S2_BIG_WGRAD=0 (64 x 64 tile for forward / data gradient / weight gradient),
- * DVT_S2_ATTN_ROWS=0 (GEMM + softmax passes), DVT_S2_FUSE_SOFTMAX_BWD=0 (with it: round 5's flow).
+ * DVT_S2_ATTN_ROWS=0 (GEMM + softmax passes), DVT_S2_FUSE_SOFTMAX_BWD=0 (with it: round 5's flow), DVT_S2_FORK_WGRAD=0 (a layer's
+ * weight gradient on the caller's stream instead of a side stream beside its data gradient; the side stream and its two events
+ * are created once per process).
  *
  * Conventions as in dvt_hip.h: int return codes (0 = ok, DVT_E_* / hipError_t otherwise), device pointers
  * owned by the caller, `stream` is a hipStream_t, nothing synchronises.

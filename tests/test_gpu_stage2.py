@@ -79,30 +79,30 @@ def test_step_gradients_vs_autograd(h, w, c, blocks, batch):
 
 
 def test_step_kernel_choices_agree(built_lib):
-    """Round 6: the step at the metric's shape (37 x 37 x 768) under every kernel choice of dvt_tune_set(18, mask) -- 31 = default:
+    """Round 6: the step at the metric's shape (37 x 37 x 768) under every kernel choice of dvt_tune_set(18, mask) -- 63 = default:
     linear layers' forward / data- / weight-gradient GEMMs on the 128 x 128 tile, softmax fused into the attention products
-    (s2_attn_rows_kernel); 0 = round 5's flow (64 x 64 tile, GEMM + softmax passes) -- gives the same loss and gradients up to
+    (s2_attn_rows_kernel), weight gradients on a side stream beside the data gradients; 0 = round 5's flow (64 x 64 tile, GEMM + softmax passes) -- gives the same loss and gradients up to
     summation order; each choice is also held against autograd by test_step_gradients_vs_autograd under the default."""
     ref, mine = make_pair(37, 37, 768, 1, seed=3)
     torch.manual_seed(4)
     x, t = torch.randn(2, 37, 37, 768, device=DEV), torch.randn(2, 37, 37, 768, device=DEV)
     out = {}
     try:
-        for mask in (31, 0, 7, 24, 16):
+        for mask in (63, 0, 7, 24, 16, 31, 32):
             assert built_lib.dvt_tune_set(18, mask) == 0
             mine.engine.grads.zero_()
             loss = mine.training_step(x, t).cpu().clone()
             out[mask] = (loss, mine.engine.grads.clone())
     finally:
-        assert built_lib.dvt_tune_set(18, 31) == 0
-    assert built_lib.dvt_tune_set(18, 32) == -1
+        assert built_lib.dvt_tune_set(18, 63) == 0
+    assert built_lib.dvt_tune_set(18, 64) == -1
     base_loss, base_g = out[0]
     for mask, (loss, g) in out.items():
         assert abs(float(loss[0] - base_loss[0])) < 1e-6 * abs(float(base_loss[0])), mask
         r = rel(g, base_g)
         print(f"[stage-2 kernel choices] mask {mask:2d}: gradient arena rel-L2 vs round 5's flow {r:.2e}")
         assert r < 5e-6, (mask, r)
-    assert not torch.equal(out[31][1], base_g)  # (the choices really are different kernels)
+    assert not torch.equal(out[63][1], base_g)  # (the choices really are different kernels)
 
 
 def test_adamw_vs_torch():
