@@ -913,9 +913,15 @@ int run(const DvtS2Config* c, const float* params, float* grads, const float* x,
     // attention: x1 = xin + proj(attn(norm1(xin)))
     S2_TRY(lin_bwd(w.d1, k.ao, P(b, PROJW), w.d2, G(b, PROJW), G(b, PROJB), R, C, C, s, w.wT));  // d2 = d ao
     {
-      // dV = P^T dao
+      // dV = P^T dao -- independent of the dS chain below (both read P and dao): on the side stream beside it (round 6, as the weight
+      // gradients in lin_bwd); dq and dk, two products of the same dS, likewise.  Joined before lin_bwd reads dqkv.
+      hipStream_t sv = s;
+      const bool fork = g_s2_fork_wgrad && s2_side_stream(&sv);
+      if (!fork) sv = s;
+      if (fork && (hipEventRecord(g_s2_ev_fork, s) != hipSuccess || hipStreamWaitEvent(sv, g_s2_ev_fork, 0) != hipSuccess))
+        return DVT_E_BADARG;
       DvtGemmEx g = attn_gemm(ad, 2, k.P, Tp, ps0, ps1, w.d2, C, os0, os1, w.dqkv + 2 * C, 3 * C, qs0, qs1, Tp, 64, Tp);
-      S2_TRY(dvt_gemm_f32_ex(&g, s));
+      S2_TRY(dvt_gemm_f32_ex(&g, sv));
       // dP = dao v^T, and the softmax backward dS = scale P (.) (dP - rowsum(dP (.) P)).  Round 6: rowsum(dP (.) P) = dao . ao per
       // (image, head, query) comes from the two [R][C] tensors (s2_rowdot_kernel) and the backward is the EPILOGUE of the dP
       // product -- dP is never written, P read once (before: 3 GB written + 9 GB read + 3 GB written by s2_softmax_bwd_kernel)
@@ -938,11 +944,15 @@ int run(const DvtS2Config* c, const float* params, float* grads, const float* x,
         hipLaunchKernelGGL(s2_softmax_bwd_kernel, dim3(dvt_cdiv(rowsP, 4)), dim3(256), 0, s, (const float*)k.P, w.dP, Tp, rowsP, scale);
         DVT_CHECK_LAUNCH();
       }
-      // dq = dS k,  dk = dS^T q
+      // dq = dS k (main stream),  dk = dS^T q (side stream: behind dV there, and behind dS here)
+      if (fork && (hipEventRecord(g_s2_ev_fork, s) != hipSuccess || hipStreamWaitEvent(sv, g_s2_ev_fork, 0) != hipSuccess))
+        return DVT_E_BADARG;
       g = attn_gemm(ad, 1, w.dP, Tp, ps0, ps1, k.qkv + C, 3 * C, qs0, qs1, w.dqkv, 3 * C, qs0, qs1, Tp, 64, Tp);
       S2_TRY(dvt_gemm_f32_ex(&g, s));
       g = attn_gemm(ad, 2, w.dP, Tp, ps0, ps1, k.qkv, 3 * C, qs0, qs1, w.dqkv + C, 3 * C, qs0, qs1, Tp, 64, Tp);
-      S2_TRY(dvt_gemm_f32_ex(&g, s));
+      S2_TRY(dvt_gemm_f32_ex(&g, sv));
+      if (fork && (hipEventRecord(g_s2_ev_join, sv) != hipSuccess || hipStreamWaitEvent(s, g_s2_ev_join, 0) != hipSuccess))
+        return DVT_E_BADARG;
     }
     S2_TRY(lin_bwd(w.dqkv, k.xn1, P(b, QKVW), w.d2, G(b, QKVW), G(b, QKVB), R, 3 * C, C, s, w.wT));
     S2_TRY(ln_bwd(C, w.d2, k.xin, k.mean1, k.rstd1, P(b, N1W), w.d1, w.d0, G(b, N1W), G(b, N1B), R, s));  // d0 = d xin
